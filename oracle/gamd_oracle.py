@@ -1,0 +1,273 @@
+"""CPU oracle for GAMD's force-inference hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a plain PyTorch (CPU, fp32) restatement
+of the reference algorithm; it exists to *check* the HIP path and to be timed
+as the "reference CPU path" (`bench.py` -> `cpu_baseline`, kind "port").  Only
+`tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may
+import it.  The product package `gamd_amd/` never does.
+
+Pinning: the reference ships no golden vectors or tests for this path
+(SURVEY.md §4), so the oracle is pinned against outputs of the reference's own
+`code/nn_module.py` / `code/md_module.py` executed in the build container
+(`oracle/make_golden.py` -> `tests/golden/*.npz`, checked by
+`tests/test_oracle_golden.py`).  The neighbour semantics of the jax-md path
+(third-party: jax-md unpinned "latest" + jax/jaxlib 0.1.67, DGL 0.7.0 — none
+vendored under /root/reference) are restated from the reference's call-site
+arguments (graph_utils.py:21-25,51-61): edge set = {(i,j): |minimg(r_j-r_i)|^2 <
+rc^2}, self pair included.  That part is "parity unpinned" by any executable
+reference.
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference/code).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------
+# neighbour search
+# --------------------------------------------------------------------------
+def _min_image(d: Tensor, box: Tensor) -> Tensor:
+    """nn_module.py:617-621 / md_module.py:66: remainder(d + L/2, L) - L/2 in fp32."""
+    half = 0.5 * box
+    return torch.remainder(d + half, box) - half
+
+
+def _box_tensor(box, dtype=torch.float32) -> Tensor:
+    """Scalar or per-axis box -> fp32 tensor [3] (nn_module.py:591-594)."""
+    b = torch.as_tensor(np.asarray(box, dtype=np.float64)).to(dtype).reshape(-1)
+    if b.numel() == 1:
+        b = b.repeat(3)
+    return b
+
+
+def neighbor_edges(pos: Tensor, box, cutoff: float, flavour: str = "jaxmd",
+                   block: int = 1024) -> Tensor:
+    """All-pairs periodic radius search, blocked so it stays O(block*N) in memory.
+
+    flavour "jaxmd": graph_utils.py:21-25 (mask_self=False -> self pair kept) and
+        graph_utils.py:51-61 (mask = dr^2 < cutoff^2, strict).  Edge order is
+        row-major (centre i, then neighbour j ascending); the reference's order
+        is (i, slot) (train_network_lj.py:166-185) — the *set* is what matters.
+    flavour "torch": md_module.py:93-126 (norm <= cutoff, self excluded).
+        Returned rows follow md_module.py:121: row0 = column index b, row1 = row
+        index a, with distance = pos[b]-pos[a]; order is (a major, b minor).
+
+    Returns LongTensor [2, E]: row0 = centre, row1 = neighbour (flavour jaxmd).
+    """
+    pos = pos.to(torch.float32)
+    n = pos.shape[0]
+    boxt = _box_tensor(box)
+    rc2 = torch.tensor(float(cutoff) ** 2, dtype=torch.float32)
+    rc = torch.tensor(float(cutoff), dtype=torch.float32)
+    rows, cols = [], []
+    for s in range(0, n, block):
+        e = min(n, s + block)
+        if flavour == "jaxmd":
+            # displacement(pos_i, pos_j) ; symmetric in |.|^2
+            d = _min_image(pos[s:e, None, :] - pos[None, :, :], boxt)
+            m = (d * d).sum(-1) < rc2
+        else:
+            # md_module.py:65: dist_mat[a, b] = pos[b] - pos[a]
+            d = _min_image(pos[None, :, :] - pos[s:e, None, :], boxt)
+            m = torch.norm(d, dim=-1) <= rc
+            idx = torch.arange(s, e)
+            m[idx - s, idx] = False
+        a, b = torch.nonzero(m, as_tuple=True)
+        rows.append(a + s)
+        cols.append(b)
+    a = torch.cat(rows)
+    b = torch.cat(cols)
+    if flavour == "jaxmd":
+        return torch.stack([a, b]).long()
+    return torch.stack([b, a]).long()
+
+
+# --------------------------------------------------------------------------
+# model pieces
+# --------------------------------------------------------------------------
+def rbf_centers(low: float = 0.0, high: float = 1.0, gap: float = 0.025) -> Tuple[Tensor, float]:
+    """nn_module.py:237-240: ceil((high-low)/gap) centres via linspace; gamma = 1/gap."""
+    num = int(np.ceil((high - low) / gap))
+    return torch.tensor(np.linspace(low, high, num)).float(), 1.0 / gap
+
+
+def mlp(sd: Dict[str, Tensor], prefix: str, x: Tensor, act: str,
+        hidden_layer: int, activation_first: bool = False) -> Tensor:
+    """nn_module.py:48-65: Sequential layout of MLP; indices are positions in
+    the nn.Sequential (activations occupy slots and have no parameters)."""
+    fn = {"gelu": F.gelu, "silu": F.silu}[act]
+
+    def lin(i, v):
+        return F.linear(v, sd[f"{prefix}.mlp_layer.{i}.weight"], sd[f"{prefix}.mlp_layer.{i}.bias"])
+
+    if hidden_layer == 3 and not activation_first:       # Lin,act,Lin,act,Lin
+        return lin(4, fn(lin(2, fn(lin(0, x)))))
+    if hidden_layer == 2 and not activation_first:       # Lin,act,Lin
+        return lin(2, fn(lin(0, x)))
+    if hidden_layer == 2 and activation_first:           # act,Lin,act,Lin
+        return lin(3, fn(lin(1, fn(x))))
+    if hidden_layer == 1 and activation_first:           # act,Lin
+        return lin(1, fn(x))
+    raise ValueError("unsupported MLP layout")
+
+
+def linear(sd, prefix, x):
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def layer_norm(sd, prefix, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
+
+
+def edge_features(sd: Dict[str, Tensor], pos: Tensor, center: Tensor, neigh: Tensor, box) -> Tensor:
+    """nn_module.py:603-634 (= :462-493): rel = pos[neigh]-pos[center], min-image,
+    norm, unit vector r/(n+1e-8), standardised length, RBF of the standardised
+    length (nn_module.py:248-263)."""
+    boxt = _box_tensor(box)
+    rel = pos[neigh] - pos[center]
+    rel = _min_image(rel, boxt)
+    nrm = rel.norm(dim=1).view(-1, 1)
+    unit = rel / (nrm + 1e-8)
+    d = (nrm - sd["length_mean"]) / sd["length_std"]
+    centers = sd["edge_expand.centers"]
+    gamma = 1.0 / 0.025
+    radial = d - centers
+    rbf = torch.exp(-gamma * (radial ** 2))
+    return torch.cat((unit, d, rbf), dim=1)
+
+
+def edge_features_from_dist(sd, distance: Tensor, distance_norm: Tensor) -> Tensor:
+    """nn_module.py:322-336 (dynamic box): sign flip -distance/(norm+1e-8)."""
+    nrm = distance_norm.view(-1, 1)
+    unit = -distance / (nrm + 1e-8)
+    d = (nrm - sd["length_mean"]) / sd["length_std"]
+    radial = d - sd["edge_expand.centers"]
+    rbf = torch.exp(-(1.0 / 0.025) * (radial ** 2))
+    return torch.cat((unit, d, rbf), dim=1)
+
+
+def bond_flags(center: Tensor, neigh: Tensor, bond: np.ndarray) -> Tensor:
+    """nn_module.py:510 + :529-534: bond graph = bonds + reversed bonds;
+    has_edges_between(center, neigh) -> bool[E]."""
+    b = torch.as_tensor(np.asarray(bond)).long()
+    n = int(max(b.max(), center.max(), neigh.max())) + 1
+    key = torch.cat([b[:, 0] * n + b[:, 1], b[:, 1] * n + b[:, 0]])
+    return torch.isin(center * n + neigh, key)
+
+
+def conv_layer(sd, p: str, e: Tensor, hn: Tensor, src: Tensor, dst: Tensor) -> Tensor:
+    """SmoothConvLayerNew.forward, nn_module.py:108-148, op for op (Linear on E
+    gathered rows, as written)."""
+    edge_code = mlp(sd, p + ".edge_affine", e, "silu", 2)                     # :135
+    src_code = linear(sd, p + ".src_affine", hn[src])                          # :136
+    dst_code = linear(sd, p + ".dst_affine", hn[dst])                          # :137
+    e_emb = mlp(sd, p + ".theta_edge", edge_code + src_code + dst_code, "silu", 2, True)  # :138
+    agg = torch.zeros_like(hn)
+    agg.index_add_(0, dst, hn[src] * e_emb)                                    # :142 u_mul_e -> sum
+    return mlp(sd, p + ".phi", linear(sd, p + ".phi_dst", hn) + linear(sd, p + ".phi_edge", agg),
+               "silu", 1, True)                                                # :147
+
+
+def n_conv_layers(sd) -> int:
+    n = 0
+    while f"graph_conv.conv.{n}.src_affine.weight" in sd:
+        n += 1
+    return n
+
+
+@torch.no_grad()
+def forward(sd: Dict[str, Tensor], pos: Tensor, edge_idx: Tensor, box,
+            feat: Optional[Tensor] = None, bond: Optional[np.ndarray] = None,
+            stages: Optional[dict] = None) -> Tensor:
+    """SimpleMDNetNew.forward (nn_module.py:672-685) when `feat` is None, else
+    WaterMDNetNew.forward (nn_module.py:545-558).  edge_idx rows: centre, neighbour.
+    Returns the *normalised* force [N,3]."""
+    center, neigh = edge_idx[0].long(), edge_idx[1].long()
+    src, dst = neigh, center                                                   # :643 dgl.graph((neigh, center))
+    f = edge_features(sd, pos, center, neigh, box)                             # :644
+    if bond is not None:
+        f = torch.cat((f, bond_flags(center, neigh, bond).view(-1, 1).to(f.dtype)), dim=1)   # :510-511
+    e = layer_norm(sd, "edge_layer_norm", mlp(sd, "edge_encoder", f, "gelu", 3))  # :646
+    n = pos.shape[0]
+    if feat is None:
+        h = sd["node_emb"].repeat((n, 1))                                      # :681
+    else:
+        h = linear(sd, "node_encoder", feat)                                   # :554
+    if stages is not None:
+        stages["feat"], stages["e"], stages["h"] = f, e, [h]
+    for l in range(n_conv_layers(sd)):                                         # :200-202
+        hn = layer_norm(sd, f"graph_conv.norm_layers.{l}", h)
+        h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst) + h
+        if stages is not None:
+            stages["h"].append(h)
+    return mlp(sd, "graph_decoder", h, "gelu", 2)                              # :684
+
+
+@torch.no_grad()
+def forward_dynamic_box(sd, pos: Tensor, feat: Tensor, box, cutoff: float,
+                        stages: Optional[dict] = None) -> Tensor:
+    """WaterMDDynamicBoxNet.forward, nn_module.py:391-407 with build_graph
+    :338-365 (md_module.get_neighbor: <=, no self; bond=None configs)."""
+    edge_idx = neighbor_edges(pos, box, cutoff, "torch")
+    center, neigh = edge_idx[0], edge_idx[1]
+    boxt = _box_tensor(box)
+    dist = _min_image(pos[center] - pos[neigh], boxt)       # md_module.py:65,121: pos[b]-pos[a], b=row0
+    f = edge_features_from_dist(sd, dist, dist.norm(dim=1))
+    e = layer_norm(sd, "edge_layer_norm", mlp(sd, "edge_encoder", f, "gelu", 3))
+    h = linear(sd, "node_encoder", feat)
+    src, dst = neigh, center
+    if stages is not None:
+        stages["feat"], stages["e"], stages["h"], stages["edge_idx"] = f, e, [h], edge_idx
+    for l in range(n_conv_layers(sd)):
+        hn = layer_norm(sd, f"graph_conv.norm_layers.{l}", h)
+        h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst) + h
+        if stages is not None:
+            stages["h"].append(h)
+    return mlp(sd, "graph_decoder", h, "gelu", 2)
+
+
+def denormalize(pred: np.ndarray, var: np.ndarray, mean: np.ndarray) -> np.ndarray:
+    """train_network_lj.py:128-131: pred*sqrt(var)+mean with f64 scaler scalars."""
+    return pred * np.sqrt(var) + mean
+
+
+@torch.no_grad()
+def predict_forces(sd, pos: np.ndarray, box: float, cutoff: float,
+                   var=np.array([1.0]), mean=np.array([0.0]),
+                   feat: Optional[Tensor] = None, bond=None) -> np.ndarray:
+    """ParticleNetLightning.predict_forces, LJ/train_network_lj.py:133-157 (and
+    water/train_network_tip3p.py:142-159): neighbour search on the f32 cast of the
+    raw positions, np.mod in f64, f32 forward, f64 denormalise."""
+    pos32 = torch.from_numpy(np.asarray(pos)).float()
+    # graph_utils.py:31: the searcher wraps with jnp.mod in f32
+    edge_idx = neighbor_edges(torch.remainder(pos32, _box_tensor(box)), box, cutoff, "jaxmd")
+    posw = torch.from_numpy(np.mod(np.asarray(pos, dtype=np.float64), np.array(box))).float()
+    pred = forward(sd, posw, edge_idx, box, feat=feat, bond=bond).numpy()
+    return denormalize(pred, var, mean)
+
+
+# --------------------------------------------------------------------------
+# integrator: the split BAOAB scheme of hack_integrator.py
+# --------------------------------------------------------------------------
+def baoab_first_half(x, v, f_last, inv_m, dt, a, b_sigma, noise):
+    """HackLangevinIntegrator, hack_integrator.py:141-165 without constraints:
+    B: v += dt/2 f/m ; A: x += dt/2 v ; O: v = a v + b sigma xi ; A: x += dt/2 v."""
+    v = v + (0.5 * dt) * f_last * inv_m
+    x = x + (0.5 * dt) * v
+    v = a * v + b_sigma * noise
+    x = x + (0.5 * dt) * v
+    return x, v
+
+
+def baoab_second_half(v, f, inv_m, dt):
+    """HackHalfVelocityIntegrator, hack_integrator.py:171-178: v += dt/2 f/m."""
+    return v + (0.5 * dt) * f * inv_m

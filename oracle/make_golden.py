@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own
+modules (`/root/reference/code/nn_module.py`, `md_module.py`) on CPU in the
+build container, through the stub dgl/jax modules of `oracle/ref_stubs.py`.
+
+TEST INFRASTRUCTURE ONLY; runs only where /root/reference exists (never on the
+GPU box).  The reference source is imported in place, never copied.  What is
+committed is data: inputs (positions that are not reproducible from a seed),
+seeds, and the reference's outputs.
+
+Weights are not stored: every case loads `gamd_amd.weights.make_state_dict(cfg,
+seed)` into the reference module with `load_state_dict(strict=True)` — which
+also proves our key names / shapes equal the reference's — so tests rebuild the
+identical weights from the seed.
+
+Usage:  python oracle/make_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ref_stubs  # noqa: E402
+from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS  # noqa: E402
+import gamd_oracle as orc  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def water_bond(n):
+    """create_water_bond, water/train_network_tip3p.py:38-42 (restated)."""
+    return np.array([[i, i + k] for i in range(0, n, 3) for k in (1, 2)])
+
+
+def jaxmd_edge_set(pos32: torch.Tensor, box: float, cutoff: float) -> torch.Tensor:
+    """Edge set of the jax-md path, restated from the call-site arguments
+    (graph_utils.py:21-25,51-61): no executable reference exists here, so the
+    same restatement as the oracle is used and only the *model* outputs on that
+    edge set come from the reference module."""
+    return orc.neighbor_edges(pos32, box, cutoff, "jaxmd")
+
+
+def margin_to_cutoff(pos32, box, cutoff):
+    boxt = orc._box_tensor(box)
+    d = orc._min_image(pos32[:, None, :] - pos32[None, :, :], boxt).norm(dim=-1)
+    return float((d - cutoff).abs().min())
+
+
+def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=None,
+                  bond=None, lmean=4.0, lstd=1.5, keep_h=True, edge_stride=1):
+    torch.manual_seed(1234)
+    sd = make_state_dict(cfg, seed, lmean, lstd)
+    if cfg.kind == "lj":
+        m = nn_module.SimpleMDNetNew(encoding_size=cfg.encoding_size, out_feats=3, box_size=box,
+                                     hidden_dim=cfg.hidden_dim, conv_layer=cfg.conv_layer,
+                                     edge_embedding_dim=cfg.edge_embedding_dim, drop_edge=False,
+                                     use_layer_norm=True)
+    else:
+        m = nn_module.WaterMDNetNew(in_feats=1, encoding_size=cfg.encoding_size, out_feats=3,
+                                    box_size=box, bond=torch.as_tensor(bond) if bond is not None else None,
+                                    hidden_dim=cfg.hidden_dim, conv_layer=cfg.conv_layer,
+                                    edge_embedding_dim=cfg.edge_embedding_dim, drop_edge=False,
+                                    use_layer_norm=True)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    # predict_forces front end (LJ/train_network_lj.py:135-142), restated
+    pos64 = np.asarray(pos, dtype=np.float64)
+    pos32 = torch.from_numpy(pos64).float()
+    edge_idx = jaxmd_edge_set(torch.remainder(pos32, orc._box_tensor(box)), box, cutoff)
+    posw = torch.from_numpy(np.mod(pos64, np.array(box))).float()
+    margin = margin_to_cutoff(posw, box, cutoff)
+    # fp32 distance error is a few ulp (~2e-6 at 10 A); 2e-5 keeps edge membership unambiguous
+    assert margin > 2e-5, f"{name}: a pair sits {margin} from the cutoff"
+
+    # capture per-stage tensors from the real module with forward hooks
+    cap = {}
+    m.edge_layer_norm.register_forward_hook(lambda mod, i, o: cap.__setitem__("e", o.detach().clone()))
+    m.edge_encoder.register_forward_hook(lambda mod, i, o: cap.__setitem__("feat", i[0].detach().clone()))
+    # residual stream h at the start of every layer (input of norm_layers[l]; the block
+    # calls conv.forward() directly so conv hooks never fire) and after the last one
+    hs = []
+    for norm in m.graph_conv.norm_layers:
+        norm.register_forward_hook(lambda mod, i, o: hs.append(i[0].detach().clone()))
+    m.graph_decoder.register_forward_hook(lambda mod, i, o: hs.append(i[0].detach().clone()))
+    with torch.no_grad():
+        if cfg.kind == "lj":
+            out = m([posw], [edge_idx])
+        else:
+            out = m([posw], feat, [edge_idx])
+    out = out.numpy()
+    mean, var = scaler
+    forces = out * np.sqrt(var) + mean          # denormalize, train_network_lj.py:128-131
+    rec = dict(pos=pos64, box=np.float64(box), cutoff=np.float64(cutoff), seed=np.int64(seed),
+               length_mean=np.float64(lmean), length_std=np.float64(lstd),
+               edge_idx=edge_idx.numpy().astype(np.int32),
+               edge_stride=np.int64(edge_stride),
+               feat_rows=cap["feat"].numpy()[::edge_stride],
+               e_rows=cap["e"].numpy()[::edge_stride],
+               out_norm=out, forces=forces, scaler_mean=mean, scaler_var=var,
+               margin=np.float64(margin),
+               cfg=np.array([cfg.kind, str(cfg.encoding_size), str(cfg.hidden_dim),
+                             str(cfg.edge_embedding_dim), str(cfg.conv_layer), str(int(cfg.use_bond))]))
+    if keep_h:
+        # h_0 .. h_L — enough to localise a diff to one layer
+        rec["h_layers"] = np.stack([h.numpy() for h in hs])
+    if feat is not None:
+        rec["node_feat"] = feat.numpy()
+    if bond is not None:
+        rec["bond"] = np.asarray(bond, dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: N={pos64.shape[0]} E={edge_idx.shape[1]} margin={margin:.2e} "
+          f"|F|max={np.abs(forces).max():.4g}")
+
+
+def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, lstd):
+    sd = make_state_dict(cfg, seed, lmean, lstd)
+    m = nn_module.WaterMDDynamicBoxNet(in_feats=1, encoding_size=cfg.encoding_size, out_feats=3,
+                                       bond=None, hidden_dim=cfg.hidden_dim, conv_layer=cfg.conv_layer,
+                                       edge_embedding_dim=cfg.edge_embedding_dim, drop_edge=False,
+                                       use_layer_norm=True, update_edge=False, expand_edge=True)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    pos32 = torch.from_numpy(np.asarray(pos)).float()
+    n = pos32.shape[0]
+    feat = torch.zeros(n, 1)
+    feat[::3] = 1.0
+    boxa = np.asarray(box, dtype=np.float32)
+    # the reference's own O(N^2) search (md_module.py:93-126), executed as is
+    edge_idx, dist, dist_norm, _ = md_module.get_neighbor(pos32, cutoff, torch.from_numpy(boxa))
+    with torch.no_grad():
+        out = m([pos32], feat, [boxa], cutoff).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        pos=pos32.numpy(), box=boxa, cutoff=np.float64(cutoff), seed=np.int64(seed),
+                        length_mean=np.float64(lmean), length_std=np.float64(lstd),
+                        edge_idx=edge_idx.numpy().astype(np.int32), dist_norm=dist_norm.numpy(),
+                        node_feat=feat.numpy(), out_norm=out,
+                        cfg=np.array([cfg.kind, str(cfg.encoding_size), str(cfg.hidden_dim),
+                                      str(cfg.edge_embedding_dim), str(cfg.conv_layer), "0"]))
+    print(f"{name}: N={n} E={edge_idx.shape[1]}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    nn_module, md_module = ref_stubs.import_reference(REF)
+    lj_pos = np.load(os.path.join(REF, "code/LJ/init_pos.npy"))          # [258,3] f32, in [0, 27.22]
+    w_pos = np.load(os.path.join(REF, "code/water/init_pos.npy"))        # [774,3] f64, centred
+    full = dict(encoding_size=128, hidden_dim=128, edge_embedding_dim=128, conv_layer=4)
+
+    # C1: the reference's own LJ snapshot, shipped LJ scaler, full-size model
+    run_fixed_box(nn_module, "lj258_seed0", ModelConfig(kind="lj", **full), 0, lj_pos, 27.27, 7.5,
+                  SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, edge_stride=29)
+    # perturbed, partly un-wrapped copy: exercises the np.mod / jnp.mod wraps
+    rng = np.random.default_rng(7)
+    pert = lj_pos.astype(np.float64) + rng.normal(0, 0.35, lj_pos.shape) + np.array([27.27, -27.27, 0.0])
+    run_fixed_box(nn_module, "lj258_pert_seed1", ModelConfig(kind="lj", **full), 1, pert, 27.27, 7.5,
+                  SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, keep_h=False, edge_stride=101)
+    # reduced-width toy (fast unit tests of the oracle's genericity)
+    toy = rng.uniform(0, 12.0, (64, 3))
+    run_fixed_box(nn_module, "lj64_h32", ModelConfig(kind="lj", encoding_size=32, hidden_dim=32,
+                                                     edge_embedding_dim=32, conv_layer=2),
+                  2, toy, 12.0, 3.9, (np.array([0.0]), np.array([1.0])), lmean=2.5, lstd=0.8)
+    # TIP3P snapshot: bonds + species feature (water/train_network_tip3p.py, test_nosehoover.py:82-89)
+    n = w_pos.shape[0]
+    feat = torch.zeros(n, 1)
+    feat[::3] = 1.0
+    run_fixed_box(nn_module, "tip3p774_seed3", ModelConfig(kind="water", use_bond=True, **full), 3,
+                  w_pos, 20.0, 4.2, SHIPPED_SCALERS["tip3p"], feat=feat, bond=water_bond(n),
+                  lmean=2.9, lstd=1.1, edge_stride=53)
+    # dynamic-box flavour (md_module.get_neighbor: <=, no self; orthorhombic box)
+    sub = np.mod(w_pos[:384], 20.0)
+    run_dynbox(nn_module, md_module, "dynbox384_seed4", ModelConfig(kind="dynbox", **full), 4,
+               sub, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
+    run_dynbox(nn_module, md_module, "dynbox384_dftcfg_seed5",
+               ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256,
+                           conv_layer=5), 5, sub, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
+
+
+if __name__ == "__main__":
+    main()

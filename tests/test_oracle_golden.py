@@ -1,0 +1,76 @@
+"""Pin the CPU oracle (oracle/gamd_oracle.py) against outputs of the reference's
+own modules (tests/golden/*.npz, produced by oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import gamd_oracle as orc
+from helpers import load_golden, rel_err, edge_set
+
+FIXED = ["lj258_seed0", "lj258_pert_seed1", "lj64_h32", "tip3p774_seed3"]
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_forward_matches_reference(name):
+    g, cfg, sd = load_golden(name)
+    box, rc = float(g["box"]), float(g["cutoff"])
+    posw = torch.from_numpy(np.mod(g["pos"], box)).float()
+    edge_idx = torch.from_numpy(g["edge_idx"]).long()
+    feat = torch.from_numpy(g["node_feat"]) if "node_feat" in g else None
+    bond = g["bond"] if "bond" in g else None
+    st = {}
+    out = orc.forward(sd, posw, edge_idx, box, feat=feat, bond=bond, stages=st).numpy()
+    s = int(g["edge_stride"])
+    # same ops in the same order -> (near) bit-equal; thresholds leave room for BLAS blocking
+    assert rel_err(st["feat"].numpy()[::s], g["feat_rows"]) < 1e-6
+    assert rel_err(st["e"].numpy()[::s], g["e_rows"]) < 5e-6
+    if "h_layers" in g:
+        for l, h in enumerate(st["h"]):
+            assert rel_err(h.numpy(), g["h_layers"][l]) < 5e-6, f"layer {l}"
+    assert rel_err(out, g["out_norm"]) < 5e-6
+    forces = orc.denormalize(out, g["scaler_var"], g["scaler_mean"])
+    assert forces.dtype == np.float64
+    assert rel_err(forces, g["forces"]) < 5e-6
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_predict_forces_front_end(name):
+    """np.mod / f32 cast / neighbour search / denormalise (train_network_lj.py:133-157)."""
+    g, cfg, sd = load_golden(name)
+    feat = torch.from_numpy(g["node_feat"]) if "node_feat" in g else None
+    bond = g["bond"] if "bond" in g else None
+    f = orc.predict_forces(sd, g["pos"], float(g["box"]), float(g["cutoff"]),
+                           var=g["scaler_var"], mean=g["scaler_mean"], feat=feat, bond=bond)
+    assert f.shape == g["forces"].shape and f.dtype == np.float64
+    assert rel_err(f, g["forces"]) < 5e-6
+
+
+def test_neighbor_semantics_jaxmd():
+    """self pair kept, strict '<' (graph_utils.py:25,59)."""
+    pos = torch.tensor([[0.0, 0, 0], [3.0, 0, 0], [9.5, 0, 0], [5.0, 5.0, 5.0]])
+    e = orc.neighbor_edges(pos, 10.0, 3.0, "jaxmd").numpy()
+    pairs = set(map(tuple, e.T))
+    assert {(i, i) for i in range(4)} <= pairs          # self edges
+    assert (0, 1) not in pairs                          # |r| == rc is excluded by '<'
+    assert (0, 2) in pairs and (2, 0) in pairs          # periodic image, distance 0.5
+    assert len(pairs) == 6
+
+
+@pytest.mark.parametrize("name", ["dynbox384_seed4", "dynbox384_dftcfg_seed5"])
+def test_dynamic_box_matches_reference(name):
+    """md_module.get_neighbor executed as-is (<=, no self, per-axis box) and
+    WaterMDDynamicBoxNet.forward."""
+    g, cfg, sd = load_golden(name)
+    pos = torch.from_numpy(g["pos"])
+    st = {}
+    out = orc.forward_dynamic_box(sd, pos, torch.from_numpy(g["node_feat"]), g["box"],
+                                  float(g["cutoff"]), stages=st).numpy()
+    assert np.array_equal(st["edge_idx"].numpy(), g["edge_idx"].astype(np.int64))   # same order too
+    assert not np.any(g["edge_idx"][0] == g["edge_idx"][1])
+    assert rel_err(out, g["out_norm"]) < 5e-6
+
+
+def test_state_dict_spec_counts():
+    from gamd_amd.weights import ModelConfig, state_dict_spec
+    n = sum(int(np.prod(s)) for s in state_dict_spec(ModelConfig(kind="lj")).values())
+    assert n == 651565          # SURVEY.md §8a parameter inventory (incl. buffers-as-params)
