@@ -1,0 +1,79 @@
+"""ctypes binding of libgamd_hip.so (C ABI: include/gamd_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or no GPU is
+present, loading / gamd_create fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgamd_hip.so")
+
+
+class GamdConfig(C.Structure):
+    _fields_ = [("n_atoms", C.c_int32), ("kind", C.c_int32), ("n_layers", C.c_int32),
+                ("use_bond", C.c_int32), ("nbr_flavour", C.c_int32), ("device", C.c_int32),
+                ("cutoff", C.c_float), ("box", C.c_float * 3), ("edge_capacity", C.c_int64),
+                ("keep_stages", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GamdMdParams(C.Structure):
+    _fields_ = [("dt_ps", C.c_float), ("mass_amu", C.c_float), ("temperature_k", C.c_float),
+                ("gamma_per_ps", C.c_float), ("seed", C.c_uint64), ("first_step", C.c_uint64)]
+
+
+# every symbol include/gamd_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+SYMBOLS = {
+    "gamd_version": (C.c_char_p, []),
+    "gamd_last_error": (C.c_char_p, []),
+    "gamd_create": (_i32, [C.POINTER(GamdConfig), C.POINTER(_vp)]),
+    "gamd_destroy": (_i32, [_vp]),
+    "gamd_load_weight": (_i32, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i32]),
+    "gamd_finalize_weights": (_i32, [_vp]),
+    "gamd_set_scaler": (_i32, [_vp, C.c_double, C.c_double]),
+    "gamd_set_bonds": (_i32, [_vp, _vp, _i64]),
+    "gamd_forces_async": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp]),
+    "gamd_sync_status": (_i32, [_vp, _vp]),
+    "gamd_forces": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp]),
+    "gamd_build_neighbors": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp]),
+    "gamd_get_counts": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "gamd_debug_get": (_i32, [_vp, _i32, _vp, C.c_size_t]),
+    "gamd_md_run": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(GamdMdParams), _i64, _vp]),
+    "gamd_profile": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, C.c_char_p, C.c_size_t,
+                            C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension was not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C gamd_amd/csrc`). "
+            "gamd_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class GamdError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str) -> int:
+    if status < 0:
+        msg = load().gamd_last_error().decode("utf-8", "replace")
+        raise GamdError(f"{what} failed with status {status}: {msg}")
+    return status

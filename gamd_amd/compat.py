@@ -1,0 +1,116 @@
+"""Reference-shaped adapters: the call contract of the rollout drivers
+(`code/LJ/test_script/test_langevin.py:74-77,91,108`,
+`code/water/test_script/test_nosehoover.py:79-81,106,123`) on top of `GamdForce`.
+
+    model = ParticleNetLightning(args).load_from_checkpoint(PATH, args=args)
+    model.load_training_stats(SCALER_CKPT); model.cuda(); model.eval()
+    force = model.predict_forces(pos)            # LJ    (np f64 [N,3] -> np f64 [N,3])
+    force = model.predict_forces(feat, pos)      # water (feat: torch [N,1], O=1/H=0)
+
+Physics constants that are module-level in the reference (BOX_SIZE, CUTOFF_RADIUS,
+NUM_OF_ATOMS; LJ/train_network_lj.py:26-29, water/train_network_tip3p.py:24-29) are
+constructor arguments here.
+"""
+from __future__ import annotations
+
+import time
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .engine import GamdForce
+from .weights import ModelConfig, load_checkpoint, load_scaler, make_state_dict, infer_config
+
+
+def create_water_bond(total_atom_num: int) -> np.ndarray:
+    """O-H1, O-H2 per molecule, atoms ordered O,H,H (water/train_network_tip3p.py:38-42)."""
+    o = np.arange(0, total_atom_num, 3)
+    return np.stack([np.repeat(o, 2), (o[:, None] + np.array([1, 2])).reshape(-1)], axis=1)
+
+
+class _ForceFieldBase:
+    def __init__(self, args=None, state_dict=None, *, num_atoms: int, box_size, cutoff: float,
+                 bond=None, scaler_ckpt: Optional[str] = None, device: int = 0):
+        self.args = args or SimpleNamespace()
+        self.num_atoms, self.box_size, self.cutoff = int(num_atoms), box_size, float(cutoff)
+        self.bond, self.device_index = bond, device
+        self.training_mean = np.array([0.])          # LJ/train_network_lj.py:105-106
+        self.training_var = np.array([1.])
+        self._sd = state_dict
+        self._engine: Optional[GamdForce] = None
+        if scaler_ckpt is not None:
+            self.load_training_stats(scaler_ckpt)
+
+    # -- construction / loading (test_langevin.py:74-77) --------------------------------------
+    def load_from_checkpoint(self, path: str, args=None, **kw):
+        """Instance-style call used by the drivers: ParticleNetLightning(args).load_from_checkpoint(PATH, args=args)."""
+        self._sd = load_checkpoint(path)
+        self._engine = None
+        return self
+
+    def load_state_dict(self, sd):
+        self._sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self._engine = None
+        return self
+
+    def load_training_stats(self, scaler_ckpt):
+        if scaler_ckpt is not None:
+            self.training_mean, self.training_var = load_scaler(scaler_ckpt)
+            if self._engine is not None:
+                self._engine.set_scaler(self.training_mean, self.training_var)
+
+    def cuda(self, device=None):
+        return self
+
+    def eval(self):
+        return self
+
+    def _get_engine(self) -> GamdForce:
+        if self._engine is None:
+            if self._sd is None:
+                raise RuntimeError("no weights loaded: call load_from_checkpoint / load_state_dict first")
+            self._engine = GamdForce(self._sd, self.num_atoms, self.box_size, self.cutoff, bond=self.bond,
+                                     scaler=(self.training_mean, self.training_var), device=self.device_index)
+        return self._engine
+
+    def denormalize(self, normalized_force, var, mean):
+        return normalized_force * np.sqrt(var) + mean         # LJ/train_network_lj.py:128-131
+
+    def _predict(self, pos: np.ndarray, feat=None, verbose=False) -> np.ndarray:
+        eng = self._get_engine()
+        t0 = time.time()
+        # enforce periodic boundary in f64 on the host, then f32 (train_network_lj.py:141-142)
+        posw = np.mod(np.asarray(pos, dtype=np.float64), np.asarray(self.box_size, dtype=np.float64))
+        species = None
+        if feat is not None:
+            species = (feat.reshape(-1) != 0)
+        pred = eng.forward(torch.from_numpy(posw).float(), species=species)
+        pred = pred.detach().cpu().numpy()                    # device -> host sync (:153)
+        t1 = time.time()
+        if verbose:
+            print('=============================================')
+            print(f'Nbr search + force eval used time: {t1 - t0}')
+        return self.denormalize(pred, self.training_var, self.training_mean)   # f64 result (:155)
+
+
+class ParticleNetLightningLJ(_ForceFieldBase):
+    """LJ flavour (code/LJ/train_network_lj.py:91-157): BOX_SIZE 27.27, CUTOFF_RADIUS 7.5, 258 atoms."""
+
+    def __init__(self, args=None, state_dict=None, *, num_atoms=258, box_size=27.27, cutoff=7.5, **kw):
+        super().__init__(args, state_dict, num_atoms=num_atoms, box_size=box_size, cutoff=cutoff, **kw)
+
+    def predict_forces(self, pos: np.ndarray, verbose=False) -> np.ndarray:
+        return self._predict(pos, None, verbose)
+
+
+class ParticleNetLightningWater(_ForceFieldBase):
+    """TIP3P/TIP4P flavour (code/water/train_network_tip3p.py:100-159): box 20, cutoff 4.2, 258*3 atoms."""
+
+    def __init__(self, args=None, state_dict=None, *, num_atoms=258 * 3, box_size=20.0, cutoff=4.2, bond=None, **kw):
+        bond = create_water_bond(num_atoms) if bond is None else bond
+        super().__init__(args, state_dict, num_atoms=num_atoms, box_size=box_size, cutoff=cutoff, bond=bond, **kw)
+
+    def predict_forces(self, feat: torch.Tensor, pos: np.ndarray) -> np.ndarray:
+        return self._predict(pos, feat)

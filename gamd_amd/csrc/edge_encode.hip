@@ -1,0 +1,155 @@
+// edge_encode.hip — fused edge-feature construction + edge encoder MLP + LayerNorm.
+//
+// Replaces (reference, code/nn_module.py):
+//   :603-634  calc_edge_feat   (gather, min-image, norm, unit vector, standardise, 40 RBFs, concat)
+//   :510-511  bond flag as 45th feature (water)
+//   :646      edge_layer_norm(edge_encoder(feat))   MLP 44|45 -> 128 -> 128 -> 128, GELU(erf)
+// The [E,44] feature matrix is never materialised: each lane builds its share of the features in
+// registers, already in MFMA operand order, and the three GEMMs chain through the register file
+// (gamd_common.h).  All three weight matrices stay resident in LDS (152 KiB) for the whole
+// persistent kernel, so the main loop has no barriers.  Output: e in fragment order (e_frag), the
+// layout the conv-layer kernel loads with perfectly coalesced 16-byte reads.
+#include "gamd_common.h"
+#include "gamd_internal.h"
+
+namespace {
+
+constexpr int ENC_W1_FLOATS = 4 * 6 * 64 * 4;              // K padded to 48 (24 MFMA steps)
+constexpr int ENC_LDS_FLOATS = ENC_W1_FLOATS + 2 * GAMD_WFRAG_FLOATS + 5 * 128 + 64;
+
+template <int NFEAT>
+__global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w1 = lds;
+    float* w2 = w1 + ENC_W1_FLOATS;
+    float* w3 = w2 + GAMD_WFRAG_FLOATS;
+    float* vb1 = w3 + GAMD_WFRAG_FLOATS;
+    float* vb2 = vb1 + 128;
+    float* vb3 = vb2 + 128;
+    float* vg = vb3 + 128;
+    float* vbeta = vg + 128;
+    float* cen = vbeta + 128;
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ENC_W1_FLOATS / 4; i += 512) ((f32x4*)w1)[i] = ((const f32x4*)a.w1p)[i];
+    for (int i = tid; i < GAMD_WFRAG_FLOATS / 4; i += 512) {
+        ((f32x4*)w2)[i] = ((const f32x4*)a.w2p)[i];
+        ((f32x4*)w3)[i] = ((const f32x4*)a.w3p)[i];
+    }
+    if (tid < 128) {
+        vb1[tid] = a.b1[tid]; vb2[tid] = a.b2[tid]; vb3[tid] = a.b3[tid];
+        vg[tid] = a.ln_g[tid]; vbeta[tid] = a.ln_b[tid];
+    }
+    if (tid < 40) cen[tid] = a.centers[tid];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, slot = lane & 31, half = lane >> 5;
+    long long E = a.counters[CNT_E];
+    if (E > a.e_cap) E = a.e_cap;
+    const int n_tiles = (int)((E + GAMD_TILE - 1) / GAMD_TILE);
+    const int n_wg_tiles = (n_tiles + 7) / 8;
+    int first, end, step;
+    gamd_xcd_range(n_wg_tiles, blockIdx.x, gridDim.x, first, end, step);
+
+    constexpr int KSTEPS = (NFEAT + 1) / 2;      // 22 (LJ) or 23 (water + bond flag)
+
+    for (int wt = first; wt < end; wt += step) {
+        const int tile = wt * 8 + wave;
+        if (tile >= n_tiles) continue;
+        const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
+        const bool valid = x < E;
+        const int src = valid ? a.col[x] : 0;
+        const int dst = valid ? a.erow[x] : 0;
+        const float4 ps = a.pos_s[src], pd = a.pos_s[dst];
+        // nn_module.py:615-624
+        const float rx = gamd_min_image(ps.x - pd.x, a.box[0], a.half[0]);
+        const float ry = gamd_min_image(ps.y - pd.y, a.box[1], a.half[1]);
+        const float rz = gamd_min_image(ps.z - pd.z, a.box[2], a.half[2]);
+        const float nrm = sqrtf((rx * rx + ry * ry) + rz * rz);
+        const float den = nrm + 1e-8f;
+        const float d = (nrm - a.length_mean) / a.length_std;          // :630
+        float F[24];
+        F[0] = half ? ry / den : rx / den;
+        F[1] = half ? d : rz / den;
+#pragma unroll
+        for (int s = 2; s < 22; ++s) {
+            const float radial = d - cen[2 * (s - 2) + half];           // :261-263
+            F[s] = expf(-a.gamma * (radial * radial));
+        }
+        F[22] = 0.f; F[23] = 0.f;
+        if (NFEAT == 45) {
+            // bond_graph.has_edges_between(centre, neigh), nn_module.py:510
+            float flag = 0.f;
+            if (a.bond_nbr) {
+                const int io = a.perm[dst], jo = a.perm[src];
+                const int4 nb = *reinterpret_cast<const int4*>(a.bond_nbr + 4 * (size_t)io);
+                flag = (nb.x == jo || nb.y == jo || nb.z == jo || nb.w == jo) ? 1.f : 0.f;
+            }
+            F[22] = half ? 0.f : flag;
+        }
+        if (a.feat_dbg && valid) {
+#pragma unroll
+            for (int s = 0; s < 24; ++s) a.feat_dbg[x * 48 + 2 * s + half] = F[s];
+        }
+
+        // ---- GEMM 1: [128 x NFEAT] ----
+        f32x16 acc[4], X[4];
+        load_bias_chain(vb1, half, acc);
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (4 * g >= KSTEPS) break;
+                const f32x4 w = ((const f32x4*)w1)[(tp * 6 + g) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * g + j < KSTEPS) acc[tp] = mfma32(w[j], F[4 * g + j], acc[tp]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[t][r] = gamd_gelu(acc[t][r]);
+        // ---- GEMM 2 ----
+        load_bias_chain(vb2, half, acc);
+        gemm128<false>((const f32x4*)w2, lane, X, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X[t][r] = gamd_gelu(acc[t][r]);
+        // ---- GEMM 3 + LayerNorm ----
+        load_bias_chain(vb3, half, acc);
+        gemm128<false>((const f32x4*)w3, lane, X, acc);
+        layernorm_chain(acc, vg, vbeta, half, 1e-5f);
+        // ---- store e fragment: 16 x 1 KiB coalesced ----
+        f32x4* out = (f32x4*)a.e_frag + (size_t)tile * 16 * 64;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[t][q * 4 + j];
+                out[(t * 4 + q) * 64 + lane] = v;
+            }
+    }
+}
+
+}  // namespace
+
+int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st) {
+    const size_t lds = sizeof(float) * ENC_LDS_FLOATS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_edge_encode<44>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute((const void*)k_edge_encode<45>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess) return (int)e1;
+        if (e2 != hipSuccess) return (int)e2;
+        attr_set = true;
+    }
+    if (a.n_feat == 44) hipLaunchKernelGGL(k_edge_encode<44>, dim3(n_blocks), dim3(512), lds, st, a);
+    else if (a.n_feat == 45) hipLaunchKernelGGL(k_edge_encode<45>, dim3(n_blocks), dim3(512), lds, st, a);
+    else return -22;
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,656 @@
+// gamd_api.hip — handle, weight packing and the extern "C" entry points of include/gamd_hip.h.
+#include "../../include/gamd_hip.h"
+#include "gamd_common.h"
+#include "gamd_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) return fail(-1000 - (int)e__, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t want, bool zero) {
+        if (want <= bytes && p) return 0;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return (int)e; p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return (int)e;
+        bytes = want;
+        if (zero) { e = hipMemset(p, 0, want); if (e != hipSuccess) return (int)e; }
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct LayerDev {
+    // edge side
+    const float *w1p, *w2p, *w3p, *w4p, *b1, *b3, *b4;
+    NodeLayerW node;
+};
+
+}  // namespace
+
+struct gamd_handle {
+    gamd_config cfg{};
+    int n = 0, L = 0, n_feat = 44, n_cu = 256;
+    std::map<std::string, HostTensor> host_w;
+    bool finalized = false;
+    double scaler_mean = 0.0, scaler_var = 1.0;
+
+    // packed weights on device
+    DevBuf wblob;
+    std::vector<LayerDev> layers;
+    const float *enc_w1p = nullptr, *enc_w2p = nullptr, *enc_w3p = nullptr, *enc_b1 = nullptr, *enc_b2 = nullptr,
+                *enc_b3 = nullptr, *enc_lng = nullptr, *enc_lnb = nullptr, *centers = nullptr;
+    const float *node_emb = nullptr, *nenc_w = nullptr, *nenc_b = nullptr;
+    const float *dec_w1p = nullptr, *dec_b1 = nullptr, *dec_w2 = nullptr, *dec_b2 = nullptr;
+    float length_mean = 0.f, length_std = 1.f;
+
+    // per-atom buffers
+    DevBuf pos_w, pos_s, cell_of, perm, inv_perm, deg, row_ptr, na_excl, bond_nbr;
+    DevBuf hbuf, hn, S, D, P, f_norm, f_den;
+    // cells
+    DevBuf cell_cnt, cell_fill, cell_start;
+    int ncell_cap = 0;
+    // edges
+    long long e_cap = 0;
+    DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg;
+    DevBuf counters;
+    int* counters_host = nullptr;   // pinned
+    bool has_bonds = false;
+
+    float box[3] = {0, 0, 0};
+    int nc[3] = {1, 1, 1};
+};
+
+namespace {
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int alloc_edges(gamd_handle* h, long long e_cap) {
+    const size_t ec = (size_t)e_cap + 2 * GAMD_TILE;
+    int r = 0;
+    r |= h->col.ensure(sizeof(int) * ec, true);
+    r |= h->erow.ensure(sizeof(int) * ec, true);
+    r |= h->chunk_piece.ensure(sizeof(int) * (ec / GAMD_CHUNK + 2), true);
+    r |= h->chunk_mask.ensure(sizeof(unsigned) * (ec / GAMD_CHUNK + 2), true);
+    r |= h->e_frag.ensure(sizeof(float) * 4096 * (ec / GAMD_TILE + 1), false);
+    r |= h->partial.ensure(sizeof(float) * GAMD_H * (ec / GAMD_CHUNK + (size_t)h->n + 2), false);
+    if (h->cfg.keep_stages) r |= h->feat_dbg.ensure(sizeof(float) * 48 * ec, true);
+    if (r) return fail(-12, "edge buffer allocation failed for capacity %lld", e_cap);
+    h->e_cap = e_cap;
+    return 0;
+}
+
+int set_box(gamd_handle* h, const float* box) {
+    long long ncell = 1;
+    for (int d = 0; d < 3; ++d) {
+        if (!(box[d] > 0.f)) return fail(-22, "box[%d] = %g is not positive", d, (double)box[d]);
+        h->box[d] = box[d];
+        int nc = (int)std::floor((double)box[d] / ((double)h->cfg.cutoff * 1.0001));
+        h->nc[d] = std::max(1, nc);
+        ncell *= h->nc[d];
+    }
+    if (ncell > (1ll << 30)) return fail(-22, "cell grid too large");
+    if ((int)ncell > h->ncell_cap) {
+        int r = 0;
+        r |= h->cell_cnt.ensure(sizeof(int) * (size_t)ncell, true);
+        r |= h->cell_fill.ensure(sizeof(int) * (size_t)ncell, true);
+        r |= h->cell_start.ensure(sizeof(int) * ((size_t)ncell + 1), true);
+        if (r) return fail(-12, "cell buffer allocation failed");
+        h->ncell_cap = (int)ncell;
+    }
+    return 0;
+}
+
+NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev) {
+    NbrArgs a{};
+    a.n = h->n;
+    a.flavour = h->cfg.nbr_flavour;
+    for (int d = 0; d < 3; ++d) {
+        a.box[d] = h->box[d];
+        a.half[d] = 0.5f * h->box[d];
+        a.nc[d] = h->nc[d];
+    }
+    a.rc = h->cfg.cutoff;
+    a.rc2 = (float)((double)h->cfg.cutoff * (double)h->cfg.cutoff);   // graph_utils.py:59 cutoff ** 2
+    a.ncell = h->nc[0] * h->nc[1] * h->nc[2];
+    a.e_cap = h->e_cap;
+    a.pos = pos_dev;
+    a.species = species_dev;
+    a.pos_w = h->pos_w.as<float4>();
+    a.pos_s = h->pos_s.as<float4>();
+    a.cell_of = h->cell_of.as<int>();
+    a.cell_cnt = h->cell_cnt.as<int>();
+    a.cell_fill = h->cell_fill.as<int>();
+    a.cell_start = h->cell_start.as<int>();
+    a.perm = h->perm.as<int>();
+    a.inv_perm = h->inv_perm.as<int>();
+    a.deg = h->deg.as<int>();
+    a.row_ptr = h->row_ptr.as<int>();
+    a.na_excl = h->na_excl.as<int>();
+    a.col = h->col.as<int>();
+    a.erow = h->erow.as<int>();
+    a.chunk_piece = h->chunk_piece.as<int>();
+    a.chunk_mask = h->chunk_mask.as<unsigned>();
+    a.counters = h->counters.as<int>();
+    return a;
+}
+
+// ---- weight packing ---------------------------------------------------------------------------
+// W [128 out][128 in] row-major -> fragment order of gamd_common.h
+void pack128(const float* W, float* out) {
+    for (int tp = 0; tp < 4; ++tp)
+        for (int t = 0; t < 4; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = 32 * tp + (lane & 31), k = 32 * t + 8 * q + 4 * (lane >> 5) + j;
+                        out[((((tp * 4 + t) * 4 + q) * 64 + lane) * 4) + j] = W[n * 128 + k];
+                    }
+}
+// encoder first layer W [128][n_feat]: MFMA step s covers features (2s, 2s+1); K padded to 48
+void pack_enc1(const float* W, int n_feat, float* out) {
+    for (int tp = 0; tp < 4; ++tp)
+        for (int g = 0; g < 6; ++g)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = 32 * tp + (lane & 31), k = 2 * (4 * g + j) + (lane >> 5);
+                    out[(((tp * 6 + g) * 64 + lane) * 4) + j] = k < n_feat ? W[n * n_feat + k] : 0.f;
+                }
+}
+
+struct BlobBuilder {
+    std::vector<float> host;
+    size_t add(size_t n_floats) {
+        const size_t off = host.size();
+        host.resize(off + ((n_floats + 63) & ~(size_t)63), 0.f);
+        return off;
+    }
+};
+
+const HostTensor* find_w(gamd_handle* h, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = h->host_w.find(name);
+    if (it == h->host_w.end()) { fail(-2, "missing weight '%s'", name.c_str()); return nullptr; }
+    if (it->second.shape != std::vector<int64_t>(shape)) {
+        std::string got;
+        for (auto d : it->second.shape) got += std::to_string(d) + ",";
+        fail(-22, "weight '%s' has shape (%s), expected a %zu-d tensor of the 128-wide architecture",
+             name.c_str(), got.c_str(), shape.size());
+        return nullptr;
+    }
+    return &it->second;
+}
+
+int ensure_stream_ok(hipStream_t st) { (void)st; return 0; }
+
+int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, float* out_norm_dev,
+                    float* out_denorm_dev, hipStream_t st, hipEvent_t* evs, int* n_ev, std::vector<std::string>* labels) {
+    auto mark = [&](const char* label) {
+        if (evs) { (void)hipEventRecord(evs[*n_ev], st); ++*n_ev; labels->push_back(label); }
+    };
+    int r;
+    mark("begin");
+    NbrArgs na = nbr_args(h, pos_dev, species_dev);
+    if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);
+    mark("neighbor_build");
+
+    EncArgs ea{};
+    ea.counters = h->counters.as<int>();
+    ea.pos_s = h->pos_s.as<float4>();
+    ea.col = h->col.as<int>();
+    ea.erow = h->erow.as<int>();
+    ea.bond_nbr = h->has_bonds ? h->bond_nbr.as<int>() : nullptr;
+    ea.perm = h->perm.as<int>();
+    for (int d = 0; d < 3; ++d) { ea.box[d] = h->box[d]; ea.half[d] = 0.5f * h->box[d]; }
+    ea.length_mean = h->length_mean;
+    ea.length_std = h->length_std;
+    ea.gamma = (float)(1.0 / 0.025);             // RBFExpansion(high=1, gap=0.025): gamma = 1/gap (nn_module.py:240)
+    ea.n_feat = h->n_feat;
+    ea.n_ksteps = (h->n_feat + 1) / 2;
+    ea.centers = h->centers;
+    ea.w1p = h->enc_w1p; ea.w2p = h->enc_w2p; ea.w3p = h->enc_w3p;
+    ea.b1 = h->enc_b1; ea.b2 = h->enc_b2; ea.b3 = h->enc_b3;
+    ea.ln_g = h->enc_lng; ea.ln_b = h->enc_lnb;
+    ea.e_frag = h->e_frag.as<float>();
+    ea.e_cap = h->e_cap;
+    ea.feat_dbg = h->cfg.keep_stages ? h->feat_dbg.as<float>() : nullptr;
+    if ((r = launch_edge_encode(ea, h->n_cu, st))) return fail(-1, "edge encode launch failed (%d)", r);
+    mark("edge_encode");
+
+    const size_t nh = (size_t)h->n * GAMD_H;
+    auto hptr = [&](int l) { return h->hbuf.as<float>() + (h->cfg.keep_stages ? (size_t)l * nh : (size_t)(l & 1) * nh); };
+
+    NodeArgs no{};
+    no.n = h->n;
+    no.pos_s = h->pos_s.as<float4>();
+    no.node_emb = h->node_emb; no.enc_w = h->nenc_w; no.enc_b = h->nenc_b;
+    no.row_ptr = h->row_ptr.as<int>(); no.na_excl = h->na_excl.as<int>(); no.deg = h->deg.as<int>();
+    no.partial = h->partial.as<float>();
+    no.P_in = h->P.as<float>();
+    no.hn_out = h->hn.as<float>(); no.S_out = h->S.as<float>(); no.D_out = h->D.as<float>(); no.P_out = h->P.as<float>();
+    no.dec_w1p = h->dec_w1p; no.dec_b1 = h->dec_b1; no.dec_w2 = h->dec_w2; no.dec_b2 = h->dec_b2;
+    no.scale = (float)std::sqrt(h->scaler_var);
+    no.shift = (float)h->scaler_mean;
+    no.perm = h->perm.as<int>();
+    no.forces_norm = out_norm_dev ? out_norm_dev : h->f_norm.as<float>();
+    no.forces = out_denorm_dev;
+
+    no.mode = 0;
+    no.pre = h->layers[0].node;
+    no.h_out = hptr(0);
+    if ((r = launch_node(no, st))) return fail(-1, "node(0) launch failed (%d)", r);
+    mark("node_first");
+
+    for (int l = 0; l < h->L; ++l) {
+        ConvEdgeArgs ca{};
+        ca.counters = h->counters.as<int>();
+        ca.col = h->col.as<int>(); ca.erow = h->erow.as<int>();
+        ca.chunk_piece = h->chunk_piece.as<int>(); ca.chunk_mask = h->chunk_mask.as<unsigned>();
+        ca.e_frag = h->e_frag.as<float>();
+        ca.hn = h->hn.as<float>(); ca.S = h->S.as<float>(); ca.D = h->D.as<float>();
+        const LayerDev& ld = h->layers[l];
+        ca.w1p = ld.w1p; ca.w2p = ld.w2p; ca.w3p = ld.w3p; ca.w4p = ld.w4p;
+        ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
+        ca.partial = h->partial.as<float>();
+        ca.e_cap = h->e_cap;
+        if ((r = launch_conv_edge(ca, h->n_cu, st))) return fail(-1, "conv edge launch failed (%d)", r);
+        mark("conv_edge");
+
+        no.mode = (l == h->L - 1) ? 2 : 1;
+        no.post = ld.node;
+        if (l + 1 < h->L) no.pre = h->layers[l + 1].node;
+        no.h_in = hptr(l);
+        no.h_out = hptr(l + 1);
+        if ((r = launch_node(no, st))) return fail(-1, "node launch failed (%d)", r);
+        mark(no.mode == 2 ? "node_last_decode" : "node_mid");
+    }
+    HIP_TRY(hipMemcpyAsync(h->counters_host, h->counters.p, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+int check_ready(gamd_handle* h) {
+    if (!h) return fail(-22, "null handle");
+    if (!h->finalized) return fail(-22, "weights not finalized (call gamd_finalize_weights)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gamd_version(void) { return "gamd_hip 0.1 (gfx950)"; }
+const char* gamd_last_error(void) { return g_err; }
+
+int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
+    if (!cfg || !out) return fail(-22, "null argument");
+    if (cfg->n_atoms <= 0) return fail(-22, "n_atoms must be positive");
+    if (cfg->n_layers <= 0 || cfg->n_layers > 16) return fail(-22, "n_layers out of range");
+    if (!(cfg->cutoff > 0.f)) return fail(-22, "cutoff must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(-19, "no HIP device available: libgamd_hip has no CPU fallback");
+    HIP_TRY(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    gamd_handle* h = new gamd_handle();
+    h->cfg = *cfg;
+    h->n = cfg->n_atoms;
+    h->L = cfg->n_layers;
+    h->n_feat = 44 + (cfg->use_bond ? 1 : 0);
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const size_t n = (size_t)h->n;
+    int r = 0;
+    r |= h->pos_w.ensure(sizeof(float4) * n, true);
+    r |= h->pos_s.ensure(sizeof(float4) * n, true);
+    r |= h->cell_of.ensure(sizeof(int) * n, true);
+    r |= h->perm.ensure(sizeof(int) * n, true);
+    r |= h->inv_perm.ensure(sizeof(int) * n, true);
+    r |= h->deg.ensure(sizeof(int) * n, true);
+    r |= h->row_ptr.ensure(sizeof(int) * (n + 1), true);
+    r |= h->na_excl.ensure(sizeof(int) * (n + 1), true);
+    const size_t nh = n * GAMD_H * sizeof(float);
+    r |= h->hbuf.ensure(nh * (cfg->keep_stages ? (size_t)h->L + 1 : 2), true);
+    r |= h->hn.ensure(nh, true);
+    r |= h->S.ensure(nh, true);
+    r |= h->D.ensure(nh, true);
+    r |= h->P.ensure(nh, true);
+    r |= h->f_norm.ensure(sizeof(float) * 3 * n, true);
+    r |= h->f_den.ensure(sizeof(float) * 3 * n, true);
+    r |= h->counters.ensure(sizeof(int) * CNT_COUNT, true);
+    if (r) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
+    if (hipHostMalloc((void**)&h->counters_host, sizeof(int) * CNT_COUNT) != hipSuccess) {
+        gamd_destroy(h);
+        return fail(-12, "pinned allocation failed");
+    }
+    memset(h->counters_host, 0, sizeof(int) * CNT_COUNT);
+    if ((r = set_box(h, cfg->box))) { gamd_destroy(h); return r; }
+    long long ecap = cfg->edge_capacity;
+    if (ecap <= 0) {
+        const double vol = (double)cfg->box[0] * cfg->box[1] * cfg->box[2];
+        const double per_atom = 4.18879 * std::pow((double)cfg->cutoff, 3) * (double)h->n / vol + 1.0;
+        ecap = (long long)(1.5 * per_atom * (double)h->n) + 1024;
+    }
+    if ((r = alloc_edges(h, ecap))) { gamd_destroy(h); return r; }
+    *out = h;
+    return 0;
+}
+
+int32_t gamd_destroy(gamd_handle* h) {
+    if (!h) return 0;
+    DevBuf* bufs[] = {&h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
+                      &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
+                      &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
+                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters};
+    for (DevBuf* b : bufs) b->release();
+    if (h->counters_host) (void)hipHostFree(h->counters_host);
+    delete h;
+    return 0;
+}
+
+int32_t gamd_load_weight(gamd_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!h || !name || !data || !shape || ndim < 1 || ndim > 2) return fail(-22, "bad argument to gamd_load_weight");
+    HostTensor t;
+    size_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); cnt *= (size_t)shape[i]; }
+    t.data.assign(data, data + cnt);
+    h->host_w[name] = std::move(t);
+    h->finalized = false;
+    return 0;
+}
+
+int32_t gamd_finalize_weights(gamd_handle* h) {
+    if (!h) return fail(-22, "null handle");
+    const int F = h->n_feat, L = h->L;
+    BlobBuilder bb;
+    struct Off { size_t w1p, w2p, w3p, w4p, b1, b3, b4, lng, lnb, wsp, wdp, wpdp, bS, bP, wpep, wphip, bphi; };
+    std::vector<Off> lo(L);
+    auto get = [&](const std::string& nm, std::initializer_list<int64_t> shp) { return find_w(h, nm, shp); };
+    auto put_vec = [&](const HostTensor* t) { size_t o = bb.add(t->data.size()); std::copy(t->data.begin(), t->data.end(), bb.host.begin() + o); return o; };
+    auto put_packed = [&](const HostTensor* t) { size_t o = bb.add(GAMD_WFRAG_FLOATS); pack128(t->data.data(), bb.host.data() + o); return o; };
+
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "graph_conv.conv." + std::to_string(l);
+        const HostTensor *ea0w = get(p + ".edge_affine.mlp_layer.0.weight", {128, 128}), *ea0b = get(p + ".edge_affine.mlp_layer.0.bias", {128});
+        const HostTensor *ea2w = get(p + ".edge_affine.mlp_layer.2.weight", {128, 128}), *ea2b = get(p + ".edge_affine.mlp_layer.2.bias", {128});
+        const HostTensor *sw = get(p + ".src_affine.weight", {128, 128}), *sb = get(p + ".src_affine.bias", {128});
+        const HostTensor *dw = get(p + ".dst_affine.weight", {128, 128}), *db = get(p + ".dst_affine.bias", {128});
+        const HostTensor *t1w = get(p + ".theta_edge.mlp_layer.1.weight", {128, 128}), *t1b = get(p + ".theta_edge.mlp_layer.1.bias", {128});
+        const HostTensor *t3w = get(p + ".theta_edge.mlp_layer.3.weight", {128, 128}), *t3b = get(p + ".theta_edge.mlp_layer.3.bias", {128});
+        const HostTensor *pdw = get(p + ".phi_dst.weight", {128, 128}), *pdb = get(p + ".phi_dst.bias", {128});
+        const HostTensor *pew = get(p + ".phi_edge.weight", {128, 128}), *peb = get(p + ".phi_edge.bias", {128});
+        const HostTensor *phw = get(p + ".phi.mlp_layer.1.weight", {128, 128}), *phb = get(p + ".phi.mlp_layer.1.bias", {128});
+        const HostTensor *ng = get("graph_conv.norm_layers." + std::to_string(l) + ".weight", {128});
+        const HostTensor *nb = get("graph_conv.norm_layers." + std::to_string(l) + ".bias", {128});
+        if (!ea0w || !ea0b || !ea2w || !ea2b || !sw || !sb || !dw || !db || !t1w || !t1b || !t3w || !t3b || !pdw ||
+            !pdb || !pew || !peb || !phw || !phb || !ng || !nb)
+            return -2;
+        Off& o = lo[l];
+        o.w1p = put_packed(ea0w); o.b1 = put_vec(ea0b);
+        o.w2p = put_packed(ea2w);
+        o.w3p = put_packed(t1w); o.b3 = put_vec(t1b);
+        o.w4p = put_packed(t3w); o.b4 = put_vec(t3b);
+        o.lng = put_vec(ng); o.lnb = put_vec(nb);
+        o.wsp = put_packed(sw); o.wdp = put_packed(dw); o.wpdp = put_packed(pdw);
+        o.bS = bb.add(128);
+        for (int i = 0; i < 128; ++i) bb.host[o.bS + i] = (sb->data[i] + db->data[i]) + ea2b->data[i];
+        o.bP = bb.add(128);
+        for (int i = 0; i < 128; ++i) bb.host[o.bP + i] = pdb->data[i] + peb->data[i];
+        o.wpep = put_packed(pew); o.wphip = put_packed(phw); o.bphi = put_vec(phb);
+    }
+    const HostTensor *e0w = get("edge_encoder.mlp_layer.0.weight", {128, (int64_t)F}), *e0b = get("edge_encoder.mlp_layer.0.bias", {128});
+    const HostTensor *e2w = get("edge_encoder.mlp_layer.2.weight", {128, 128}), *e2b = get("edge_encoder.mlp_layer.2.bias", {128});
+    const HostTensor *e4w = get("edge_encoder.mlp_layer.4.weight", {128, 128}), *e4b = get("edge_encoder.mlp_layer.4.bias", {128});
+    const HostTensor *elg = get("edge_layer_norm.weight", {128}), *elb = get("edge_layer_norm.bias", {128});
+    const HostTensor *cen = get("edge_expand.centers", {40});
+    const HostTensor *lm = get("length_mean", {1}), *ls = get("length_std", {1});
+    const HostTensor *d0w = get("graph_decoder.mlp_layer.0.weight", {128, 128}), *d0b = get("graph_decoder.mlp_layer.0.bias", {128});
+    const HostTensor *d2w = get("graph_decoder.mlp_layer.2.weight", {3, 128}), *d2b = get("graph_decoder.mlp_layer.2.bias", {3});
+    if (!e0w || !e0b || !e2w || !e2b || !e4w || !e4b || !elg || !elb || !cen || !lm || !ls || !d0w || !d0b || !d2w || !d2b)
+        return -2;
+    const size_t o_e1 = bb.add(4 * 6 * 64 * 4);
+    pack_enc1(e0w->data.data(), F, bb.host.data() + o_e1);
+    const size_t o_e2 = put_packed(e2w), o_e3 = put_packed(e4w);
+    const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(e4b), o_elg = put_vec(elg), o_elb = put_vec(elb);
+    const size_t o_cen = put_vec(cen);
+    const size_t o_d1 = put_packed(d0w), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
+    size_t o_emb = 0, o_nw = 0, o_nb = 0;
+    if (h->cfg.kind == GAMD_KIND_LJ) {
+        const HostTensor* emb = get("node_emb", {1, 128});
+        if (!emb) return -2;
+        o_emb = put_vec(emb);
+    } else {
+        const HostTensor *nw = get("node_encoder.weight", {128, 1}), *nb = get("node_encoder.bias", {128});
+        if (!nw || !nb) return -2;
+        o_nw = put_vec(nw); o_nb = put_vec(nb);
+    }
+    h->length_mean = lm->data[0];
+    h->length_std = ls->data[0];
+
+    if (h->wblob.ensure(sizeof(float) * bb.host.size(), false)) return fail(-12, "weight blob allocation failed");
+    HIP_TRY(hipMemcpy(h->wblob.p, bb.host.data(), sizeof(float) * bb.host.size(), hipMemcpyHostToDevice));
+    const float* B = h->wblob.as<float>();
+    h->layers.assign(L, LayerDev{});
+    for (int l = 0; l < L; ++l) {
+        const Off& o = lo[l];
+        LayerDev& d = h->layers[l];
+        d.w1p = B + o.w1p; d.w2p = B + o.w2p; d.w3p = B + o.w3p; d.w4p = B + o.w4p;
+        d.b1 = B + o.b1; d.b3 = B + o.b3; d.b4 = B + o.b4;
+        d.node.ln_g = B + o.lng; d.node.ln_b = B + o.lnb;
+        d.node.wsp = B + o.wsp; d.node.wdp = B + o.wdp; d.node.wpdp = B + o.wpdp;
+        d.node.bS = B + o.bS; d.node.bP = B + o.bP;
+        d.node.wpep = B + o.wpep; d.node.wphip = B + o.wphip; d.node.bphi = B + o.bphi;
+    }
+    h->enc_w1p = B + o_e1; h->enc_w2p = B + o_e2; h->enc_w3p = B + o_e3;
+    h->enc_b1 = B + o_eb1; h->enc_b2 = B + o_eb2; h->enc_b3 = B + o_eb3;
+    h->enc_lng = B + o_elg; h->enc_lnb = B + o_elb; h->centers = B + o_cen;
+    h->dec_w1p = B + o_d1; h->dec_b1 = B + o_db1; h->dec_w2 = B + o_d2; h->dec_b2 = B + o_db2;
+    h->node_emb = h->cfg.kind == GAMD_KIND_LJ ? B + o_emb : nullptr;
+    h->nenc_w = h->cfg.kind == GAMD_KIND_LJ ? nullptr : B + o_nw;
+    h->nenc_b = h->cfg.kind == GAMD_KIND_LJ ? nullptr : B + o_nb;
+    h->finalized = true;
+    return 0;
+}
+
+int32_t gamd_set_scaler(gamd_handle* h, double mean, double var) {
+    if (!h) return fail(-22, "null handle");
+    if (!(var >= 0.0)) return fail(-22, "scaler variance must be non-negative");
+    h->scaler_mean = mean;
+    h->scaler_var = var;
+    return 0;
+}
+
+int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds) {
+    if (!h || (!bonds && n_bonds > 0)) return fail(-22, "bad argument to gamd_set_bonds");
+    std::vector<int> tab((size_t)h->n * 4, -1);
+    auto add = [&](int i, int j) -> int {
+        for (int k = 0; k < 4; ++k) {
+            if (tab[(size_t)i * 4 + k] == j) return 0;
+            if (tab[(size_t)i * 4 + k] < 0) { tab[(size_t)i * 4 + k] = j; return 0; }
+        }
+        return -1;
+    };
+    for (int64_t b = 0; b < n_bonds; ++b) {
+        const int i = bonds[2 * b], j = bonds[2 * b + 1];
+        if (i < 0 || j < 0 || i >= h->n || j >= h->n) return fail(-22, "bond %lld references atom out of range", (long long)b);
+        if (add(i, j) || add(j, i)) return fail(-22, "more than 4 bonded partners for one atom is not supported");
+    }
+    if (h->bond_nbr.ensure(sizeof(int) * tab.size(), false)) return fail(-12, "bond table allocation failed");
+    HIP_TRY(hipMemcpy(h->bond_nbr.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+    h->has_bonds = n_bonds > 0;
+    return 0;
+}
+
+int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box, void* stream) {
+    int r;
+    if ((r = check_ready(h))) return r;
+    if (!pos_dev || !box) return fail(-22, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if ((r = set_box(h, box))) return r;
+        NbrArgs na = nbr_args(h, pos_dev, species_dev);
+        if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);
+        HIP_TRY(hipMemcpyAsync(h->counters_host, h->counters.p, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!h->counters_host[CNT_OVERFLOW]) return attempt ? 1 : 0;
+        const long long need = (long long)(1.25 * (double)h->counters_host[CNT_E]) + 1024;
+        if ((r = alloc_edges(h, need))) return r;
+    }
+    return fail(-34, "neighbor buffers still overflow after regrowing");
+}
+
+int32_t gamd_forces_async(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                          float* out_norm_dev, float* out_denorm_dev, void* stream) {
+    int r;
+    if ((r = check_ready(h))) return r;
+    if (!pos_dev || !box) return fail(-22, "null argument");
+    if (h->cfg.kind == GAMD_KIND_WATER && !species_dev) return fail(-22, "water model needs species");
+    if (h->cfg.use_bond && !h->has_bonds) return fail(-22, "use_bond set but no bonds given (gamd_set_bonds)");
+    if ((r = set_box(h, box))) return r;
+    return enqueue_forward(h, pos_dev, species_dev, out_norm_dev, out_denorm_dev, (hipStream_t)stream, nullptr, nullptr, nullptr);
+}
+
+int32_t gamd_sync_status(gamd_handle* h, void* stream) {
+    if (!h) return fail(-22, "null handle");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (h->counters_host[CNT_OVERFLOW]) {
+        const long long need = (long long)(1.25 * (double)h->counters_host[CNT_E]) + 1024;
+        int r = alloc_edges(h, need);
+        if (r) return r;
+        return fail(-34, "neighbour buffers overflowed (E=%d); regrown to %lld, re-issue the call",
+                    h->counters_host[CNT_E], need);
+    }
+    return 0;
+}
+
+int32_t gamd_forces(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                    float* out_norm_dev, float* out_denorm_dev, void* stream) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        int r = gamd_forces_async(h, pos_dev, species_dev, box, out_norm_dev, out_denorm_dev, stream);
+        if (r) return r;
+        r = gamd_sync_status(h, stream);
+        if (r == 0) return attempt ? 1 : 0;
+        if (r != -34) return r;
+    }
+    return fail(-34, "neighbour buffers still overflow after regrowing");
+}
+
+int32_t gamd_get_counts(gamd_handle* h, int64_t* n_edges, int64_t* n_pieces, int64_t* edge_capacity) {
+    if (!h) return fail(-22, "null handle");
+    if (n_edges) *n_edges = h->counters_host[CNT_E];
+    if (n_pieces) *n_pieces = h->counters_host[CNT_PIECES];
+    if (edge_capacity) *edge_capacity = h->e_cap;
+    return 0;
+}
+
+int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t bytes) {
+    if (!h || !host_out) return fail(-22, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = (size_t)h->n;
+    const size_t E = (size_t)std::min<long long>(h->counters_host[CNT_E], h->e_cap);
+    const void* src = nullptr;
+    size_t avail = 0;
+    if (what == GAMD_DBG_PERM) { src = h->perm.p; avail = sizeof(int) * n; }
+    else if (what == GAMD_DBG_ROWPTR) { src = h->row_ptr.p; avail = sizeof(int) * (n + 1); }
+    else if (what == GAMD_DBG_COL) { src = h->col.p; avail = sizeof(int) * E; }
+    else if (what == GAMD_DBG_EFRAG) { src = h->e_frag.p; avail = sizeof(float) * 4096 * ((E + 31) / 32); }
+    else if (what == GAMD_DBG_FEAT) {
+        if (!h->cfg.keep_stages) return fail(-22, "FEAT needs keep_stages=1");
+        src = h->feat_dbg.p; avail = sizeof(float) * 48 * E;
+    } else if (what >= GAMD_DBG_H0 && what <= GAMD_DBG_H0 + h->L) {
+        if (!h->cfg.keep_stages) return fail(-22, "H_l needs keep_stages=1");
+        src = h->hbuf.as<float>() + (size_t)(what - GAMD_DBG_H0) * n * GAMD_H; avail = sizeof(float) * n * GAMD_H;
+    } else return fail(-22, "unknown debug tensor %d", what);
+    if (bytes < avail) return fail(-22, "host buffer too small: %zu < %zu", bytes, avail);
+    HIP_TRY(hipMemcpy(host_out, src, avail, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
+                    const float* box, const gamd_md_params* p, int64_t n_steps, void* stream) {
+    int r;
+    if ((r = check_ready(h))) return r;
+    if (!x_dev || !v_dev || !f_dev || !box || !p) return fail(-22, "null argument");
+    if ((r = set_box(h, box))) return r;
+    hipStream_t st = (hipStream_t)stream;
+    MdArgs m{};
+    m.n = h->n; m.x = x_dev; m.v = v_dev; m.f = f_dev;
+    m.inv_mass = 1.0f / p->mass_amu;
+    m.dt = p->dt_ps;
+    const double kB = 0.00831446261815324;                       // kJ/mol/K
+    const double a = std::exp(-(double)p->gamma_per_ps * p->dt_ps);
+    m.a = (float)a;
+    m.b_sigma = (float)(std::sqrt(1.0 - a * a) * 10.0 * std::sqrt(kB * p->temperature_k / p->mass_amu));
+    for (int d = 0; d < 3; ++d) m.box[d] = box[d];
+    m.seed = p->seed;
+    for (int64_t s = 0; s < n_steps; ++s) {
+        m.step = p->first_step + (uint64_t)s;
+        if ((r = launch_baoab_first(m, st))) return fail(-1, "integrator launch failed (%d)", r);
+        if ((r = enqueue_forward(h, x_dev, species_dev, nullptr, f_dev, st, nullptr, nullptr, nullptr))) return r;
+        if ((r = launch_baoab_second(m, st))) return fail(-1, "integrator launch failed (%d)", r);
+    }
+    return 0;
+}
+
+int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                     float* out_norm_dev, void* stream, char* names, size_t names_bytes, float* ms, int32_t max_ms,
+                     int32_t* n_out) {
+    int r;
+    if ((r = check_ready(h))) return r;
+    if (!pos_dev || !box || !names || !ms || !n_out) return fail(-22, "null argument");
+    if ((r = set_box(h, box))) return r;
+    hipStream_t st = (hipStream_t)stream;
+    const int max_ev = 64;
+    hipEvent_t evs[max_ev];
+    for (int i = 0; i < max_ev; ++i) HIP_TRY(hipEventCreate(&evs[i]));
+    int n_ev = 0;
+    std::vector<std::string> labels;
+    r = enqueue_forward(h, pos_dev, species_dev, out_norm_dev, nullptr, st, evs, &n_ev, &labels);
+    if (r == 0) {
+        HIP_TRY(hipStreamSynchronize(st));
+        std::string all;
+        int cnt = 0;
+        for (int i = 1; i < n_ev && cnt < max_ms; ++i, ++cnt) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, evs[i - 1], evs[i]));
+            ms[cnt] = t;
+            all += labels[i];
+            all += "\n";
+        }
+        *n_out = cnt;
+        snprintf(names, names_bytes, "%s", all.c_str());
+    }
+    for (int i = 0; i < max_ev; ++i) (void)hipEventDestroy(evs[i]);
+    return r;
+}
+
+}  // extern "C"

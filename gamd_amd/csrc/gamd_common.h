@@ -1,0 +1,183 @@
+// gamd_common.h — shared device helpers and data-layout contract of the gfx950 kernels.
+//
+// Layout contract:
+//
+// * Work unit of every MFMA kernel is a "wave tile": 32 rows (edges or atoms) owned by one
+//   64-lane wavefront.  lane = (slot = lane & 31, half = lane >> 5).
+// * A 128-wide activation row-block lives in registers as X[4] (f32x16 each), the "chain layout":
+//       lane (slot, half), X[t][r]  <->  row `slot`, feature  32*t + (r&3) + 8*(r>>2) + 4*half
+//   This is exactly the C/D fragment layout of v_mfma_f32_32x32x2_f32 when the MFMA computes
+//   Y^T = W * X^T (rows = output features, cols = slots), AND exactly the A/B operand layout the
+//   next MFMA wants for its K index (lanes 0-31 supply k_lo, lanes 32-63 supply k_hi = k_lo + 4).
+//   So a GEMM chain  X -> act(W1 X) -> act(W2 .) -> ...  never leaves the register file.
+// * The LDS/global-resident operand (the weights) is pre-packed on the host into fragment order
+//       Wp[((tp*4 + t)*4 + q)*64 + lane]  (float4)  =  W[32*tp + slot][32*t + 8*q + 4*half + 0..3]
+//   so that one conflict-free ds_read_b128 (lane-linear, 1 KiB per wave) feeds four MFMAs.
+//   The same packed image serves both orientations:
+//     F1 (A = W fragment, B = X reg):  D[row = out feature][col = slot]   -> chain layout again
+//     F2 (A = X reg, B = W fragment):  D[row = slot][col = out feature]   -> "row layout":
+//        lane (nu = lane&31, half), acc[tp][r] <-> out feature 32*tp + nu, slot (r&3)+8*(r>>2)+4*half
+//   F2 is used for the last GEMM of a conv layer so that the per-destination segment sum becomes
+//   an in-lane sum over r (no cross-lane traffic, no atomics).
+// * Slot <-> CSR edge mapping inside a 32-edge tile: slot rho holds CSR edge
+//       base + PI(rho),  PI(rho) = 16*((rho>>2)&1) + (rho&3) + 4*(rho>>3)
+//   so that in the F2 row layout, (half, r) enumerates CSR edges base + 16*half + r in order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GAMD_H 128            // feature width of every hidden tensor (all shipped configs)
+#define GAMD_TILE 32          // rows per wave tile
+#define GAMD_CHUNK 16         // edges per (tile, half) = granularity of partial-sum pieces
+#define GAMD_WFRAG_FLOATS (GAMD_H * GAMD_H)   // one packed 128x128 weight = 64 KiB
+
+__device__ __forceinline__ int gamd_pi(int rho) {
+    return 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+}
+
+// feature index of chain-layout register (t, r) for a lane in `half`
+__device__ __forceinline__ int gamd_feat(int t, int r, int half) {
+    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// One 128x128 GEMM step of the chain.  W: packed fragment image (LDS or global), X: input in chain
+// layout, acc: accumulators (pre-initialised with bias / zeros by the caller).
+//   F2 == false:  acc (chain layout)  += W * X^T
+//   F2 == true :  acc (row layout)    += X * W^T
+template <bool F2, typename WPtr>
+__device__ __forceinline__ void gemm128_tile(WPtr W, int lane, const f32x16 (&X)[4], f32x16& acc, int tp) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = W[((tp * 4 + t) * 4 + q) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = X[t][q * 4 + j];
+                acc = F2 ? mfma32(x, w[j], acc) : mfma32(w[j], x, acc);
+            }
+        }
+    }
+}
+
+template <bool F2, typename WPtr>
+__device__ __forceinline__ void gemm128(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) gemm128_tile<F2>(W, lane, X, acc[tp], tp);
+}
+
+// ---- activations, written to match torch's fp32 CPU kernels op for op -------------------------
+__device__ __forceinline__ float gamd_silu(float x) {      // nn.SiLU: x * sigmoid(x) = x / (1 + exp(-x))
+    return x / (1.0f + expf(-x));
+}
+__device__ __forceinline__ float gamd_gelu(float x) {      // nn.GELU() default: exact erf form
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// torch.remainder for floats (result takes the sign of the divisor)
+__device__ __forceinline__ float gamd_remainder(float a, float b) {
+    float m = fmodf(a, b);
+    if (m != 0.0f && ((b < 0.0f) != (m < 0.0f))) m += b;
+    return m;
+}
+
+// minimum image exactly as nn_module.py:617-621: remainder(d + L/2, L) - L/2
+__device__ __forceinline__ float gamd_min_image(float d, float L, float halfL) {
+    return gamd_remainder(d + halfL, L) - halfL;
+}
+
+// bias fragment in chain layout: 16 float4 (one per (t,q)), from a plain [128] vector
+template <typename BPtr>
+__device__ __forceinline__ void load_bias_chain(BPtr b, int half, f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&b[32 * t + 8 * q + 4 * half]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][q * 4 + j] = v[j];
+        }
+}
+
+// row `row_ptr` (plain row-major [128] floats) -> chain layout registers (16 x 16-byte loads)
+__device__ __forceinline__ void load_row_chain(const float* __restrict__ row, int half, f32x16 (&X)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + 32 * t + 8 * q + 4 * half);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = v[j];
+        }
+}
+
+__device__ __forceinline__ void store_row_chain(float* __restrict__ row, int half, const f32x16 (&X)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = X[t][q * 4 + j];
+            *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q + 4 * half) = v;
+        }
+}
+
+// sum of a per-lane value over the two halves of a slot (lane l <-> l ^ 32)
+__device__ __forceinline__ float gamd_xhalf_sum(float v) {
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// LayerNorm over the 128 features of each slot, in place on chain-layout registers.
+// torch.nn.LayerNorm: biased variance, eps inside the sqrt.
+template <typename GPtr>
+__device__ __forceinline__ void layernorm_chain(f32x16 (&X)[4], GPtr gamma, GPtr beta, int half, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += X[t][r];
+    const float mean = gamd_xhalf_sum(s) * (1.0f / 128.0f);
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = X[t][r] - mean;
+            v += d * d;
+        }
+    const float var = gamd_xhalf_sum(v) * (1.0f / 128.0f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(&gamma[32 * t + 8 * q + 4 * half]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&beta[32 * t + 8 * q + 4 * half]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = (X[t][q * 4 + j] - mean) * rstd * g[j] + b[j];
+        }
+}
+
+// XCD-aware persistent work split: workgroup b is observed to run on XCD b % 8 (speed only, never
+// correctness).  Give each XCD one contiguous eighth of the tile range so that its private L2 sees a
+// compact slice of the node tables.  Returns the first tile and the stride via out params; caller
+// iterates  for (tile = first; tile < end; tile += step).
+__device__ __forceinline__ void gamd_xcd_range(int n_tiles, int block, int n_blocks, int& first, int& end, int& step) {
+    const int nx = 8;
+    if (n_blocks % nx != 0 || n_blocks < nx) { first = block; end = n_tiles; step = n_blocks; return; }
+    const int x = block % nx, w = block / nx, per = n_blocks / nx;
+    const int q = n_tiles / nx, rem = n_tiles % nx;
+    const int lo = x * q + (x < rem ? x : rem);
+    const int cnt = q + (x < rem ? 1 : 0);
+    first = lo + w; end = lo + cnt; step = per;
+}
+
+#define GAMD_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

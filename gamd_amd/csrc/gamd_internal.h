@@ -1,0 +1,127 @@
+// gamd_internal.h — kernel argument blocks and launcher prototypes shared by the .hip translation
+// units of libgamd_hip.so.  Not part of the public C ABI (that is include/gamd_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_COUNT = 8 };
+
+// ---- neighbour build --------------------------------------------------------------------------
+struct NbrArgs {
+    int n;                 // atoms
+    int flavour;           // 0: jax-md path (dr^2 < rc^2, self kept); 1: torch path (|dr| <= rc, no self)
+    float box[3], half[3]; // box and 0.5*box in fp32 (nn_module.py:617-621)
+    float rc, rc2;
+    int nc[3], ncell;
+    long long e_cap;       // edge capacity of col/erow/e_frag
+    const float* pos;      // [n][3] caller positions (any image)
+    const uint8_t* species;// [n] or null
+    float4* pos_w;         // [n] wrapped, original order
+    float4* pos_s;         // [n] wrapped, sorted order; .w = species
+    int* cell_of;          // [n]
+    int* cell_cnt;         // [ncell]
+    int* cell_fill;        // [ncell]
+    int* cell_start;       // [ncell+1]
+    int* perm;             // [n] sorted -> original
+    int* inv_perm;         // [n] original -> sorted
+    int* deg;              // [n]
+    int* row_ptr;          // [n+1]
+    int* na_excl;          // [n+1]
+    int* col;              // [e_cap] source (neighbour) atom, sorted index
+    int* erow;             // [e_cap] destination (centre) atom, sorted index
+    int* chunk_piece;      // [(e_cap+32)/16]
+    unsigned* chunk_mask;  // [(e_cap+32)/16]
+    int* counters;         // [CNT_COUNT]
+};
+int launch_neighbor_build(const NbrArgs& a, hipStream_t st);
+
+// ---- edge encoder -----------------------------------------------------------------------------
+struct EncArgs {
+    const int* counters;
+    const float4* pos_s;
+    const int* col;
+    const int* erow;
+    const int* bond_nbr;       // [n][4] original-index bonded partners (-1 pad) or null
+    const int* perm;           // sorted -> original (bond lookup)
+    float box[3], half[3];
+    float length_mean, length_std, gamma;
+    int n_feat;                // 44 or 45
+    int n_ksteps;              // ceil(n_feat/2)
+    const float* centers;      // [40]
+    const float* w1p;          // packed [4][6][64][4]  (K padded to 48)
+    const float* w2p;          // packed 128x128
+    const float* w3p;          // packed 128x128
+    const float* b1; const float* b2; const float* b3;   // [128]
+    const float* ln_g; const float* ln_b;                // [128]
+    float* e_frag;             // [tiles][4][4][64][4]
+    long long e_cap;
+    float* feat_dbg;           // optional [e_cap][48] raw features (debug/parity), or null
+};
+int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st);
+
+// ---- conv layer, edge side --------------------------------------------------------------------
+struct ConvEdgeArgs {
+    const int* counters;
+    const int* col;
+    const int* erow;
+    const int* chunk_piece;
+    const unsigned* chunk_mask;
+    const float* e_frag;
+    const float* hn;           // [n][128] LayerNorm'd node features
+    const float* S;            // [n][128] src_affine(hn) + b_src + b_dst + b_edge_affine2
+    const float* D;            // [n][128] dst_affine(hn) (no bias)
+    const float* w1p; const float* w2p; const float* w3p; const float* w4p;   // packed 128x128
+    const float* b1; const float* b3; const float* b4;                           // [128]
+    float* partial;            // [pieces][128]
+    long long e_cap;
+};
+int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
+
+// ---- node side --------------------------------------------------------------------------------
+struct NodeLayerW {            // one conv layer's node-side parameters (device pointers)
+    const float* ln_g; const float* ln_b;
+    const float* wsp; const float* wdp; const float* wpdp;   // packed src_affine, dst_affine, phi_dst
+    const float* bS;           // b_src + b_dst + b_edge_affine.2
+    const float* bP;           // b_phi_dst + b_phi_edge
+    const float* wpep;         // packed phi_edge
+    const float* wphip;        // packed phi.mlp_layer.1
+    const float* bphi;
+};
+struct NodeArgs {
+    int n;
+    int mode;                  // 0: first (embed + pre(0)); 1: post(l-1) + pre(l); 2: post(L-1) + decoder
+    // inputs
+    const float4* pos_s;       // .w = species feature
+    const float* node_emb;     // [128] (lj) or null
+    const float* enc_w; const float* enc_b;   // node_encoder Linear(1->128): weight[:,0], bias (water)
+    const int* row_ptr; const int* na_excl; const int* deg;
+    const float* partial;
+    const float* h_in;         // [n][128] residual stream before this layer's conv (mode 1,2)
+    const float* P_in;         // [n][128] phi_dst(hn)+biases from pre()
+    NodeLayerW post;           // layer being finished (mode 1,2)
+    NodeLayerW pre;            // layer being prepared (mode 0,1)
+    // decoder (mode 2)
+    const float* dec_w1p; const float* dec_b1; const float* dec_w2; const float* dec_b2;   // w2: [3][128] plain
+    float scale, shift;        // sqrt(var), mean of the force scaler (fp32 copy for the device path)
+    const int* perm;
+    // outputs
+    float* h_out;              // [n][128]
+    float* hn_out; float* S_out; float* D_out; float* P_out;
+    float* forces_norm;        // [n][3] normalised network output, ORIGINAL atom order (mode 2)
+    float* forces;             // [n][3] denormalised fp32 (device MD loop), original order, or null
+};
+int launch_node(const NodeArgs& a, hipStream_t st);
+
+// ---- integrator -------------------------------------------------------------------------------
+struct MdArgs {
+    int n;
+    float* x; float* v;        // [n][3] Angstrom, Angstrom/ps
+    const float* f;            // [n][3] kJ/mol/nm
+    float inv_mass;            // 1/amu
+    float dt;                  // ps
+    float a, b_sigma;          // exp(-gamma dt), sqrt(1-a^2)*sqrt(kT/m) [Angstrom/ps]
+    float box[3];
+    unsigned long long seed; unsigned long long step;
+};
+int launch_baoab_first(const MdArgs& a, hipStream_t st);    // B A O A  (hack_integrator.py:141-165)
+int launch_baoab_second(const MdArgs& a, hipStream_t st);   // B        (hack_integrator.py:175-178)

@@ -1,0 +1,225 @@
+// neighbor.hip — periodic cell-list radius search -> destination-sorted CSR, on device, no host sync.
+//
+// Replaces (reference, code/):
+//   graph_utils.py:21-26,29-44   jax-md partition.neighbor_list (cell list, padded dense idx)
+//   graph_utils.py:51-61         exact-cutoff mask  dr^2 < rc^2  (strict), self pair kept
+//   LJ/train_network_lj.py:166-185  dense -> COO compaction
+//   md_module.py:63-78,93-126    O(N^2) search of the dynamic-box model (norm <= rc, self excluded)
+//
+// Pipeline (all stream-ordered, sizes read from device memory by later kernels):
+//   bin -> scan(cells) -> fill cells -> sort each cell by atom id (determinism) -> gather sorted
+//   positions -> count neighbours (27-cell sweep) -> scan(deg) -> fill CSR -> chunk metadata.
+// Atoms are renumbered in cell order ("sorted order"); every later kernel works in that order, which
+// makes the h[src] gathers of a destination tile land in a compact slice of the node tables.
+#include "gamd_common.h"
+#include "gamd_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int cell_coord(float p, float box, int nc) {
+    int c = (int)floorf(p * ((float)nc / box));
+    return c < 0 ? 0 : (c >= nc ? nc - 1 : c);     // remainder() may round up to exactly `box`
+}
+
+__global__ void k_bin(NbrArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float4 p;
+    p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);    // graph_utils.py:31 jnp.mod(pos, box)
+    p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
+    p.z = gamd_remainder(a.pos[3 * i + 2], a.box[2]);
+    p.w = 0.f;
+    a.pos_w[i] = p;
+    const int c = (cell_coord(p.x, a.box[0], a.nc[0]) * a.nc[1] + cell_coord(p.y, a.box[1], a.nc[1])) * a.nc[2] +
+                  cell_coord(p.z, a.box[2], a.nc[2]);
+    a.cell_of[i] = c;
+    atomicAdd(&a.cell_cnt[c], 1);
+}
+
+// single-block exclusive scan, any length; out has n+1 entries (out[n] = total)
+template <typename F>
+__device__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? load(i) : 0;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wave_tot[wv] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; ++w) woff += wave_tot[w];
+        const int carry = carry_s;
+        if (i < n) out[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry_s;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_cells(NbrArgs a) {
+    block_exclusive_scan(a.ncell, [&](int i) { return a.cell_cnt[i]; }, a.cell_start);
+}
+
+__global__ void k_fill_cells(NbrArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int c = a.cell_of[i];
+    const int s = atomicAdd(&a.cell_fill[c], 1);
+    a.perm[a.cell_start[c] + s] = i;
+}
+
+// atomics above give an arbitrary order inside a cell; sort by original atom id so that the CSR
+// (and with it every floating-point summation order downstream) is bit-reproducible run to run.
+__global__ void k_sort_cells(NbrArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.ncell) return;
+    const int s = a.cell_start[c], e = a.cell_start[c + 1];
+    for (int i = s + 1; i < e; ++i) {
+        const int v = a.perm[i];
+        int j = i - 1;
+        while (j >= s && a.perm[j] > v) { a.perm[j + 1] = a.perm[j]; --j; }
+        a.perm[j + 1] = v;
+    }
+}
+
+__global__ void k_gather_sorted(NbrArgs a) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n) return;
+    const int i = a.perm[s];
+    float4 p = a.pos_w[i];
+    p.w = a.species ? (float)a.species[i] : 0.f;      // node feature rides along (O=1, H=0)
+    a.pos_s[s] = p;
+    a.inv_perm[i] = s;
+}
+
+// 27-cell sweep shared by the count and the fill pass.  visit(b) is called for every accepted
+// neighbour b (sorted index) of centre a, in a fixed order.
+template <typename V>
+__device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, V visit) {
+    const float4 pc = a.pos_s[ctr];
+    const int cx = cell_coord(pc.x, a.box[0], a.nc[0]);
+    const int cy = cell_coord(pc.y, a.box[1], a.nc[1]);
+    const int cz = cell_coord(pc.z, a.box[2], a.nc[2]);
+    // axes with fewer than 3 cells: visit every cell of that axis exactly once
+    const int lx = a.nc[0] >= 3 ? -1 : -cx, hx = a.nc[0] >= 3 ? 1 : a.nc[0] - 1 - cx;
+    const int ly = a.nc[1] >= 3 ? -1 : -cy, hy = a.nc[1] >= 3 ? 1 : a.nc[1] - 1 - cy;
+    const int lz = a.nc[2] >= 3 ? -1 : -cz, hz = a.nc[2] >= 3 ? 1 : a.nc[2] - 1 - cz;
+    for (int dx = lx; dx <= hx; ++dx) {
+        int x = cx + dx; x += x < 0 ? a.nc[0] : 0; x -= x >= a.nc[0] ? a.nc[0] : 0;
+        for (int dy = ly; dy <= hy; ++dy) {
+            int y = cy + dy; y += y < 0 ? a.nc[1] : 0; y -= y >= a.nc[1] ? a.nc[1] : 0;
+            for (int dz = lz; dz <= hz; ++dz) {
+                int z = cz + dz; z += z < 0 ? a.nc[2] : 0; z -= z >= a.nc[2] ? a.nc[2] : 0;
+                const int c = (x * a.nc[1] + y) * a.nc[2] + z;
+                const int s = a.cell_start[c], e = a.cell_start[c + 1];
+                for (int b = s; b < e; ++b) {
+                    const float4 pb = a.pos_s[b];
+                    // rel = pos[neigh] - pos[centre], min image (nn_module.py:615-621)
+                    const float rx = gamd_min_image(pb.x - pc.x, a.box[0], a.half[0]);
+                    const float ry = gamd_min_image(pb.y - pc.y, a.box[1], a.half[1]);
+                    const float rz = gamd_min_image(pb.z - pc.z, a.box[2], a.half[2]);
+                    const float d2 = (rx * rx + ry * ry) + rz * rz;
+                    bool ok;
+                    if (a.flavour == 0) ok = d2 < a.rc2;                      // graph_utils.py:59, self kept
+                    else ok = (sqrtf(d2) <= a.rc) && (b != ctr);              // md_module.py:111
+                    if (ok) visit(b);
+                }
+            }
+        }
+    }
+}
+
+__global__ void k_count(NbrArgs a) {
+    const int ctr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ctr >= a.n) return;
+    int cnt = 0;
+    sweep(a, ctr, [&](int) { ++cnt; });
+    a.deg[ctr] = cnt;
+}
+
+// row_ptr = exscan(deg); NA = inclusive count of non-empty segments that start off a chunk boundary;
+// publishes E, the piece count and the overflow flag.
+__global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
+    block_exclusive_scan(a.n, [&](int i) { return a.deg[i]; }, a.row_ptr);
+    __syncthreads();
+    block_exclusive_scan(a.n, [&](int i) { return (a.deg[i] > 0 && (a.row_ptr[i] % GAMD_CHUNK) != 0) ? 1 : 0; },
+                         a.na_excl);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int E = a.row_ptr[a.n];
+        a.counters[CNT_E] = E;
+        a.counters[CNT_PIECES] = (E + GAMD_CHUNK - 1) / GAMD_CHUNK + a.na_excl[a.n];
+        if ((long long)E > a.e_cap) a.counters[CNT_OVERFLOW] = 1;
+        a.counters[CNT_TILES] = (E + GAMD_TILE - 1) / GAMD_TILE;
+    }
+}
+
+__global__ void k_fill(NbrArgs a) {
+    const int ctr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ctr >= a.n) return;
+    long long w = a.row_ptr[ctr];
+    sweep(a, ctr, [&](int b) {
+        if (w < a.e_cap) { a.col[w] = b; a.erow[w] = ctr; }
+        ++w;
+    });
+}
+
+// per 16-edge chunk: first piece id and the bit mask of edges that close a destination segment
+__global__ void k_chunk_meta(NbrArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    long long E = a.counters[CNT_E];
+    if (E > a.e_cap) E = a.e_cap;
+    const long long x0 = (long long)c * GAMD_CHUNK;
+    if (x0 >= E) {
+        if (x0 < a.e_cap + GAMD_TILE) { a.chunk_piece[c] = 0; a.chunk_mask[c] = 0; }
+        return;
+    }
+    const int first_atom = a.erow[x0];
+    // pieces before this chunk: one per earlier chunk + one per off-boundary segment start <= x0
+    const int na_incl = a.na_excl[first_atom] +
+                        ((a.deg[first_atom] > 0 && (a.row_ptr[first_atom] % GAMD_CHUNK) != 0) ? 1 : 0);
+    a.chunk_piece[c] = c + na_incl;
+    unsigned mask = 0;
+    int prev = first_atom;
+    for (int r = 0; r < GAMD_CHUNK; ++r) {
+        const long long x = x0 + r;
+        if (x >= E) break;
+        const int nxt = (x + 1 < E) ? a.erow[x + 1] : -1;
+        if (nxt != prev) mask |= 1u << r;
+        prev = nxt;
+    }
+    a.chunk_mask[c] = mask;
+}
+
+}  // namespace
+
+int launch_neighbor_build(const NbrArgs& a, hipStream_t st) {
+    hipError_t e;
+    e = hipMemsetAsync(a.cell_cnt, 0, sizeof(int) * (size_t)a.ncell, st); if (e) return (int)e;
+    e = hipMemsetAsync(a.cell_fill, 0, sizeof(int) * (size_t)a.ncell, st); if (e) return (int)e;
+    e = hipMemsetAsync(a.counters, 0, sizeof(int) * CNT_COUNT, st); if (e) return (int)e;
+    const int tb = 256, gb = (a.n + tb - 1) / tb;
+    hipLaunchKernelGGL(k_bin, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_fill_cells, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sort_cells, dim3((a.ncell + 63) / 64), dim3(64), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
+    const int tc = 64, gc = (a.n + tc - 1) / tc;
+    hipLaunchKernelGGL(k_count, dim3(gc), dim3(tc), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_fill, dim3(gc), dim3(tc), 0, st, a); GAMD_CHECK_LAUNCH();
+    const long long nchunk_cap = (a.e_cap + GAMD_TILE) / GAMD_CHUNK;
+    hipLaunchKernelGGL(k_chunk_meta, dim3((unsigned)((nchunk_cap + 255) / 256)), dim3(256), 0, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}

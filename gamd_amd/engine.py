@@ -1,0 +1,242 @@
+"""Host side of the MI355X force path: `GamdForce.forward(pos, box, species) -> forces`.
+
+Mirrors what the reference's Python drivers call:
+``ParticleNetLightning.predict_forces`` (LJ/train_network_lj.py:133-157,
+water/train_network_tip3p.py:142-159) = neighbour search + model forward +
+denormalise.  PyTorch is used for device memory and streams only; all compute
+is in libgamd_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GamdConfig, GamdMdParams, check
+from .weights import ModelConfig, infer_config, validate_state_dict
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+KIND = {"lj": 0, "water": 1, "dynbox": 1}
+FLAVOUR = {"jaxmd": 0, "torch": 1}
+
+
+def _box3(box) -> np.ndarray:
+    b = np.asarray(box, dtype=np.float64).reshape(-1)
+    if b.size == 1:
+        b = np.repeat(b, 3)
+    if b.size != 3:
+        raise ValueError("box must be a scalar or 3 values")
+    return b.astype(np.float32)
+
+
+class GamdForce:
+    """One GPU-resident force model for a fixed atom count.
+
+    Parameters mirror build_model()/ParticleNetLightning.__init__ of the reference:
+    ``state_dict`` (reference key names), ``box``/``cutoff`` (BOX_SIZE / CUTOFF_RADIUS
+    module constants there), ``bond`` (create_water_bond) and the scaler (mean, var).
+    """
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], n_atoms: int, box, cutoff: float,
+                 bond: Optional[np.ndarray] = None, scaler: Tuple[float, float] = (0.0, 1.0),
+                 nbr_flavour: str = "jaxmd", device: int = 0, keep_stages: bool = False,
+                 edge_capacity: int = 0, cfg: Optional[ModelConfig] = None):
+        self._h = C.c_void_p()
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GamdError("GamdForce needs a HIP device (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        cfg = cfg or infer_config(state_dict)
+        if (cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim) != (128, 128, 128):
+            raise ValueError("the gfx950 kernels are built for the 128-wide shipped configs "
+                             f"(got enc={cfg.encoding_size} hidden={cfg.hidden_dim} edge={cfg.edge_embedding_dim})")
+        validate_state_dict(state_dict, cfg)
+        self.cfg = cfg
+        self.n = int(n_atoms)
+        self.device = torch.device("cuda", device)
+        self.box = _box3(box)
+        self.cutoff = float(cutoff)
+        c = GamdConfig()
+        c.n_atoms, c.kind, c.n_layers = self.n, KIND[cfg.kind], cfg.conv_layer
+        c.use_bond, c.nbr_flavour, c.device = int(cfg.use_bond), FLAVOUR[nbr_flavour], device
+        c.cutoff = self.cutoff
+        for d in range(3):
+            c.box[d] = float(self.box[d])
+        c.edge_capacity, c.keep_stages = int(edge_capacity), int(keep_stages)
+        check(self._lib.gamd_create(C.byref(c), C.byref(self._h)), "gamd_create")
+        self.keep_stages = keep_stages
+        for name, t in state_dict.items():
+            a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            check(self._lib.gamd_load_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
+                  f"gamd_load_weight({name})")
+        check(self._lib.gamd_finalize_weights(self._h), "gamd_finalize_weights")
+        self.set_scaler(*scaler)
+        if cfg.use_bond:
+            if bond is None:
+                raise ValueError("use_bond model needs the bond list")
+            b = np.ascontiguousarray(np.asarray(bond, dtype=np.int32))
+            check(self._lib.gamd_set_bonds(self._h, b.ctypes.data_as(C.c_void_p), b.shape[0]), "gamd_set_bonds")
+        self._out = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
+        self._out_den = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
+        self.last_status = 0
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.gamd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------------------------
+    def set_scaler(self, mean, var):
+        """load_training_stats (LJ/train_network_lj.py:119-123): mean/var of scaler.npz."""
+        self.scaler_mean = np.asarray(mean, dtype=np.float64).reshape(-1)[:1]
+        self.scaler_var = np.asarray(var, dtype=np.float64).reshape(-1)[:1]
+        check(self._lib.gamd_set_scaler(self._h, float(self.scaler_mean[0]), float(self.scaler_var[0])),
+              "gamd_set_scaler")
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev_pos(self, pos: ArrayLike) -> torch.Tensor:
+        if isinstance(pos, np.ndarray):
+            pos = torch.from_numpy(np.ascontiguousarray(pos, dtype=np.float32))
+        pos = pos.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(pos.shape) != (self.n, 3):
+            raise ValueError(f"pos must be [{self.n}, 3], got {tuple(pos.shape)}")
+        return pos
+
+    def _dev_species(self, species) -> Optional[torch.Tensor]:
+        if species is None:
+            return None
+        if isinstance(species, np.ndarray):
+            species = torch.from_numpy(species)
+        s = species.reshape(-1).to(device=self.device)
+        if s.numel() != self.n:
+            raise ValueError("species must have one entry per atom")
+        return (s != 0).to(torch.uint8).contiguous()
+
+    def _box_arg(self, box):
+        b = self.box if box is None else _box3(box)
+        return (C.c_float * 3)(*[float(x) for x in b])
+
+    # -- the hot path ----------------------------------------------------------------------------
+    def forward(self, pos: ArrayLike, box=None, species=None, denormalize: bool = False) -> torch.Tensor:
+        """pos [N,3] (any periodic image), box scalar/[3] (default: constructor box), species [N]
+        (O=1/H=0; ignored for LJ) -> network output [N,3] fp32 on the device, in the caller's atom
+        order.  Normalised like ``pnet_model(...)`` unless ``denormalize`` (then fp32 out*sqrt(var)+mean)."""
+        p = self._dev_pos(pos)
+        s = self._dev_species(species)
+        st = self._lib.gamd_forces(self._h, C.c_void_p(p.data_ptr()),
+                                   C.c_void_p(s.data_ptr()) if s is not None else None,
+                                   self._box_arg(box), C.c_void_p(self._out.data_ptr()),
+                                   C.c_void_p(self._out_den.data_ptr()), self._stream())
+        self.last_status = check(st, "gamd_forces")
+        return self._out_den if denormalize else self._out
+
+    __call__ = forward
+
+    def build_neighbors(self, pos: ArrayLike, box=None, species=None) -> int:
+        p = self._dev_pos(pos)
+        s = self._dev_species(species)
+        st = self._lib.gamd_build_neighbors(self._h, C.c_void_p(p.data_ptr()),
+                                            C.c_void_p(s.data_ptr()) if s is not None else None,
+                                            self._box_arg(box), self._stream())
+        return check(st, "gamd_build_neighbors")
+
+    def counts(self) -> Tuple[int, int, int]:
+        e, p, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._lib.gamd_get_counts(self._h, C.byref(e), C.byref(p), C.byref(c)), "gamd_get_counts")
+        return e.value, p.value, c.value
+
+    # -- stage getters for parity tests ----------------------------------------------------------
+    def _dbg(self, what: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        check(self._lib.gamd_debug_get(self._h, what, out.ctypes.data_as(C.c_void_p), out.nbytes), "gamd_debug_get")
+        return out
+
+    def debug_perm(self) -> np.ndarray:
+        return self._dbg(0, (self.n,), np.int32)
+
+    def debug_csr(self) -> Tuple[np.ndarray, np.ndarray]:
+        e = self.counts()[0]
+        return self._dbg(1, (self.n + 1,), np.int32), self._dbg(2, (e,), np.int32)
+
+    def debug_edges(self) -> np.ndarray:
+        """[2,E] (centre, neighbour) in ORIGINAL atom ids, CSR order."""
+        perm = self.debug_perm().astype(np.int64)
+        row_ptr, col = self.debug_csr()
+        dst = np.repeat(np.arange(self.n), np.diff(row_ptr))
+        return np.stack([perm[dst], perm[col]])
+
+    def debug_e(self) -> np.ndarray:
+        """e [E,128] de-fragmented to CSR edge order."""
+        e = self.counts()[0]
+        nt = (e + 31) // 32
+        frag = self._dbg(3, (nt, 4, 4, 64, 4), np.float32)
+        lane = np.arange(64)
+        slot, half = lane & 31, lane >> 5
+        pi = 16 * ((slot >> 2) & 1) + (slot & 3) + 4 * (slot >> 3)
+        out = np.zeros((nt * 32, 128), dtype=np.float32)
+        for t in range(4):
+            for q in range(4):
+                for j in range(4):
+                    feat = 32 * t + 8 * q + 4 * half + j           # per lane
+                    rows = (np.arange(nt)[:, None] * 32 + pi[None, :])
+                    out[rows, feat[None, :]] = frag[:, t, q, :, j]
+        return out[:e]
+
+    def debug_feat(self, n_feat: int) -> np.ndarray:
+        e = self.counts()[0]
+        return self._dbg(4, (e, 48), np.float32)[:, :n_feat]
+
+    def debug_h(self, layer: int) -> np.ndarray:
+        """residual stream h_layer [N,128] in ORIGINAL atom order."""
+        hs = self._dbg(16 + layer, (self.n, 128), np.float32)
+        out = np.empty_like(hs)
+        out[self.debug_perm()] = hs
+        return out
+
+    # -- on-device MD (split BAOAB of hack_integrator.py) ----------------------------------------
+    def md_run(self, x: torch.Tensor, v: torch.Tensor, f: torch.Tensor, n_steps: int, dt_ps=0.002,
+               mass_amu=39.9, temperature_k=100.0, gamma_per_ps=25.0, seed=0, first_step=0,
+               box=None, species=None, sync: bool = True) -> None:
+        """Advance (x, v, f) in place by n_steps; f holds denormalised forces (kJ/mol/nm) at x."""
+        for t in (x, v, f):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n, 3)
+        s = self._dev_species(species)
+        p = GamdMdParams(dt_ps, mass_amu, temperature_k, gamma_per_ps, seed, first_step)
+        st = self._lib.gamd_md_run(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()),
+                                   C.c_void_p(f.data_ptr()), C.c_void_p(s.data_ptr()) if s is not None else None,
+                                   self._box_arg(box), C.byref(p), int(n_steps), self._stream())
+        check(st, "gamd_md_run")
+        if sync:
+            check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
+
+    def sync_status(self) -> int:
+        return check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
+
+    def profile(self, pos: ArrayLike, box=None, species=None):
+        """Event-timed single forward: list of (kernel label, ms)."""
+        p = self._dev_pos(pos)
+        s = self._dev_species(species)
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        n = C.c_int32()
+        st = self._lib.gamd_profile(self._h, C.c_void_p(p.data_ptr()),
+                                    C.c_void_p(s.data_ptr()) if s is not None else None, self._box_arg(box),
+                                    C.c_void_p(self._out.data_ptr()), self._stream(), names, 4096, ms, 64, C.byref(n))
+        check(st, "gamd_profile")
+        labels = names.value.decode().strip().split("\n")
+        return list(zip(labels, [ms[i] for i in range(n.value)]))

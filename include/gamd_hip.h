@@ -1,0 +1,138 @@
+/* gamd_hip.h — C ABI of libgamd_hip.so, the MI355X (gfx950) implementation of GAMD's
+ * force-inference hot path.
+ *
+ * The reference has no FFI layer: its hot path sits behind Python objects
+ * (SURVEY.md §8b).  This header is the boundary a maintainer binds with ctypes
+ * (INTEGRATION.md shows the stub); every entry point names the reference
+ * interface it replaces (paths relative to /root/reference/code).
+ *
+ * Conventions
+ *   - plain C types only; all `*_dev` pointers are caller-owned DEVICE pointers,
+ *     all other pointers are HOST pointers; `stream` is a hipStream_t passed as void*
+ *     (NULL = default stream).  Work is stream-ordered.
+ *   - every function returns an int32 status: 0 = ok, 1 = ok after the neighbour
+ *     buffers overflowed and were regrown (the analogue of jax-md's
+ *     did_buffer_overflow -> re-allocate, graph_utils.py:41-42), < 0 = error
+ *     (text via gamd_last_error).  No exceptions cross the ABI.
+ *   - one handle per GPU, not thread-safe (the reference is single-threaded too).
+ *   - atoms keep the CALLER's order at the boundary; internally they are renumbered
+ *     in cell order every call.
+ */
+#ifndef GAMD_HIP_H
+#define GAMD_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gamd_handle gamd_handle;
+
+enum { GAMD_KIND_LJ = 0, GAMD_KIND_WATER = 1 };        /* SimpleMDNetNew | WaterMDNetNew / WaterMDDynamicBoxNet */
+enum { GAMD_NBR_JAXMD = 0, GAMD_NBR_TORCH = 1 };        /* dr^2 < rc^2 + self pair | |dr| <= rc, no self */
+
+/* Constructor arguments.  Replaces build_model() + NeighborSearcher(BOX_SIZE, cutoff):
+ * LJ/train_network_lj.py:68-88,108-112; water/train_network_tip3p.py:75-97;
+ * graph_utils.py:12-27.  hidden sizes are fixed at 128 (every shipped LJ/TIP config,
+ * LJ/test_script/test_langevin.py:63-73). */
+typedef struct gamd_config {
+    int32_t n_atoms;
+    int32_t kind;            /* GAMD_KIND_*  */
+    int32_t n_layers;        /* conv_layer (4 in build_model) */
+    int32_t use_bond;        /* water: 45th edge feature from the bond graph (nn_module.py:450-454) */
+    int32_t nbr_flavour;     /* GAMD_NBR_*  */
+    int32_t device;          /* HIP device ordinal */
+    float cutoff;            /* CUTOFF_RADIUS */
+    float box[3];            /* initial box (may change per call) */
+    int64_t edge_capacity;   /* 0 = estimate from density */
+    int32_t keep_stages;     /* 1 = keep per-stage tensors for the debug getters */
+    int32_t reserved;
+} gamd_config;
+
+const char* gamd_version(void);
+const char* gamd_last_error(void);
+
+int32_t gamd_create(const gamd_config* cfg, gamd_handle** out);
+int32_t gamd_destroy(gamd_handle* h);
+
+/* Weights contract = the reference state_dict: call once per key with the
+ * reference's key name (e.g. "graph_conv.conv.0.src_affine.weight"), fp32 host data, row-major
+ * torch shape; then gamd_finalize_weights packs them into MFMA fragment order on the device.
+ * Replaces model.load_state_dict / load_from_checkpoint (LJ/train_network_lj.py:85-87,
+ * LJ/test_script/test_langevin.py:74). */
+int32_t gamd_load_weight(gamd_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+int32_t gamd_finalize_weights(gamd_handle* h);
+
+/* scaler.npz mean/var.  Replaces load_training_stats (LJ/train_network_lj.py:119-123). */
+int32_t gamd_set_scaler(gamd_handle* h, double mean, double var);
+
+/* Bond list [n_bonds][2] (both directions are implied).  Replaces build_bond_graph
+ * (nn_module.py:529-534) fed by create_water_bond (water/train_network_tip3p.py:38-42). */
+int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds);
+
+/* Enqueue neighbour build + full network forward for positions `pos_dev` [n][3] fp32 (any periodic
+ * image), optional species [n] (u8: O=1/H=0 -> node feature, water/test_script/test_nosehoover.py:82-89),
+ * box[3].  Writes the NORMALISED network output [n][3] fp32 to out_norm_dev (what
+ * pnet_model([pos],[edge_idx]) returns, nn_module.py:672-685 / :545-558) and, if out_denorm_dev is not NULL,
+ * out*sqrt(var)+mean in fp32 (device-side copy of denormalize(), train_network_lj.py:128-131).
+ * Replaces search_for_neighbor + get_edge_idx + model.forward (LJ/train_network_lj.py:135-147,166-199).
+ * Does not synchronise; call gamd_sync_status afterwards. */
+int32_t gamd_forces_async(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                          float* out_norm_dev, float* out_denorm_dev, void* stream);
+
+/* Wait for the stream, report 0 / -ERANGE-style overflow.  On overflow the buffers have been regrown
+ * and the caller must re-issue the work (gamd_forces does that for you). */
+int32_t gamd_sync_status(gamd_handle* h, void* stream);
+
+/* gamd_forces_async + gamd_sync_status + automatic regrow-and-retry; returns 0 or 1. */
+int32_t gamd_forces(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                    float* out_norm_dev, float* out_denorm_dev, void* stream);
+
+/* Neighbour build only (stage entry point for parity tests / profiling). */
+int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                             void* stream);
+
+/* n_edges = directed edge count of the last build (incl. self edges in the jax-md flavour). */
+int32_t gamd_get_counts(gamd_handle* h, int64_t* n_edges, int64_t* n_pieces, int64_t* edge_capacity);
+
+/* Debug / parity getters: copy a stage tensor of the last call to HOST memory (synchronises).
+ * Need keep_stages = 1 for H / FEAT. */
+enum {
+    GAMD_DBG_PERM = 0,      /* int32 [n]      sorted -> original atom id */
+    GAMD_DBG_ROWPTR = 1,    /* int32 [n+1]    CSR by destination, sorted ids */
+    GAMD_DBG_COL = 2,       /* int32 [E]      source atom (sorted id) per CSR edge */
+    GAMD_DBG_EFRAG = 3,     /* fp32  [ceil(E/32)][4][4][64][4]  e in fragment order */
+    GAMD_DBG_FEAT = 4,      /* fp32  [E][48]  raw edge features (first 44|45 columns valid) */
+    GAMD_DBG_H0 = 16        /* fp32  [n][128] residual stream h_l, sorted order: GAMD_DBG_H0 + l */
+};
+int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t bytes);
+
+/* Split BAOAB Langevin step of the reference drivers, on device:
+ *   first half  B A O A   HackLangevinIntegrator     hack_integrator.py:141-165
+ *   force eval            predict_forces             LJ/test_script/test_langevin.py:108
+ *   second half B         HackHalfVelocityIntegrator hack_integrator.py:175-178
+ * x [n][3] Angstrom, v [n][3] Angstrom/ps, f [n][3] kJ/mol/nm (denormalised; in: forces at x, out: forces
+ * at the new x).  Enqueues n_steps steps without synchronising. */
+typedef struct gamd_md_params {
+    float dt_ps;             /* 0.002 in the drivers */
+    float mass_amu;          /* 39.9 for argon */
+    float temperature_k;     /* 100 */
+    float gamma_per_ps;      /* 25 */
+    uint64_t seed;
+    uint64_t first_step;     /* RNG counter of the first step */
+} gamd_md_params;
+int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
+                    const float* box, const gamd_md_params* p, int64_t n_steps, void* stream);
+
+/* Event-timed replay of one force evaluation: per-kernel milliseconds of the last gamd_profile call.
+ * names: newline-separated kernel labels; ms: one float per label.  For bench.py's roofline block. */
+int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                     float* out_norm_dev, void* stream, char* names, size_t names_bytes, float* ms, int32_t max_ms,
+                     int32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAMD_HIP_H */
