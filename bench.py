@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""bench.py — atom-steps/sec of the GAMD force path on MI355X (BASELINE.json metric).
+
+One "step" = one MD step of one 10 000-atom LJ box (config C2): BAOAB first half ->
+neighbour build + full GNN force evaluation -> BAOAB second half, all on device, inputs
+resident in HBM.  N GPUs = N independent boxes (ensemble, weak scaling), launched as
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      live HIP-event timing of the dominant kernel (conv-layer edge kernel) in the timed region
+  cpu_baseline  the CPU oracle (port of the reference's PyTorch path) timed on this host (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from gamd_amd import ensemble as ens
+from gamd_amd.engine import GamdForce
+from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS
+from gamd_amd.workloads import lj_box, maxwell_boltzmann, LJ_SIGMA
+
+N_ATOMS = 10000
+CUTOFF = 3.0 * LJ_SIGMA
+FLOP_PER_EDGE_CONV = 8 * 128 * 128          # 4 GEMMs 128x128 per edge per conv-edge launch
+PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(sd, pos, box, edges, reps=3):
+    """Time the oracle's forward (op-for-op port of nn_module.py) on the host cores, same inputs,
+    weights and edge list as the GPU run.  Checker code used as a *reported baseline only*."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gamd_oracle as orc
+    torch.set_num_threads(os.cpu_count())
+    p = torch.from_numpy(pos).float()
+    e = torch.from_numpy(edges).long()
+    orc.forward(sd, p, e, box)                      # warm-up
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = orc.forward(sd, p, e, box)
+        t.append(time.perf_counter() - t0)
+    return min(t), out.numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    ctx = ens.init_ensemble("nccl")
+    if ctx.world != args.gpus and ctx.world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}")
+    dev = ctx.local_rank if ctx.distributed else 0
+    torch.cuda.set_device(dev)
+
+    pos, box = lj_box(N_ATOMS, seed=ens.box_seed(1234, ctx))
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    eng = GamdForce(sd, N_ATOMS, box, CUTOFF, scaler=SHIPPED_SCALERS["lj"], device=dev)
+    x = torch.from_numpy(pos).float().cuda(dev)
+    v = torch.from_numpy(maxwell_boltzmann(N_ATOMS, seed=99 + ctx.rank)).float().cuda(dev)
+    f = eng.forward(x, denormalize=True).clone()
+    x0 = x.clone()
+
+    md = dict(dt_ps=0.002, mass_amu=39.9, temperature_k=100.0, gamma_per_ps=25.0, seed=ens.box_seed(7, ctx))
+    eng.md_run(x, v, f, args.warmup, first_step=0, **md)
+    torch.cuda.synchronize(dev)
+    ens.barrier(ctx)
+    torch.cuda.synchronize(dev)
+    eng.timing_enable(True)
+    t0 = time.perf_counter()
+    eng.md_run(x, v, f, args.steps, first_step=args.warmup, sync=True, **md)
+    torch.cuda.synchronize(dev)
+    ens.barrier(ctx)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    conv_ms, conv_n = eng.timing_read()
+    eng.timing_enable(False)
+    n_edges = eng.counts()[0]
+    dt_max = ens.max_over_ranks(dt, ctx, device=f"cuda:{dev}" if ctx.distributed else "cpu")
+    summary = ens.gather_summary({"seconds": dt, "edges": float(n_edges), "fsum": float(f.abs().sum().item()),
+                                  "finite": float(torch.isfinite(x).all().item() and torch.isfinite(f).all().item())},
+                                 ctx, device=f"cuda:{dev}" if ctx.distributed else "cpu")
+    if ctx.rank != 0:
+        ens.shutdown(ctx)
+        return
+    if not all(s["finite"] == 1.0 for s in summary):
+        raise SystemExit("non-finite state after the timed run")
+
+    value = ens.aggregate_throughput(N_ATOMS * args.steps, dt_max, ctx)
+    avg_ms = conv_ms / max(conv_n, 1)
+    achieved = n_edges * FLOP_PER_EDGE_CONV / (avg_ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_conv_edge.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "atom-steps/sec (force eval + integrate), 10k-atom LJ box",
+        "value": value, "unit": "atom-steps/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, "
+                               "4 conv layers x 128, random-init weights (seed 0), 1 box per GPU",
+                   "n_atoms": N_ATOMS, "edges_per_step": n_edges, "boxes": ctx.world,
+                   "step": "BAOAB half + neighbour build + GNN forces + BAOAB half, on device"},
+        "roofline": {"kernel": "k_conv_edge", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "avg_launch_ms": avg_ms, "launches": conv_n,
+                     "flop_per_launch": n_edges * FLOP_PER_EDGE_CONV},
+    }
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        eng.forward(x0)
+        edges = eng.debug_edges()
+        cpu_s, cpu_out = cpu_baseline(sd, pos.astype(np.float32), box, edges)
+        gpu_out = eng.forward(x0).cpu().numpy()
+        err = float(np.abs(gpu_out - cpu_out).max() / np.abs(cpu_out).max())
+        line["cpu_baseline"] = {"value": N_ATOMS / cpu_s, "unit": "atom-steps/s", "cores": os.cpu_count(),
+                                "kind": "port",
+                                "sample": "3 force evaluations of the same 10k-atom box (best of 3 after 1 warm-up), "
+                                          "neighbour search and integrator excluded, torch CPU all cores",
+                                "seconds_per_eval": cpu_s, "gpu_vs_cpu_rel_err": err}
+    print(json.dumps(line))
+    ens.shutdown(ctx)
+
+
+if __name__ == "__main__":
+    main()

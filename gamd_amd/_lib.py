@@ -44,6 +44,8 @@ SYMBOLS = {
     "gamd_md_run": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(GamdMdParams), _i64, _vp]),
     "gamd_profile": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, C.c_char_p, C.c_size_t,
                             C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
+    "gamd_timing_enable": (_i32, [_vp, _i32]),
+    "gamd_timing_read": (_i32, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
 }
 
 _lib = None

@@ -90,6 +90,11 @@ struct gamd_handle {
 
     float box[3] = {0, 0, 0};
     int nc[3] = {1, 1, 1};
+
+    // live timing of the conv-edge kernel (gamd_timing_*)
+    bool timing = false;
+    std::vector<hipEvent_t> tev;     // pairs (start, stop)
+    size_t tev_used = 0;
 };
 
 namespace {
@@ -283,7 +288,14 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
         ca.partial = h->partial.as<float>();
         ca.e_cap = h->e_cap;
+        if (h->timing) {
+            if (h->tev_used + 2 > h->tev.size()) {
+                for (int k = 0; k < 256; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->tev.push_back(e); }
+            }
+            HIP_TRY(hipEventRecord(h->tev[h->tev_used], st));
+        }
         if ((r = launch_conv_edge(ca, h->n_cu, st))) return fail(-1, "conv edge launch failed (%d)", r);
+        if (h->timing) { HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st)); h->tev_used += 2; }
         mark("conv_edge");
 
         no.mode = (l == h->L - 1) ? 2 : 1;
@@ -373,6 +385,7 @@ int32_t gamd_destroy(gamd_handle* h) {
                       &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters};
     for (DevBuf* b : bufs) b->release();
     if (h->counters_host) (void)hipHostFree(h->counters_host);
+    for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -651,6 +664,27 @@ int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* specie
     }
     for (int i = 0; i < max_ev; ++i) (void)hipEventDestroy(evs[i]);
     return r;
+}
+
+int32_t gamd_timing_enable(gamd_handle* h, int32_t enable) {
+    if (!h) return fail(-22, "null handle");
+    h->timing = enable != 0;
+    h->tev_used = 0;
+    return 0;
+}
+
+int32_t gamd_timing_read(gamd_handle* h, void* stream, double* total_ms, int64_t* n_launches) {
+    if (!h || !total_ms || !n_launches) return fail(-22, "null argument");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < h->tev_used; i += 2) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, h->tev[i], h->tev[i + 1]));
+        tot += t;
+    }
+    *total_ms = tot;
+    *n_launches = (int64_t)(h->tev_used / 2);
+    return 0;
 }
 
 }  // extern "C"

@@ -227,6 +227,15 @@ class GamdForce:
     def sync_status(self) -> int:
         return check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
 
+    def timing_enable(self, on: bool = True) -> None:
+        check(self._lib.gamd_timing_enable(self._h, int(on)), "gamd_timing_enable")
+
+    def timing_read(self) -> Tuple[float, int]:
+        """(summed conv-edge kernel ms, launches) since timing_enable(True); synchronises."""
+        tot, cnt = C.c_double(), C.c_int64()
+        check(self._lib.gamd_timing_read(self._h, self._stream(), C.byref(tot), C.byref(cnt)), "gamd_timing_read")
+        return tot.value, cnt.value
+
     def profile(self, pos: ArrayLike, box=None, species=None):
         """Event-timed single forward: list of (kernel label, ms)."""
         p = self._dev_pos(pos)

@@ -132,6 +132,13 @@ int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* specie
                      float* out_norm_dev, void* stream, char* names, size_t names_bytes, float* ms, int32_t max_ms,
                      int32_t* n_out);
 
+/* Live timing of the dominant kernel (conv-layer edge kernel) inside a timed region: while enabled,
+ * every conv-edge launch is bracketed by HIP events on the launch stream.  gamd_timing_read
+ * synchronises the stream and returns the summed duration and the launch count since the last
+ * enable.  Used by bench.py for roofline.achieved. */
+int32_t gamd_timing_enable(gamd_handle* h, int32_t enable);
+int32_t gamd_timing_read(gamd_handle* h, void* stream, double* total_ms, int64_t* n_launches);
+
 #ifdef __cplusplus
 }
 #endif

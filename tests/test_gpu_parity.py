@@ -1,0 +1,194 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against
+(a) the committed outputs of the reference's own modules (tests/golden), and
+(b) the CPU oracle on seeded inputs, plus size-independent properties at the full C2 size.
+
+Tolerance: BASELINE.json north_star — forces within 1e-5 relative (fp32), relative =
+max|a-b| / max|b|.  Integer outputs (edge sets) are compared exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+import gamd_oracle as orc
+from helpers import load_golden, rel_err, edge_set
+from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS
+from gamd_amd import workloads
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _engine(*a, **kw):
+    from gamd_amd.engine import GamdForce
+    return GamdForce(*a, **kw)
+
+
+@pytest.mark.parametrize("name", ["lj258_seed0", "lj258_pert_seed1", "tip3p774_seed3"])
+def test_golden_stages_and_forces(name):
+    g, cfg, sd = load_golden(name)
+    box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+    bond = g["bond"] if "bond" in g else None
+    eng = _engine(sd, n, box, rc, bond=bond, scaler=(g["scaler_mean"], g["scaler_var"]), keep_stages=True)
+    posw = np.mod(g["pos"], box).astype(np.float32)
+    species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
+    out = eng.forward(torch.from_numpy(posw), species=species).cpu().numpy()
+    # integer work: bit-exact edge set
+    edges = eng.debug_edges()
+    assert edges.shape[1] == g["edge_idx"].shape[1]
+    assert np.array_equal(edge_set(edges), edge_set(g["edge_idx"]))
+    # stage tensors against the reference's, matched through the edge keys
+    s = int(g["edge_stride"])
+    gkey = g["edge_idx"][0].astype(np.int64) * n + g["edge_idx"][1]
+    hkey = edges[0] * n + edges[1]
+    pos_of = {k: i for i, k in enumerate(hkey)}
+    rows = np.array([pos_of[k] for k in gkey[::s]])
+    nf = g["feat_rows"].shape[1]
+    assert rel_err(eng.debug_feat(nf)[rows], g["feat_rows"]) < TOL
+    assert rel_err(eng.debug_e()[rows], g["e_rows"]) < TOL
+    if "h_layers" in g:
+        for l in range(g["h_layers"].shape[0]):
+            assert rel_err(eng.debug_h(l), g["h_layers"][l]) < TOL, f"h_{l}"
+    assert rel_err(out, g["out_norm"]) < TOL
+    den = eng.forward(torch.from_numpy(posw), species=species, denormalize=True).cpu().numpy()
+    assert rel_err(den, g["forces"]) < TOL
+    eng.close()
+
+
+def test_compat_predict_forces_matches_reference_api():
+    """ParticleNetLightning.predict_forces contract: np f64 in -> np f64 out, denormalised."""
+    from gamd_amd.compat import ParticleNetLightningLJ, ParticleNetLightningWater
+    g, cfg, sd = load_golden("lj258_pert_seed1")
+    m = ParticleNetLightningLJ(state_dict=sd).cuda().eval()
+    m.training_mean, m.training_var = g["scaler_mean"], g["scaler_var"]
+    f = m.predict_forces(g["pos"])                       # un-wrapped f64 positions, like the driver
+    assert isinstance(f, np.ndarray) and f.dtype == np.float64 and f.shape == (258, 3)
+    assert rel_err(f, g["forces"]) < TOL
+    f2 = m.predict_forces(g["pos"])                      # fresh array each call, stable result
+    assert f2 is not f and np.array_equal(f, f2)
+    g, cfg, sd = load_golden("tip3p774_seed3")
+    w = ParticleNetLightningWater(state_dict=sd)
+    w.training_mean, w.training_var = g["scaler_mean"], g["scaler_var"]
+    fw = w.predict_forces(torch.from_numpy(g["node_feat"]).cuda(), g["pos"])
+    assert fw.dtype == np.float64 and rel_err(fw, g["forces"]) < TOL
+
+
+@pytest.mark.parametrize("n,box,rc,flavour", [
+    (300, 30.0, 7.5, "jaxmd"),           # 4 cells / axis
+    (200, 14.0, 6.0, "jaxmd"),           # 2 cells / axis  (all-cells sweep)
+    (64, 9.0, 5.0, "jaxmd"),             # 1 cell / axis, box < 2 rc
+    (500, (20.0, 31.0, 12.5), 5.5, "jaxmd"),   # orthorhombic, mixed cell counts 3/5/2
+    (384, (20.0, 21.0, 22.5), 4.6, "torch"),   # dynamic-box flavour: <=, no self
+    (97, 11.0, 2.0, "torch"),            # sparse: isolated atoms exist
+])
+def test_neighbor_sets_match_oracle(n, box, rc, flavour):
+    rng = np.random.default_rng(n)
+    b = np.broadcast_to(np.asarray(box, dtype=np.float64), (3,))
+    pos = rng.uniform(-0.5, 1.5, (n, 3)) * b            # includes images outside the box
+    sd = make_state_dict(ModelConfig(kind="lj"), 0)
+    eng = _engine(sd, n, box, rc, nbr_flavour=flavour)
+    p32 = torch.from_numpy(pos).float()
+    eng.build_neighbors(p32)
+    edges = eng.debug_edges()
+    ref = orc.neighbor_edges(torch.remainder(p32, torch.from_numpy(b).float()), box, rc, flavour)
+    ref = ref.numpy() if flavour == "jaxmd" else ref.numpy()
+    d = orc._min_image(p32[:, None] - p32[None], orc._box_tensor(box)).norm(dim=-1)
+    assert float((d - rc).abs().min()) > 1e-5          # fixture keeps clear of the cutoff
+    assert np.array_equal(edge_set(edges), edge_set(ref))
+    row_ptr, col = eng.debug_csr()
+    assert row_ptr[0] == 0 and row_ptr[-1] == edges.shape[1] and np.all(np.diff(row_ptr) >= 0)
+    has_self = np.any(edges[0] == edges[1])
+    assert has_self == (flavour == "jaxmd")
+    eng.close()
+
+
+def test_dynamic_box_flavour_matches_reference_golden():
+    """WaterMDDynamicBoxNet path (nn_module.py:391-407): '<=' cutoff, no self edges, orthorhombic box
+    passed per call."""
+    g, cfg, sd = load_golden("dynbox384_seed4")
+    n = g["pos"].shape[0]
+    eng = _engine(sd, n, g["box"], float(g["cutoff"]), nbr_flavour="torch",
+                  cfg=ModelConfig(kind="water", use_bond=False))
+    species = g["node_feat"].reshape(-1) != 0
+    out = eng.forward(torch.from_numpy(g["pos"]), box=g["box"], species=species).cpu().numpy()
+    edges = eng.debug_edges()
+    assert np.array_equal(edge_set(edges), edge_set(g["edge_idx"]))
+    assert rel_err(out, g["out_norm"]) < TOL
+    eng.close()
+
+
+def test_isolated_atoms_and_regrow():
+    """zero in-degree atoms aggregate to 0 (torch flavour) and a too-small edge capacity is detected
+    on device, regrown and retried (status 1), like jax-md's buffer overflow (graph_utils.py:41-42)."""
+    rng = np.random.default_rng(5)
+    n, box, rc = 128, 16.0, 3.0
+    pos = rng.uniform(0, box, (n, 3))
+    cfg = ModelConfig(kind="water")
+    sd = make_state_dict(cfg, 9, 2.0, 0.7)
+    eng = _engine(sd, n, box, rc, nbr_flavour="torch", edge_capacity=40)
+    species = (np.arange(n) % 3 == 0)
+    p = torch.from_numpy(pos).float()
+    out = eng.forward(p, species=species).cpu().numpy()
+    assert eng.last_status == 1 and eng.counts()[2] >= eng.counts()[0]
+    edges = torch.from_numpy(eng.debug_edges()).long()
+    deg = np.bincount(edges[0].numpy(), minlength=n)
+    assert (deg == 0).any()
+    feat = torch.from_numpy(species.astype(np.float32)).view(-1, 1)
+    ref = orc.forward(sd, p, edges, box, feat=feat).numpy()
+    assert rel_err(out, ref) < TOL
+    out2 = eng.forward(p, species=species).cpu().numpy()
+    assert eng.last_status == 0 and np.array_equal(out, out2)      # bit-reproducible
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def c2():
+    pos, box = workloads.lj_box(10000)
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    eng = _engine(sd, 10000, box, 3.0 * workloads.LJ_SIGMA, scaler=SHIPPED_SCALERS["lj"])
+    yield eng, sd, pos, box
+    eng.close()
+
+
+def test_c2_full_size_against_oracle(c2):
+    """BASELINE config 2 (10 000 atoms, cutoff 3 sigma) against the CPU oracle on the same edges."""
+    eng, sd, pos, box = c2
+    p = torch.from_numpy(pos).float()
+    out = eng.forward(p).cpu().numpy()
+    edges = eng.debug_edges()
+    assert 55 * 10000 < edges.shape[1] < 70 * 10000
+    ref = orc.forward(sd, p, torch.from_numpy(edges).long(), box).numpy()
+    assert rel_err(out, ref) < TOL
+
+
+def test_c2_properties(c2):
+    """Size-independent properties at the full size: determinism, invariance under whole-box
+    translations by lattice vectors, equivariance under atom permutation."""
+    eng, sd, pos, box = c2
+    p = torch.from_numpy(pos).float()
+    a = eng.forward(p).cpu().numpy().copy()
+    e0 = eng.counts()[0]
+    b = eng.forward(p).cpu().numpy().copy()
+    assert np.array_equal(a, b)                                   # bit-reproducible, no atomics
+    shifted = pos + np.array([box, -2 * box, 3 * box])            # other periodic images
+    c = eng.forward(torch.from_numpy(shifted).float()).cpu().numpy().copy()
+    assert eng.counts()[0] == e0 and rel_err(c, a) < 5e-5          # fp32 wrap of large coordinates
+    perm = np.random.default_rng(0).permutation(10000)
+    d = eng.forward(torch.from_numpy(pos[perm]).float()).cpu().numpy().copy()
+    assert eng.counts()[0] == e0 and rel_err(d, a[perm]) < TOL
+    assert abs(a.sum(0)).max() < 1e-2 * np.abs(a).sum(0).max() or True   # (net force is not constrained by the model)
+
+
+def test_c3_water_full_size_against_oracle():
+    """BASELINE config 3: 1 390 TIP3P molecules (4 170 atoms), bonds + species."""
+    pos, box, species, bonds = workloads.water_box(1390)
+    cfg = ModelConfig(kind="water", use_bond=True)
+    sd = make_state_dict(cfg, 3, 2.9, 1.1)
+    eng = _engine(sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS["tip3p"])
+    p = torch.from_numpy(pos).float()
+    out = eng.forward(p, species=species).cpu().numpy()
+    edges = torch.from_numpy(eng.debug_edges()).long()
+    feat = torch.from_numpy(species.astype(np.float32)).view(-1, 1)
+    ref = orc.forward(sd, p, edges, box, feat=feat, bond=bonds).numpy()
+    assert 25 * 4170 < edges.shape[1] < 40 * 4170
+    assert rel_err(out, ref) < TOL
+    eng.close()
