@@ -11,29 +11,103 @@
 // 32-edge tile and carries its activations through four 128x128 fp32 MFMA GEMMs in registers
 // (gamd_common.h).  The four weight matrices of the layer (4 x 64 KiB) are streamed L2 -> LDS with
 // global_load_lds into a two-slot ring, one matrix ahead of the GEMM that consumes it; one
-// workgroup barrier per GEMM phase.  The last GEMM runs in the F2 orientation so each lane ends up
-// with 16 edges x 1 feature: the multiply by hn[src] and the segment sum are then in-lane, and every
-// maximal run of edges (same destination, same 16-edge chunk) is written once as a "piece".  Pieces
-// are summed per atom, in order, by the node kernel -> no atomics, bit-reproducible.
+// workgroup barrier per GEMM phase.
+//
+// What the schedule is built around (measured with s_memtime, profiles/r01_conv_edge_cycles.md):
+// the two waves of a SIMD do NOT interleave their MFMA streams — the older wave owns the matrix pipe
+// until its GEMM is done, then the younger one runs.  A phase therefore costs
+//     (older wave: barrier release -> first MFMA) + 2 GEMMs + (younger wave: last MFMA -> barrier).
+// So: (1) everything a GEMM needs besides its LDS weights is loaded BEFORE the preceding barrier,
+// into whichever of the three 64-register sets is free, and stays in flight across the barrier
+// (raw s_barrier + counted vmcnt: only the weight DMA, issued earlier, must have landed);
+// (2) element-wise post-ops (SiLU, message, segment sum) of output tile tp-1 are issued in the
+// shadow of the MFMAs of tile tp, so only a quarter of them trails the last MFMA.
+//
+// The last GEMM runs in the F2 orientation so each lane ends up with 16 edges x 4 features: the
+// multiply by hn[src] and the segment sum are in-lane, and every maximal run of edges (same
+// destination, same 16-edge chunk) is written once as a "piece".  Pieces are summed per atom, in
+// order, by the node kernel -> no atomics, bit-reproducible.
 //
 // Roofline: MFMA-bound.  8*128*128 = 131072 FLOP per edge per launch against ~1.6 KB of traffic.
 #include "gamd_common.h"
 #include "gamd_internal.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
 
-__device__ __forceinline__ void stage_weight(const float* __restrict__ gw, float* ldsbuf, int wave, int lane) {
+// L2 -> LDS copy of one packed 64 KiB weight matrix, 8 x 1 KiB per wave.  lane16 is made opaque so
+// the 64-bit addresses are rebuilt (1 VALU each) instead of being hoisted out of the tile loop and
+// spilled (a spilled pointer = scratch reload + s_waitcnt vmcnt(0) in front of every copy).
+__device__ __forceinline__ void stage_weight(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
+    asm volatile("" : "+v"(lane16));
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int chunk = k * 8 + wave;      // 64 chunks of 1 KiB, lane-linear image == packed global image
+        const char* base = reinterpret_cast<const char*>(gw) + chunk * 1024;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(gw + chunk * 256 + lane * 4),
+            (const __attribute__((address_space(1))) void*)(base + lane16),
             (__attribute__((address_space(3))) void*)(ldsbuf + chunk * 256), 16, 0, 0);
     }
 }
 
+// x * sigmoid(x) on the hardware transcendental units: v_exp_f32 + v_rcp_f32 (1 ulp each).
+__device__ __forceinline__ float silu_hw(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// 128x128 GEMM of the chain with a software-pipelined element-wise post-op: while output tile tp is
+// being accumulated (64 MFMAs in 16 groups of 4), post(tp-1, g) finishes element g of the previous,
+// already complete, output tile.  Only tile 3's post-op trails the last MFMA.
+template <bool F2, typename WPtr, typename Post>
+__device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post) {
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = W[((tp * 4 + t) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = X[t][q * 4 + j];
+                    acc[tp] = F2 ? mfma32(x, w[j], acc[tp]) : mfma32(w[j], x, acc[tp]);
+                }
+                if (tp > 0) post(tp - 1, t * 4 + q);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) post(3, g);
+}
+
+// End of a phase: every wave has its own weight DMA (issued at the phase start, before the N most
+// recent VMEM loads) landed, then the workgroup meets.  The N prefetch loads stay in flight.
+// vmcnt retires in order, so "at most N outstanding" proves the older DMA is done only if at least
+// N loads really were issued after it: callers pass 0 on paths that skip the prefetch.
+template <int N>
+__device__ __forceinline__ void phase_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, int tile, int lane, f32x16 (&X)[4]) {
+    const f32x4* ef = (const f32x4*)e_frag + (size_t)tile * 16 * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = ef[(t * 4 + q) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = v[j];
+        }
+}
+
+// TIME: s_memtime instrumentation (profiling builds only, GAMD_CONV_VARIANT=1)
+template <bool TIME>
 __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* buf0 = lds;
@@ -42,136 +116,176 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     float* vb3 = vb1 + 128;
     float* vb4 = vb3 + 128;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slot = lane & 31, half = lane >> 5;
-    long long E = a.counters[CNT_E];
-    if (E > a.e_cap) E = a.e_cap;
-    const int n_tiles = (int)((E + GAMD_TILE - 1) / GAMD_TILE);
+    const int tid = threadIdx.x, lane = tid & 63, slot = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    int E = a.counters[CNT_E];
+    if ((long long)E > a.e_cap) E = (int)a.e_cap;
+    const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
     const int n_wg_tiles = (n_tiles + 7) / 8;
     int first, end, step;
     gamd_xcd_range(n_wg_tiles, blockIdx.x, gridDim.x, first, end, step);
     if (first >= end) return;
 
+    long long tacc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) tacc[i] = 0;
+    long long tprev = 0;
+#define TMARK(i) do { if (TIME) { const long long tn__ = (long long)__builtin_readcyclecounter(); tacc[i] += tn__ - tprev; tprev = tn__; } } while (0)
+
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
-    stage_weight(a.w1p, buf0, wave, lane);
+    stage_weight(a.w1p, buf0, wave, lane16);
+
+    // three 64-register sets rotate through the roles {GEMM input, GEMM output, prefetched gather}
+    f32x16 RA[4], RB[4], RC[4];
+
+    // per-lane edge of the current tile (slot order) and prefetch for the first tile
+    int tile = first * 8 + wave;
+    bool active = tile < n_tiles;
+    int src = 0, dst = 0;
+    {
+        const int x = tile * GAMD_TILE + gamd_pi(slot);
+        if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
+        if (active) {
+            load_e_tile(a.e_frag, tile, lane, RA);
+            load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
+        }
+    }
     __syncthreads();
+    if (TIME) tprev = (long long)__builtin_readcyclecounter();
 
     for (int wt = first; wt < end; wt += step) {
-        const int tile = wt * 8 + wave;
-        const bool active = tile < n_tiles;
-        const long long base = (long long)tile * GAMD_TILE;
-        const long long x = base + gamd_pi(slot);
-        const bool valid = active && x < E;
-        const int src = valid ? a.col[x] : 0;
-        const int dst = valid ? a.erow[x] : 0;
+        const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
+        int nvalid = E - x0;
+        nvalid = !active ? 0 : (nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid));
+        // next tile of this wave (indices prefetched during phase 3)
+        const int tile_n = (wt + step) * 8 + wave;
+        const bool active_n = (wt + step < end) && tile_n < n_tiles;
+        int src_n = 0, dst_n = 0;
 
-        f32x16 X[4], acc[4];
-        // ================= phase 1: T1 = SiLU(W1 e + b1) =================
-        stage_weight(a.w2p, buf1, wave, lane);
+        // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====
+        stage_weight(a.w2p, buf1, wave, lane16);
         if (active) {
-            const f32x4* ef = (const f32x4*)a.e_frag + (size_t)tile * 16 * 64;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = ef[(t * 4 + q) * 64 + lane];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = v[j];
-                }
-            load_bias_chain(vb1, half, acc);
-            gemm128<false>((const f32x4*)buf0, lane, X, acc);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) X[t][r] = gamd_silu(acc[t][r]);
-            // C-in of GEMM 2 = D[dst]; the loads fly across the barrier
-            load_row_chain(a.D + (size_t)dst * GAMD_H, half, acc);
+            load_bias_chain(vb1, half, RB);
+            TMARK(0);
+            gemm128_post<false>((const f32x4*)buf0, lane, RA, RB,
+                                [&](int tp, int g) { RB[tp][g] = silu_hw(RB[tp][g]); });
+            load_row_chain(a.S + (size_t)src * GAMD_H, half, RA);        // for phase 2's post-op
+            TMARK(1);
         }
-        __syncthreads();
-        // ================= phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]) =================
-        stage_weight(a.w3p, buf0, wave, lane);
+        if (active) phase_barrier<16>(); else phase_barrier<0>();
+        TMARK(2);
+        // ===== phase 2: RC = SiLU(W2 T1 + D[dst] + S[src])        in RB, S in RA =====
+        stage_weight(a.w3p, buf0, wave, lane16);
         if (active) {
-            f32x16 SD[4];
-            load_row_chain(a.S + (size_t)src * GAMD_H, half, SD);     // issued now, consumed after the GEMM
-            gemm128<false>((const f32x4*)buf1, lane, X, acc);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) X[t][r] = gamd_silu(acc[t][r] + SD[t][r]);
-        }
-        __syncthreads();
-        // ================= phase 3: T4 = SiLU(W3 T3 + b3) =================
-        stage_weight(a.w4p, buf1, wave, lane);
-        if (active) {
-            load_bias_chain(vb3, half, acc);
-            gemm128<false>((const f32x4*)buf0, lane, X, acc);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) X[t][r] = gamd_silu(acc[t][r]);
-        }
-        __syncthreads();
-        // ================= phase 4: e_emb = T4 W4^T + b4 (F2), message, segment sum =================
-        stage_weight(a.w1p, buf0, wave, lane);       // next tile's W1 (harmless on the last iteration)
-        if (active) {
-            const int chunk = tile * 2 + half;
-            const long long x0 = base + 16 * half;   // this half's 16 CSR edges: x0 + r
-            long long nv = E - x0;
-            const int nvalid = nv >= 16 ? 16 : (nv <= 0 ? 0 : (int)nv);
-            int srcs[16];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int4 c4 = *reinterpret_cast<const int4*>(a.col + x0 + 4 * g);
-                srcs[4 * g + 0] = c4.x; srcs[4 * g + 1] = c4.y; srcs[4 * g + 2] = c4.z; srcs[4 * g + 3] = c4.w;
-            }
-            f32x16 hv[4];
+            TMARK(3);
+            gemm128_post<false>((const f32x4*)buf1, lane, RB, RC,
+                                [&](int tp, int g) { RC[tp][g] = silu_hw(RC[tp][g] + RA[tp][g]); });
+            // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge); the source index of
+            // edge (half, r) lives in lane rho(r, half) of `src`
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int s = r < nvalid ? srcs[r] : 0;
+                const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int s = __shfl(src, rho, 64);
                 const float* hrow = a.hn + (size_t)s * GAMD_H + slot;
 #pragma unroll
-                for (int tp = 0; tp < 4; ++tp) hv[tp][r] = hrow[32 * tp];
+                for (int tp = 0; tp < 4; ++tp) RA[tp][r] = hrow[32 * tp];
             }
+            TMARK(4);
+        }
+        if (active) phase_barrier<63>(); else phase_barrier<0>();
+        TMARK(5);
+        // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
+        stage_weight(a.w4p, buf1, wave, lane16);
+        unsigned mask = 0;
+        int p0 = 0;
+        if (active) {
+            load_bias_chain(vb3, half, RB);
+            TMARK(6);
+            gemm128_post<false>((const f32x4*)buf0, lane, RC, RB,
+                                [&](int tp, int g) { RB[tp][g] = silu_hw(RB[tp][g]); });
+            mask = a.chunk_mask[tile * 2 + half];
+            p0 = a.chunk_piece[tile * 2 + half];
+            TMARK(7);
+        }
+        if (active_n) {
+            const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
+            if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
+        }
+        phase_barrier<0>();
+        TMARK(8);
+        // ===== phase 4: RC = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
+        stage_weight(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
+        if (active) {
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {
                 const float b = vb4[32 * tp + slot];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tp][r] = b;
+                for (int r = 0; r < 16; ++r) RC[tp][r] = b;
             }
-            gemm128<true>((const f32x4*)buf1, lane, X, acc);
-            const unsigned mask = a.chunk_mask[chunk];
-            const int p0 = a.chunk_piece[chunk];
-#pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                float* out = a.partial + 32 * tp + slot;
-                int p = p0;
-                float sum = 0.f;
-                bool open = false;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (r < nvalid) {
-                        sum = __fadd_rn(sum, __fmul_rn(hv[tp][r], acc[tp][r]));   // nn_module.py:142 u_mul_e, sum
-                        open = true;
-                        if ((mask >> r) & 1u) { out[(size_t)p * GAMD_H] = sum; sum = 0.f; ++p; open = false; }
+            TMARK(9);
+            float sum = 0.f;
+            int p = p0;
+            bool open = false;
+            // element (tp, r): message h[src] * e_emb, running sum over this lane's 16 edges, one store
+            // per finished piece (nn_module.py:142 u_mul_e -> sum)
+            gemm128_post<true>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
+                if (r == 0) { sum = 0.f; p = p0; open = false; }
+                if (r < nvalid) {
+                    sum = __fadd_rn(sum, __fmul_rn(RA[tp][r], RC[tp][r]));
+                    open = true;
+                    if ((mask >> r) & 1u) {
+                        a.partial[(size_t)p * GAMD_H + 32 * tp + slot] = sum;
+                        sum = 0.f; ++p; open = false;
                     }
                 }
-                if (open) out[(size_t)p * GAMD_H] = sum;       // run continues in the next chunk: own piece
-            }
+                if (r == 15 && open) a.partial[(size_t)p * GAMD_H + 32 * tp + slot] = sum;
+            });
+            TMARK(10);
         }
-        __syncthreads();
+        // prefetch the next tile's e (-> RA) and D[dst] (-> RC): in flight across the barrier
+        if (active_n) {
+            load_e_tile(a.e_frag, tile_n, lane, RA);
+            load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
+        }
+        if (active_n) phase_barrier<32>(); else phase_barrier<0>();
+        TMARK(11);
+        tile = tile_n; active = active_n; src = src_n; dst = dst_n;
     }
+    if (TIME && a.tdbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) a.tdbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = tacc[i];
+    }
+#undef TMARK
+}
+
+int conv_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* s = getenv("GAMD_CONV_VARIANT");
+        v = s ? atoi(s) : 0;
+        if (v < 0 || v > 1) v = 0;
+    }
+    return v;
+}
+
+template <bool TIME>
+int launch_variant(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
+    const size_t lds = sizeof(float) * CONV_LDS_FLOATS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge<TIME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess) return (int)e1;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv_edge<TIME>, dim3(n_blocks), dim3(512), lds, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
 }
 
 }  // namespace
 
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
-    const size_t lds = sizeof(float) * CONV_LDS_FLOATS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e1 != hipSuccess) return (int)e1;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_conv_edge, dim3(n_blocks), dim3(512), lds, st, a);
-    GAMD_CHECK_LAUNCH();
-    return 0;
+    // GAMD_CONV_VARIANT=1 selects the s_memtime-instrumented build (profiling only)
+    return conv_variant() == 1 ? launch_variant<true>(a, n_blocks, st) : launch_variant<false>(a, n_blocks, st);
 }

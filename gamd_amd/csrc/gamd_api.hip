@@ -84,7 +84,7 @@ struct gamd_handle {
     // edges
     long long e_cap = 0;
     DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg;
-    DevBuf counters;
+    DevBuf counters, tdbg;
     int* counters_host = nullptr;   // pinned
     bool has_bonds = false;
 
@@ -288,6 +288,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
         ca.partial = h->partial.as<float>();
         ca.e_cap = h->e_cap;
+        ca.tdbg = h->tdbg.as<long long>();
         if (h->timing) {
             if (h->tev_used + 2 > h->tev.size()) {
                 for (int k = 0; k < 256; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->tev.push_back(e); }
@@ -359,6 +360,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->f_norm.ensure(sizeof(float) * 3 * n, true);
     r |= h->f_den.ensure(sizeof(float) * 3 * n, true);
     r |= h->counters.ensure(sizeof(int) * CNT_COUNT, true);
+    r |= h->tdbg.ensure(sizeof(long long) * 16 * 8 * 1024, true);
     if (r) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
     if (hipHostMalloc((void**)&h->counters_host, sizeof(int) * CNT_COUNT) != hipSuccess) {
         gamd_destroy(h);
@@ -382,7 +384,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     DevBuf* bufs[] = {&h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
-                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters};
+                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg};
     for (DevBuf* b : bufs) b->release();
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
@@ -602,6 +604,7 @@ int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t byte
     } else if (what >= GAMD_DBG_H0 && what <= GAMD_DBG_H0 + h->L) {
         if (!h->cfg.keep_stages) return fail(-22, "H_l needs keep_stages=1");
         src = h->hbuf.as<float>() + (size_t)(what - GAMD_DBG_H0) * n * GAMD_H; avail = sizeof(float) * n * GAMD_H;
+    } else if (what == 5) { src = h->tdbg.p; avail = sizeof(long long) * 16 * 8 * (size_t)h->n_cu;
     } else return fail(-22, "unknown debug tensor %d", what);
     if (bytes < avail) return fail(-22, "host buffer too small: %zu < %zu", bytes, avail);
     HIP_TRY(hipMemcpy(host_out, src, avail, hipMemcpyDeviceToHost));

@@ -74,6 +74,7 @@ struct ConvEdgeArgs {
     const float* b1; const float* b3; const float* b4;                           // [128]
     float* partial;            // [pieces][128]
     long long e_cap;
+    long long* tdbg;           // profiling only: [blocks][8 waves][16] cycle sums (GAMD_CONV_VARIANT bit 4), or null
 };
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 

@@ -1,0 +1,95 @@
+// Probe: where does the conv-edge kernel lose MFMA throughput?  Times building blocks in isolation.
+//   mode 0: pure MFMA, 4 independent accumulators, operands in registers          (chip ceiling)
+//   mode 1: gemm128 from LDS-resident packed weights, chained, no barrier, no activation
+//   mode 2: mode 1 + hardware SiLU after every GEMM
+//   mode 3: mode 2 + one __syncthreads and one 64 KiB global_load_lds restage per GEMM (the kernel's phase)
+//   mode 4: mode 3 without SiLU
+#include "../gamd_common.h"
+#include <cstdio>
+#include <vector>
+
+__device__ __forceinline__ float silu_hw(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x16 X[4], acc[4];
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) { X[t][r] = 0.001f * (lane + r + t); acc[t][r] = 0.f; }
+    if (MODE == 0) {
+        float a = 0.5f + lane * 1e-3f, b = 0.25f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, b, acc[t]);
+            }
+        }
+    } else {
+        float* buf0 = lds; float* buf1 = lds + GAMD_WFRAG_FLOATS;
+        for (int i = tid; i < GAMD_WFRAG_FLOATS / 4; i += 512) { ((f32x4*)buf0)[i] = ((const f32x4*)W)[i]; ((f32x4*)buf1)[i] = ((const f32x4*)W)[i]; }
+        __syncthreads();
+        for (int it = 0; it < iters; ++it) {
+            float* cur = (it & 1) ? buf1 : buf0;
+            float* nxt = (it & 1) ? buf0 : buf1;
+            if (MODE >= 3) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int chunk = kk * 8 + wave;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + chunk * 256 + lane * 4),
+                                                     (__attribute__((address_space(3))) void*)(nxt + chunk * 256), 16, 0, 0);
+                }
+            }
+            for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.01f;
+            gemm128<false>((const f32x4*)cur, lane, X, acc);
+            if (MODE == 2 || MODE == 3) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) X[t][r] = silu_hw(acc[t][r]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) X[t] = acc[t] * 0.01f;
+            }
+            if (MODE >= 3) __syncthreads();
+        }
+    }
+    float s = 0.f;
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r] + X[t][r];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int MODE>
+double run(const float* dW, float* dOut, int iters) {
+    const size_t ldsb = sizeof(float) * 2 * GAMD_WFRAG_FLOATS;
+    hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<256, 512, ldsb>>>(dW, dOut, 4);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<MODE><<<256, 512, ldsb>>>(dW, dOut, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flop = 256.0 * 8 * iters * 256 * 4096.0;   // blocks*waves*iters*MFMAs*flop
+    return flop / (ms * 1e-3) / 1e12;
+}
+
+int main() {
+    std::vector<float> W(GAMD_WFRAG_FLOATS);
+    for (size_t i = 0; i < W.size(); ++i) W[i] = ((i * 2654435761u) % 1000) * 1e-5f - 0.005f;
+    float *dW, *dOut; hipMalloc(&dW, W.size() * 4); hipMalloc(&dOut, 256 * 512 * 4);
+    hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
+    const int iters = 400;
+    for (int rep = 0; rep < 2; ++rep) {
+        printf("mode0 pure mfma        : %.1f TF\n", run<0>(dW, dOut, iters));
+        printf("mode1 gemm128 from LDS : %.1f TF\n", run<1>(dW, dOut, iters));
+        printf("mode2 + silu           : %.1f TF\n", run<2>(dW, dOut, iters));
+        printf("mode3 + barrier+stage  : %.1f TF\n", run<3>(dW, dOut, iters));
+        printf("mode4 barrier+stage, no silu: %.1f TF\n", run<4>(dW, dOut, iters));
+    }
+    return 0;
+}
