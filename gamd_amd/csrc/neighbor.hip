@@ -16,6 +16,15 @@
 
 namespace {
 
+// remainder(d + L/2, L) - L/2 for |d| <= L (differences of wrapped coordinates): fmod is exact, so the
+// branch form below is bit-identical to gamd_min_image / torch.remainder on that range
+__device__ __forceinline__ float min_image_wrapped(float d, float L, float halfL) {
+    float t = d + halfL;
+    if (t < 0.0f) t += L;
+    else if (t >= L) t -= L;
+    return t - halfL;
+}
+
 __device__ __forceinline__ int cell_coord(float p, float box, int nc) {
     int c = (int)floorf(p * ((float)nc / box));
     return c < 0 ? 0 : (c >= nc ? nc - 1 : c);     // remainder() may round up to exactly `box`
@@ -80,32 +89,51 @@ __global__ void k_fill_cells(NbrArgs a) {
 
 // atomics above give an arbitrary order inside a cell; sort by original atom id so that the CSR
 // (and with it every floating-point summation order downstream) is bit-reproducible run to run.
-__global__ void k_sort_cells(NbrArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per cell: rank by counting (cells hold ~14 atoms), then gather the sorted positions.
+__global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
     if (c >= a.ncell) return;
-    const int s = a.cell_start[c], e = a.cell_start[c + 1];
-    for (int i = s + 1; i < e; ++i) {
-        const int v = a.perm[i];
-        int j = i - 1;
-        while (j >= s && a.perm[j] > v) { a.perm[j + 1] = a.perm[j]; --j; }
-        a.perm[j + 1] = v;
+    const int s = a.cell_start[c], e = a.cell_start[c + 1], cnt = e - s;
+    if (cnt <= 64) {
+        const int v = lane < cnt ? a.perm[s + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += (__shfl(v, j, 64) < v) ? 1 : 0;
+        if (lane < cnt) {
+            a.perm[s + rank] = v;                 // ids are distinct -> ranks are a permutation
+            float4 p = a.pos_w[v];
+            p.w = a.species ? (float)a.species[v] : 0.f;      // node feature rides along (O=1, H=0)
+            a.pos_s[s + rank] = p;
+            a.inv_perm[v] = s + rank;
+        }
+    } else {
+        if (lane == 0) {                          // over-full cell (cutoff >> spacing): serial fallback
+            for (int i = s + 1; i < e; ++i) {
+                const int v = a.perm[i];
+                int j = i - 1;
+                while (j >= s && a.perm[j] > v) { a.perm[j + 1] = a.perm[j]; --j; }
+                a.perm[j + 1] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int i = s + lane; i < e; i += 64) {
+            const int v = ((volatile int*)a.perm)[i];
+            float4 p = a.pos_w[v];
+            p.w = a.species ? (float)a.species[v] : 0.f;
+            a.pos_s[i] = p;
+            a.inv_perm[v] = i;
+        }
     }
 }
 
-__global__ void k_gather_sorted(NbrArgs a) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.n) return;
-    const int i = a.perm[s];
-    float4 p = a.pos_w[i];
-    p.w = a.species ? (float)a.species[i] : 0.f;      // node feature rides along (O=1, H=0)
-    a.pos_s[s] = p;
-    a.inv_perm[i] = s;
-}
-
-// 27-cell sweep shared by the count and the fill pass.  visit(b) is called for every accepted
-// neighbour b (sorted index) of centre a, in a fixed order.
+// 27-cell sweep shared by the count and the fill pass: one half-wave (32 lanes) per centre atom, lanes
+// test the atoms of a cell in parallel.  visit(ok, b) is called by every lane for every pass; the
+// accepted neighbours of a pass are compacted in lane order with a ballot, so the CSR order is fixed:
+// cells in (dx,dy,dz) order, atoms by ascending original id inside a cell.
 template <typename V>
-__device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, V visit) {
+__device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit) {
     const float4 pc = a.pos_s[ctr];
     const int cx = cell_coord(pc.x, a.box[0], a.nc[0]);
     const int cy = cell_coord(pc.y, a.box[1], a.nc[1]);
@@ -122,29 +150,40 @@ __device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, V visit) {
                 int z = cz + dz; z += z < 0 ? a.nc[2] : 0; z -= z >= a.nc[2] ? a.nc[2] : 0;
                 const int c = (x * a.nc[1] + y) * a.nc[2] + z;
                 const int s = a.cell_start[c], e = a.cell_start[c + 1];
-                for (int b = s; b < e; ++b) {
-                    const float4 pb = a.pos_s[b];
-                    // rel = pos[neigh] - pos[centre], min image (nn_module.py:615-621)
-                    const float rx = gamd_min_image(pb.x - pc.x, a.box[0], a.half[0]);
-                    const float ry = gamd_min_image(pb.y - pc.y, a.box[1], a.half[1]);
-                    const float rz = gamd_min_image(pb.z - pc.z, a.box[2], a.half[2]);
-                    const float d2 = (rx * rx + ry * ry) + rz * rz;
-                    bool ok;
-                    if (a.flavour == 0) ok = d2 < a.rc2;                      // graph_utils.py:59, self kept
-                    else ok = (sqrtf(d2) <= a.rc) && (b != ctr);              // md_module.py:111
-                    if (ok) visit(b);
+                for (int b0 = s; b0 < e; b0 += 32) {
+                    const int b = b0 + l;
+                    bool ok = false;
+                    if (b < e) {
+                        const float4 pb = a.pos_s[b];
+                        // rel = pos[neigh] - pos[centre], min image (nn_module.py:615-621)
+                        const float rx = min_image_wrapped(pb.x - pc.x, a.box[0], a.half[0]);
+                        const float ry = min_image_wrapped(pb.y - pc.y, a.box[1], a.half[1]);
+                        const float rz = min_image_wrapped(pb.z - pc.z, a.box[2], a.half[2]);
+                        const float d2 = (rx * rx + ry * ry) + rz * rz;
+                        if (a.flavour == 0) ok = d2 < a.rc2;                      // graph_utils.py:59, self kept
+                        else ok = (sqrtf(d2) <= a.rc) && (b != ctr);              // md_module.py:111
+                    }
+                    visit(ok, b);
                 }
             }
         }
     }
 }
 
-__global__ void k_count(NbrArgs a) {
-    const int ctr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ctr >= a.n) return;
+// my half-wave's 32-bit slice of a 64-lane ballot
+__device__ __forceinline__ unsigned half_ballot(bool p) {
+    const unsigned long long m = __ballot(p);
+    return (unsigned)(m >> (threadIdx.x & 32));
+}
+
+__global__ void __launch_bounds__(256) k_count(NbrArgs a) {
+    const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    const bool live = ctr < a.n;
     int cnt = 0;
-    sweep(a, ctr, [&](int) { ++cnt; });
-    a.deg[ctr] = cnt;
+    // both halves of a wave must run the same number of ballots: sweep a clamped atom, discard below
+    sweep(a, live ? ctr : a.n - 1, l, [&](bool ok, int) { cnt += __popc(half_ballot(ok)); });
+    if (live && l == 0) a.deg[ctr] = cnt;
 }
 
 // row_ptr = exscan(deg); NA = inclusive count of non-empty segments that start off a chunk boundary;
@@ -164,13 +203,19 @@ __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
     }
 }
 
-__global__ void k_fill(NbrArgs a) {
-    const int ctr = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ctr >= a.n) return;
-    long long w = a.row_ptr[ctr];
-    sweep(a, ctr, [&](int b) {
-        if (w < a.e_cap) { a.col[w] = b; a.erow[w] = ctr; }
-        ++w;
+__global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
+    const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    const bool live = ctr < a.n;
+    const int c = live ? ctr : a.n - 1;
+    long long w = a.row_ptr[c];
+    sweep(a, c, l, [&](bool ok, int b) {
+        const unsigned m = half_ballot(ok);
+        if (ok && live) {
+            const long long at = w + __popc(m & ((1u << l) - 1u));
+            if (at < a.e_cap) { a.col[at] = b; a.erow[at] = c; }
+        }
+        w += __popc(m);
     });
 }
 
@@ -212,12 +257,11 @@ int launch_neighbor_build(const NbrArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_bin, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_fill_cells, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sort_cells, dim3((a.ncell + 63) / 64), dim3(64), 0, st, a); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
-    const int tc = 64, gc = (a.n + tc - 1) / tc;
-    hipLaunchKernelGGL(k_count, dim3(gc), dim3(tc), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sort_gather, dim3((a.ncell + 3) / 4), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
+    const int ga = (a.n + 7) / 8;                      // 8 half-waves (atoms) per 256-thread block
+    hipLaunchKernelGGL(k_count, dim3(ga), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_fill, dim3(gc), dim3(tc), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_fill, dim3(ga), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
     const long long nchunk_cap = (a.e_cap + GAMD_TILE) / GAMD_CHUNK;
     hipLaunchKernelGGL(k_chunk_meta, dim3((unsigned)((nchunk_cap + 255) / 256)), dim3(256), 0, st, a);
     GAMD_CHECK_LAUNCH();

@@ -12,121 +12,180 @@
 //   post(l): agg = sum of this atom's partial-sum pieces, in order   (:142)
 //            h' = phi(P + phi_edge(agg)) + h                    (:147, :202 residual)
 //
-// One wave per 32-atom tile, activations chained through registers (gamd_common.h); the packed
-// weight fragments are read straight from L2 (no LDS: nothing is shared between waves here).
+// N is small (10^4 rows): the kernel is latency-bound, not throughput-bound, so a 32-atom tile is
+// split over the 4 waves of a workgroup by OUTPUT feature quarter: wave w computes features
+// [32w, 32w+32) of every GEMM (64 MFMAs instead of 256, its 16 KiB weight quarter read straight from
+// L2), and the full 128-wide activation row is re-assembled through a 16.5 KiB LDS exchange buffer
+// between chained GEMMs.  Activations are in the chain layout of gamd_common.h throughout.
 #include "gamd_common.h"
 #include "gamd_internal.h"
+#include <cstdlib>
 
 namespace {
 
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
+constexpr int XLD = 132;                       // padded row stride of the exchange buffer (floats)
+
+// acc (this wave's 32 output features x 32 atoms, one C tile) += W[quarter] * X^T
+__device__ __forceinline__ void gemm_quarter(const float* __restrict__ Wp, int quarter, int lane,
+                                             const f32x16 (&X)[4], f32x16& acc) {
+    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 16 * 64 + lane;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 w = W[(t * 4 + q) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma32(w[j], X[t][q * 4 + j], acc);
+        }
 }
 
-__global__ void __launch_bounds__(64) k_node(NodeArgs a) {
+// 16 floats of a plain row-major [128] row that belong to (quarter, half) in chain order
+__device__ __forceinline__ f32x16 load_slice(const float* __restrict__ row, int quarter, int half) {
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 32 * quarter + 8 * q + 4 * half);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[q * 4 + j] = x[j];
+    }
+    return v;
+}
+
+__device__ __forceinline__ void store_slice(float* __restrict__ row, int quarter, int half, const f32x16& v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = v[q * 4 + j];
+        *reinterpret_cast<f32x4*>(row + 32 * quarter + 8 * q + 4 * half) = x;
+    }
+}
+
+// every wave contributes its quarter; afterwards every wave holds the full row block in chain layout
+__device__ __forceinline__ void exchange(float* xbuf, int quarter, int slot, int half, const f32x16& mine,
+                                         f32x16 (&X)[4]) {
+    __syncthreads();                                        // previous readers are done
+    store_slice(xbuf + slot * XLD, quarter, half, mine);
+    __syncthreads();
+    load_row_chain(xbuf + slot * XLD, half, X);
+}
+
+__global__ void __launch_bounds__(256) k_node(NodeArgs a) {
+    __shared__ __attribute__((aligned(16))) float xbuf[32 * XLD];
+    __shared__ float obuf[4][32][3];
+    __shared__ float red[2][4][32];
+
     const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
+    const int quarter = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int atom_raw = blockIdx.x * GAMD_TILE + slot;
     const bool valid = atom_raw < a.n;
     const int atom = valid ? atom_raw : a.n - 1;
     const size_t row = (size_t)atom * GAMD_H;
 
-    f32x16 X[4], acc[4], hres[4];
+    f32x16 X[4];          // full activation row block (chain layout)
+    f32x16 mine;          // this wave's output quarter
 
     if (a.mode == 0) {
         if (a.node_emb) {
-            load_bias_chain(a.node_emb, half, hres);
+            mine = load_slice(a.node_emb, quarter, half);
         } else {
             const float f = a.pos_s[atom].w;                       // species feature (O=1, H=0)
-            f32x16 w[4];
-            load_bias_chain(a.enc_w, half, w);
-            load_bias_chain(a.enc_b, half, hres);
+            const f32x16 w = load_slice(a.enc_w, quarter, half);
+            mine = load_slice(a.enc_b, quarter, half);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hres[t][r] = f * w[t][r] + hres[t][r];
+            for (int r = 0; r < 16; ++r) mine[r] = f * w[r] + mine[r];
         }
+        if (valid) store_slice(a.h_out + row, quarter, half, mine);
     } else {
-        // ---- post(l-1): aggregate pieces -------------------------------------------------------
+        // ---- post(l-1): aggregate this quarter's slice of the pieces, in order ------------------
         const int rp0 = a.row_ptr[atom], dg = a.deg[atom];
         const int na_incl = a.na_excl[atom] + ((dg > 0 && (rp0 % GAMD_CHUNK) != 0) ? 1 : 0);
         const int p0 = rp0 / GAMD_CHUNK + na_incl;
         const int np = dg > 0 ? ((rp0 + dg - 1) / GAMD_CHUNK - rp0 / GAMD_CHUNK + 1) : 0;
-        zero_acc(X);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r] = 0.f;
         for (int k = 0; __any(k < np); ++k) {
-            if (k < np) {
-                const float* pr = a.partial + (size_t)(p0 + k) * GAMD_H;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(pr + 32 * t + 8 * q + 4 * half);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) X[t][q * 4 + j] += v[j];
-                    }
-            }
+            if (k < np) mine += load_slice(a.partial + (size_t)(p0 + k) * GAMD_H, quarter, half);
         }
-        load_row_chain(a.P_in + row, half, acc);
-        gemm128<false>((const f32x4*)a.post.wpep, lane, X, acc);
+        exchange(xbuf, quarter, slot, half, mine, X);            // X = agg
+        mine = load_slice(a.P_in + row, quarter, half);
+        gemm_quarter(a.post.wpep, quarter, lane, X, mine);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) X[t][r] = gamd_silu(acc[t][r]);
-        load_bias_chain(a.post.bphi, half, acc);
-        gemm128<false>((const f32x4*)a.post.wphip, lane, X, acc);
-        load_row_chain(a.h_in + row, half, hres);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hres[t][r] = acc[t][r] + hres[t][r];
+        for (int r = 0; r < 16; ++r) mine[r] = gamd_silu(mine[r]);
+        exchange(xbuf, quarter, slot, half, mine, X);            // X = SiLU(P + phi_edge(agg))
+        mine = load_slice(a.post.bphi, quarter, half);
+        gemm_quarter(a.post.wphip, quarter, lane, X, mine);
+        mine += load_slice(a.h_in + row, quarter, half);          // residual
+        if (valid) store_slice(a.h_out + row, quarter, half, mine);
     }
-    if (valid) store_row_chain(a.h_out + row, half, hres);
 
     if (a.mode != 2) {
-        // ---- pre(l) ----------------------------------------------------------------------------
+        // ---- pre(l): LayerNorm over the row = two cross-wave reductions of per-atom partial sums ----
+        float ps = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) X[t] = hres[t];
-        layernorm_chain(X, a.pre.ln_g, a.pre.ln_b, half, 1e-5f);
-        if (valid) store_row_chain(a.hn_out + row, half, X);
-        load_bias_chain(a.pre.bS, half, acc);
-        gemm128<false>((const f32x4*)a.pre.wsp, lane, X, acc);
-        if (valid) store_row_chain(a.S_out + row, half, acc);
-        zero_acc(acc);
-        gemm128<false>((const f32x4*)a.pre.wdp, lane, X, acc);
-        if (valid) store_row_chain(a.D_out + row, half, acc);
-        load_bias_chain(a.pre.bP, half, acc);
-        gemm128<false>((const f32x4*)a.pre.wpdp, lane, X, acc);
-        if (valid) store_row_chain(a.P_out + row, half, acc);
+        for (int r = 0; r < 16; ++r) ps += mine[r];
+        ps = gamd_xhalf_sum(ps);
+        if (half == 0) red[0][quarter][slot] = ps;
+        __syncthreads();
+        const float mean = ((red[0][0][slot] + red[0][1][slot]) + (red[0][2][slot] + red[0][3][slot])) * (1.0f / 128.0f);
+        float pv = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = mine[r] - mean; pv += d * d; }
+        pv = gamd_xhalf_sum(pv);
+        if (half == 0) red[1][quarter][slot] = pv;
+        __syncthreads();
+        const float var = ((red[1][0][slot] + red[1][1][slot]) + (red[1][2][slot] + red[1][3][slot])) * (1.0f / 128.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        {
+            const f32x16 g = load_slice(a.pre.ln_g, quarter, half), b = load_slice(a.pre.ln_b, quarter, half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r] = (mine[r] - mean) * rstd * g[r] + b[r];
+        }
+        if (valid) store_slice(a.hn_out + row, quarter, half, mine);
+        exchange(xbuf, quarter, slot, half, mine, X);            // X = hn
+        mine = load_slice(a.pre.bS, quarter, half);
+        gemm_quarter(a.pre.wsp, quarter, lane, X, mine);
+        if (valid) store_slice(a.S_out + row, quarter, half, mine);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r] = 0.f;
+        gemm_quarter(a.pre.wdp, quarter, lane, X, mine);
+        if (valid) store_slice(a.D_out + row, quarter, half, mine);
+        mine = load_slice(a.pre.bP, quarter, half);
+        gemm_quarter(a.pre.wpdp, quarter, lane, X, mine);
+        if (valid) store_slice(a.P_out + row, quarter, half, mine);
     } else {
         // ---- decoder: Lin(128,128) GELU Lin(128,3); denormalise -------------------------------
-        load_bias_chain(a.dec_b1, half, acc);
-        gemm128<false>((const f32x4*)a.dec_w1p, lane, hres, acc);
+        exchange(xbuf, quarter, slot, half, mine, X);            // X = h'
+        mine = load_slice(a.dec_b1, quarter, half);
+        gemm_quarter(a.dec_w1p, quarter, lane, X, mine);
         float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * quarter + 8 * q + 4 * half;
+            f32x4 g;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int f0 = 32 * t + 8 * q + 4 * half;
-                f32x4 g;
+            for (int j = 0; j < 4; ++j) g[j] = gamd_gelu(mine[q * 4 + j]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = gamd_gelu(acc[t][q * 4 + j]);
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(a.dec_w2 + c * GAMD_H + f0);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(a.dec_w2 + c * GAMD_H + f0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[c] += w[j] * g[j];
-                }
+                for (int j = 0; j < 4; ++j) o[c] += w[j] * g[j];
             }
+        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = gamd_xhalf_sum(o[c]) + a.dec_b2[c];
-        if (valid && half == 0) {
+        for (int c = 0; c < 3; ++c) o[c] = gamd_xhalf_sum(o[c]);
+        if (half == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) obuf[quarter][slot][c] = o[c];
+        }
+        __syncthreads();
+        if (quarter == 0 && half == 0 && valid) {
             const int orig = a.perm[atom];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                a.forces_norm[3 * (size_t)orig + c] = o[c];
-                if (a.forces) a.forces[3 * (size_t)orig + c] = o[c] * a.scale + a.shift;
+                const float v = ((obuf[0][slot][c] + obuf[1][slot][c]) + (obuf[2][slot][c] + obuf[3][slot][c])) + a.dec_b2[c];
+                a.forces_norm[3 * (size_t)orig + c] = v;
+                if (a.forces) a.forces[3 * (size_t)orig + c] = v * a.scale + a.shift;
             }
         }
     }
@@ -134,9 +193,10 @@ __global__ void __launch_bounds__(64) k_node(NodeArgs a) {
 
 }  // namespace
 
-int launch_node(const NodeArgs& a, hipStream_t st) {
+int launch_node(const NodeArgs& a0, hipStream_t st) {
+    const NodeArgs& a = a0;
     const int nb = (a.n + GAMD_TILE - 1) / GAMD_TILE;
-    hipLaunchKernelGGL(k_node, dim3(nb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_node, dim3(nb), dim3(256), 0, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
 }
