@@ -33,21 +33,38 @@ FLOP_PER_EDGE_CONV = 8 * 128 * 128          # 4 GEMMs 128x128 per edge per conv-
 PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def cpu_baseline(sd, pos, box, edges, reps=3):
-    """Time the oracle's forward (op-for-op port of nn_module.py) on the host cores, same inputs,
-    weights and edge list as the GPU run.  Checker code used as a *reported baseline only*."""
+CPU_SAMPLE_ATOMS = 2000
+
+
+def cpu_baseline(sd, dev):
+    """Time the oracle's forward (op-for-op port of nn_module.py, unfused nn.Linear on E gathered rows,
+    index_add_ aggregation) on the host cores, on a BOUNDED sample of the workload: a 2 000-atom LJ box of
+    the same density / cutoff / weights (cost is linear in atoms: ~64 edges per atom either way).
+    torch's CPU kernels stop scaling long before this host's core count, so a few thread counts are
+    tried and the best is reported with the threads it used.  Checker code, used as a *reported
+    baseline only*; the same sample is also evaluated on the GPU as a parity check."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gamd_oracle as orc
-    torch.set_num_threads(os.cpu_count())
+    pos, box = lj_box(CPU_SAMPLE_ATOMS, seed=4321)
     p = torch.from_numpy(pos).float()
-    e = torch.from_numpy(edges).long()
-    orc.forward(sd, p, e, box)                      # warm-up
-    t = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        out = orc.forward(sd, p, e, box)
-        t.append(time.perf_counter() - t0)
-    return min(t), out.numpy()
+    edges = orc.neighbor_edges(p, box, CUTOFF, "jaxmd")
+    best, best_thr, out = None, None, None
+    ncpu = os.cpu_count() or 1
+    for thr in sorted({min(ncpu, t) for t in (8, 16, 32)}):
+        torch.set_num_threads(thr)
+        orc.forward(sd, p, edges, box)                  # warm-up
+        for _ in range(2):
+            t0 = time.perf_counter()
+            out = orc.forward(sd, p, edges, box)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, best_thr = dt, thr
+    eng = GamdForce(sd, CPU_SAMPLE_ATOMS, box, CUTOFF, device=dev)
+    gpu = eng.forward(p).cpu().numpy()
+    same_edges = eng.counts()[0] == edges.shape[1]
+    eng.close()
+    err = float(np.abs(gpu - out.numpy()).max() / np.abs(out.numpy()).max())
+    return best, best_thr, int(edges.shape[1]), err, same_edges
 
 
 def main():
@@ -70,7 +87,6 @@ def main():
     x = torch.from_numpy(pos).float().cuda(dev)
     v = torch.from_numpy(maxwell_boltzmann(N_ATOMS, seed=99 + ctx.rank)).float().cuda(dev)
     f = eng.forward(x, denormalize=True).clone()
-    x0 = x.clone()
 
     md = dict(dt_ps=0.002, mass_amu=39.9, temperature_k=100.0, gamma_per_ps=25.0, seed=ens.box_seed(7, ctx))
     eng.md_run(x, v, f, args.warmup, first_step=0, **md)
@@ -122,16 +138,14 @@ def main():
                      "flop_per_launch": n_edges * FLOP_PER_EDGE_CONV},
     }
     if ctx.world == 1 and not args.no_cpu_baseline:
-        eng.forward(x0)
-        edges = eng.debug_edges()
-        cpu_s, cpu_out = cpu_baseline(sd, pos.astype(np.float32), box, edges)
-        gpu_out = eng.forward(x0).cpu().numpy()
-        err = float(np.abs(gpu_out - cpu_out).max() / np.abs(cpu_out).max())
-        line["cpu_baseline"] = {"value": N_ATOMS / cpu_s, "unit": "atom-steps/s", "cores": os.cpu_count(),
+        cpu_s, thr, cpu_edges, err, same_edges = cpu_baseline(sd, dev)
+        line["cpu_baseline"] = {"value": CPU_SAMPLE_ATOMS / cpu_s, "unit": "atom-steps/s", "cores": thr,
                                 "kind": "port",
-                                "sample": "3 force evaluations of the same 10k-atom box (best of 3 after 1 warm-up), "
-                                          "neighbour search and integrator excluded, torch CPU all cores",
-                                "seconds_per_eval": cpu_s, "gpu_vs_cpu_rel_err": err}
+                                "sample": f"force evaluation of a {CPU_SAMPLE_ATOMS}-atom LJ box (same density, cutoff "
+                                          f"and weights; {cpu_edges} edges), best of 2 after warm-up at the best of "
+                                          f"8/16/32 torch threads on a {os.cpu_count()}-thread host; neighbour search "
+                                          "and integrator excluded",
+                                "seconds_per_eval": cpu_s, "gpu_vs_cpu_rel_err": err, "same_edge_count": same_edges}
     print(json.dumps(line))
     ens.shutdown(ctx)
 
