@@ -107,7 +107,7 @@ __device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, in
 }
 
 // TIME: s_memtime instrumentation (profiling builds only, GAMD_CONV_VARIANT=1)
-template <bool TIME>
+template <bool TIME, int EXP>
 __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* buf0 = lds;
@@ -224,23 +224,35 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
                 for (int r = 0; r < 16; ++r) RC[tp][r] = b;
             }
             TMARK(9);
-            float sum = 0.f;
-            int p = p0;
-            bool open = false;
-            // element (tp, r): message h[src] * e_emb, running sum over this lane's 16 edges, one store
-            // per finished piece (nn_module.py:142 u_mul_e -> sum)
-            gemm128_post<true>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
-                if (r == 0) { sum = 0.f; p = p0; open = false; }
-                if (r < nvalid) {
-                    sum = __fadd_rn(sum, __fmul_rn(RA[tp][r], RC[tp][r]));
-                    open = true;
-                    if ((mask >> r) & 1u) {
-                        a.partial[(size_t)p * GAMD_H + 32 * tp + slot] = sum;
-                        sum = 0.f; ++p; open = false;
-                    }
-                }
-                if (r == 15 && open) a.partial[(size_t)p * GAMD_H + 32 * tp + slot] = sum;
+            // e_emb for this lane's 16 edges x 4 features, then message + segment sum (nn_module.py:142
+            // u_mul_e -> sum).  In-stream part is branch-free: RC[tp][r] becomes the running sum of the
+            // messages of the current piece (reset after every edge that closes a destination segment).
+            const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
+            gemm128_post<(EXP != 2)>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
+                if (EXP == 1 || EXP == 3) return;
+                const float prod = (r < nvalid) ? RA[tp][r] * RC[tp][r] : 0.f;
+                if (r == 0) RC[tp][0] = prod;
+                else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
             });
+            // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge
+            // does not close a segment, that edge too (the run continues in the next chunk as its own piece)
+            unsigned ends = mask;
+            if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends |= 1u << (nvalid - 1);
+            int p = p0;
+            while (__any(ends != 0)) {
+                if (ends != 0) {
+                    const int r = __builtin_ctz(ends);
+                    ends &= ends - 1;
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) {
+                        float v = RC[tp][0];
+#pragma unroll
+                        for (int k = 1; k < 16; ++k) v = (r == k) ? RC[tp][k] : v;
+                        a.partial[(size_t)p * GAMD_H + 32 * tp + slot] = v;
+                    }
+                    ++p;
+                }
+            }
             TMARK(10);
         }
         // prefetch the next tile's e (-> RA) and D[dst] (-> RC): in flight across the barrier
@@ -264,21 +276,21 @@ int conv_variant() {
     if (v < 0) {
         const char* s = getenv("GAMD_CONV_VARIANT");
         v = s ? atoi(s) : 0;
-        if (v < 0 || v > 1) v = 0;
+        if (v < 0 || v > 3) v = 0;
     }
     return v;
 }
 
-template <bool TIME>
+template <bool TIME, int EXP>
 int launch_variant(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * CONV_LDS_FLOATS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge<TIME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge<TIME, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return (int)e1;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_conv_edge<TIME>, dim3(n_blocks), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_conv_edge<TIME, EXP>), dim3(n_blocks), dim3(512), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
 }
@@ -287,5 +299,10 @@ int launch_variant(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
 
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     // GAMD_CONV_VARIANT=1 selects the s_memtime-instrumented build (profiling only)
-    return conv_variant() == 1 ? launch_variant<true>(a, n_blocks, st) : launch_variant<false>(a, n_blocks, st);
+    switch (conv_variant()) {
+        case 1: return launch_variant<true, 0>(a, n_blocks, st);
+        case 2: return launch_variant<true, 1>(a, n_blocks, st);     // experiment: no phase-4 post-op
+        case 3: return launch_variant<true, 2>(a, n_blocks, st);     // experiment: phase 4 in F1 orientation
+        default: return launch_variant<false, 0>(a, n_blocks, st);
+    }
 }

@@ -13,6 +13,23 @@ __device__ __forceinline__ float silu_hw(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// explicit one-group-ahead prefetch of the weight fragment
+template <bool F2, typename WPtr>
+__device__ __forceinline__ void gemm128_pf(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4]) {
+    f32x4 w = W[lane];
+#pragma unroll
+    for (int g = 0; g < 64; ++g) {
+        const int tp = g >> 4, t = (g >> 2) & 3, q = g & 3;
+        f32x4 wn = w;
+        if (g + 1 < 64) wn = W[(g + 1) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tp] = mfma32(w[j], X[t][q * 4 + j], acc[tp]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        w = wn;
+    }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* __restrict__ out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -36,7 +53,7 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
         for (int it = 0; it < iters; ++it) {
             float* cur = (it & 1) ? buf1 : buf0;
             float* nxt = (it & 1) ? buf0 : buf1;
-            if (MODE >= 3) {
+            if (MODE == 3 || MODE == 4 || MODE == 6) {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const int chunk = kk * 8 + wave;
@@ -45,8 +62,10 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
                 }
             }
             for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.01f;
-            gemm128<false>((const f32x4*)cur, lane, X, acc);
-            if (MODE == 2 || MODE == 3) {
+            if (MODE == 7) gemm128<true>((const f32x4*)cur, lane, X, acc);
+            else if (MODE >= 5) gemm128_pf<false>((const f32x4*)cur, lane, X, acc);
+            else gemm128<false>((const f32x4*)cur, lane, X, acc);
+            if (MODE == 2 || MODE == 3 || MODE == 6) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -55,7 +74,7 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
 #pragma unroll
                 for (int t = 0; t < 4; ++t) X[t] = acc[t] * 0.01f;
             }
-            if (MODE >= 3) __syncthreads();
+            if (MODE == 3 || MODE == 4 || MODE == 6) __syncthreads();
         }
     }
     float s = 0.f;
@@ -64,17 +83,17 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
 }
 
 template <int MODE>
-double run(const float* dW, float* dOut, int iters) {
+double run(const float* dW, float* dOut, int iters, int threads = 512) {
     const size_t ldsb = sizeof(float) * 2 * GAMD_WFRAG_FLOATS;
     hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<MODE><<<256, 512, ldsb>>>(dW, dOut, 4);
+    k<MODE><<<256, threads, ldsb>>>(dW, dOut, 4);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<MODE><<<256, 512, ldsb>>>(dW, dOut, iters);
+    k<MODE><<<256, threads, ldsb>>>(dW, dOut, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double flop = 256.0 * 8 * iters * 256 * 4096.0;   // blocks*waves*iters*MFMAs*flop
+    const double flop = 256.0 * (threads / 64) * iters * 256 * 4096.0;   // blocks*waves*iters*MFMAs*flop
     return flop / (ms * 1e-3) / 1e12;
 }
 
@@ -90,6 +109,12 @@ int main() {
         printf("mode2 + silu           : %.1f TF\n", run<2>(dW, dOut, iters));
         printf("mode3 + barrier+stage  : %.1f TF\n", run<3>(dW, dOut, iters));
         printf("mode4 barrier+stage, no silu: %.1f TF\n", run<4>(dW, dOut, iters));
+        printf("mode5 prefetch gemm (8 waves)        : %.1f TF\n", run<5>(dW, dOut, iters));
+        printf("mode6 prefetch + silu + barrier+stage: %.1f TF\n", run<6>(dW, dOut, iters));
+        printf("mode7 gemm128 F2 orientation (8 waves): %.1f TF\n", run<7>(dW, dOut, iters));
+        printf("mode1 4 waves/CU (1 per SIMD)        : %.1f TF\n", run<1>(dW, dOut, iters, 256));
+        printf("mode5 4 waves/CU prefetch            : %.1f TF\n", run<5>(dW, dOut, iters, 256));
+        printf("mode2 4 waves/CU + silu              : %.1f TF\n", run<2>(dW, dOut, iters, 256));
     }
     return 0;
 }
