@@ -53,12 +53,6 @@ __device__ __forceinline__ void stage_weight(const float* __restrict__ gw, float
     }
 }
 
-// x * sigmoid(x) on the hardware transcendental units: v_exp_f32 + v_rcp_f32 (1 ulp each).
-__device__ __forceinline__ float silu_hw(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
 // 128x128 GEMM of the chain with a software-pipelined element-wise post-op: while output tile tp is
 // being accumulated (64 MFMAs in 16 groups of 4), post(tp-1, g) finishes element g of the previous,
 // already complete, output tile.  Only tile 3's post-op trails the last MFMA.
@@ -107,7 +101,7 @@ __device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, in
 }
 
 // TIME: s_memtime instrumentation (profiling builds only, GAMD_CONV_VARIANT=1)
-template <bool TIME, int EXP>
+template <bool TIME>
 __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* buf0 = lds;
@@ -153,6 +147,8 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     }
     __syncthreads();
     if (TIME) tprev = (long long)__builtin_readcyclecounter();
+    unsigned pend_ends = 0;           // piece stores of the tile just finished (issued after its last barrier)
+    int pend_p = 0;
 
     for (int wt = first; wt < end; wt += step) {
         const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
@@ -169,7 +165,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             load_bias_chain(vb1, half, RB);
             TMARK(0);
             gemm128_post<false>((const f32x4*)buf0, lane, RA, RB,
-                                [&](int tp, int g) { RB[tp][g] = silu_hw(RB[tp][g]); });
+                                [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
             load_row_chain(a.S + (size_t)src * GAMD_H, half, RA);        // for phase 2's post-op
             TMARK(1);
         }
@@ -180,7 +176,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         if (active) {
             TMARK(3);
             gemm128_post<false>((const f32x4*)buf1, lane, RB, RC,
-                                [&](int tp, int g) { RC[tp][g] = silu_hw(RC[tp][g] + RA[tp][g]); });
+                                [&](int tp, int g) { RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]); });
             // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge); the source index of
             // edge (half, r) lives in lane rho(r, half) of `src`
 #pragma unroll
@@ -199,18 +195,21 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         stage_weight(a.w4p, buf1, wave, lane16);
         unsigned mask = 0;
         int p0 = 0;
+        // small index loads for phase 4 / the next tile go first: done long before the barrier needs vmcnt(0)
         if (active) {
-            load_bias_chain(vb3, half, RB);
-            TMARK(6);
-            gemm128_post<false>((const f32x4*)buf0, lane, RC, RB,
-                                [&](int tp, int g) { RB[tp][g] = silu_hw(RB[tp][g]); });
             mask = a.chunk_mask[tile * 2 + half];
             p0 = a.chunk_piece[tile * 2 + half];
-            TMARK(7);
         }
         if (active_n) {
             const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
             if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
+        }
+        if (active) {
+            load_bias_chain(vb3, half, RB);
+            TMARK(6);
+            gemm128_post<false>((const f32x4*)buf0, lane, RC, RB,
+                                [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
+            TMARK(7);
         }
         phase_barrier<0>();
         TMARK(8);
@@ -228,40 +227,40 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             // u_mul_e -> sum).  In-stream part is branch-free: RC[tp][r] becomes the running sum of the
             // messages of the current piece (reset after every edge that closes a destination segment).
             const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
-            gemm128_post<(EXP != 2)>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
-                if (EXP == 1 || EXP == 3) return;
+            gemm128_post<true>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
                 const float prod = (r < nvalid) ? RA[tp][r] * RC[tp][r] : 0.f;
                 if (r == 0) RC[tp][0] = prod;
                 else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
             });
-            // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge
-            // does not close a segment, that edge too (the run continues in the next chunk as its own piece)
-            unsigned ends = mask;
-            if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends |= 1u << (nvalid - 1);
-            int p = p0;
-            while (__any(ends != 0)) {
-                if (ends != 0) {
-                    const int r = __builtin_ctz(ends);
-                    ends &= ends - 1;
-#pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) {
-                        float v = RC[tp][0];
-#pragma unroll
-                        for (int k = 1; k < 16; ++k) v = (r == k) ? RC[tp][k] : v;
-                        a.partial[(size_t)p * GAMD_H + 32 * tp + slot] = v;
-                    }
-                    ++p;
-                }
-            }
+            // piece stores are deferred past the barrier (vmcnt counts stores too: issued here they would sit
+            // in front of the prefetch loads and the counted wait below would wait for their write latency)
+            pend_ends = mask;
+            if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) pend_ends |= 1u << (nvalid - 1);
+            pend_p = p0;
             TMARK(10);
         }
-        // prefetch the next tile's e (-> RA) and D[dst] (-> RC): in flight across the barrier
-        if (active_n) {
-            load_e_tile(a.e_frag, tile_n, lane, RA);
-            load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
-        }
-        if (active_n) phase_barrier<32>(); else phase_barrier<0>();
+        // prefetch the next tile's e (-> RA): in flight across the barrier
+        if (active_n) load_e_tile(a.e_frag, tile_n, lane, RA);
+        if (active_n) phase_barrier<16>(); else phase_barrier<0>();
         TMARK(11);
+        // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge does
+        // not close a segment, that edge too (the run continues in the next chunk as its own piece)
+        while (__any(pend_ends != 0)) {
+            if (pend_ends != 0) {
+                const int r = __builtin_ctz(pend_ends);
+                pend_ends &= pend_ends - 1;
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    float v = RC[tp][0];
+#pragma unroll
+                    for (int k = 1; k < 16; ++k) v = (r == k) ? RC[tp][k] : v;
+                    a.partial[(size_t)pend_p * GAMD_H + 32 * tp + slot] = v;
+                }
+                ++pend_p;
+            }
+        }
+        // D[dst] of the next tile (C-in of its phase 2) -> RC, now free; lands during phase 1
+        if (active_n) load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
         tile = tile_n; active = active_n; src = src_n; dst = dst_n;
     }
     if (TIME && a.tdbg && lane == 0) {
@@ -276,21 +275,21 @@ int conv_variant() {
     if (v < 0) {
         const char* s = getenv("GAMD_CONV_VARIANT");
         v = s ? atoi(s) : 0;
-        if (v < 0 || v > 3) v = 0;
+        if (v < 0 || v > 1) v = 0;
     }
     return v;
 }
 
-template <bool TIME, int EXP>
+template <bool TIME>
 int launch_variant(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * CONV_LDS_FLOATS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge<TIME, EXP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge<TIME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return (int)e1;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_conv_edge<TIME, EXP>), dim3(n_blocks), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(k_conv_edge<TIME>, dim3(n_blocks), dim3(512), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
 }
@@ -299,10 +298,5 @@ int launch_variant(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
 
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     // GAMD_CONV_VARIANT=1 selects the s_memtime-instrumented build (profiling only)
-    switch (conv_variant()) {
-        case 1: return launch_variant<true, 0>(a, n_blocks, st);
-        case 2: return launch_variant<true, 1>(a, n_blocks, st);     // experiment: no phase-4 post-op
-        case 3: return launch_variant<true, 2>(a, n_blocks, st);     // experiment: phase 4 in F1 orientation
-        default: return launch_variant<false, 0>(a, n_blocks, st);
-    }
+    return conv_variant() == 1 ? launch_variant<true>(a, n_blocks, st) : launch_variant<false>(a, n_blocks, st);
 }

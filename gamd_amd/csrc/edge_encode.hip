@@ -11,13 +11,14 @@
 // layout the conv-layer kernel loads with perfectly coalesced 16-byte reads.
 #include "gamd_common.h"
 #include "gamd_internal.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int ENC_W1_FLOATS = 4 * 6 * 64 * 4;              // K padded to 48 (24 MFMA steps)
 constexpr int ENC_LDS_FLOATS = ENC_W1_FLOATS + 2 * GAMD_WFRAG_FLOATS + 5 * 128 + 64;
 
-template <int NFEAT>
+template <int NFEAT, int ABL>
 __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w1 = lds;
@@ -53,18 +54,30 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
 
     constexpr int KSTEPS = (NFEAT + 1) / 2;      // 22 (LJ) or 23 (water + bond flag)
 
+    // geometry of the first tile; every iteration then prefetches the next tile's indices and positions
+    // (a three-deep dependent load chain) behind the current tile's GEMMs
+    int E32 = (int)E;
+    auto fetch_idx = [&](int tile, int& src, int& dst) {
+        const int x = tile * GAMD_TILE + gamd_pi(slot);
+        src = 0; dst = 0;
+        if (tile < n_tiles && x < E32) { src = a.col[x]; dst = a.erow[x]; }
+    };
+    int src_c, dst_c;
+    fetch_idx(first * 8 + wave, src_c, dst_c);
+    float4 ps = a.pos_s[src_c], pd = a.pos_s[dst_c];
+
     for (int wt = first; wt < end; wt += step) {
         const int tile = wt * 8 + wave;
+        int src_n, dst_n;
+        fetch_idx((wt + step < end) ? (wt + step) * 8 + wave : n_tiles, src_n, dst_n);
         if (tile >= n_tiles) continue;
         const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
-        const int src = valid ? a.col[x] : 0;
-        const int dst = valid ? a.erow[x] : 0;
-        const float4 ps = a.pos_s[src], pd = a.pos_s[dst];
+        const int src = src_c, dst = dst_c;
         // nn_module.py:615-624
-        const float rx = gamd_min_image(ps.x - pd.x, a.box[0], a.half[0]);
-        const float ry = gamd_min_image(ps.y - pd.y, a.box[1], a.half[1]);
-        const float rz = gamd_min_image(ps.z - pd.z, a.box[2], a.half[2]);
+        const float rx = gamd_min_image_wrapped(ps.x - pd.x, a.box[0], a.half[0]);
+        const float ry = gamd_min_image_wrapped(ps.y - pd.y, a.box[1], a.half[1]);
+        const float rz = gamd_min_image_wrapped(ps.z - pd.z, a.box[2], a.half[2]);
         const float nrm = sqrtf((rx * rx + ry * ry) + rz * rz);
         const float den = nrm + 1e-8f;
         const float d = (nrm - a.length_mean) / a.length_std;          // :630
@@ -74,7 +87,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
 #pragma unroll
         for (int s = 2; s < 22; ++s) {
             const float radial = d - cen[2 * (s - 2) + half];           // :261-263
-            F[s] = expf(-a.gamma * (radial * radial));
+            F[s] = (ABL & 8) ? radial : __builtin_amdgcn_exp2f((a.gamma * -1.4426950408889634f) * (radial * radial));
         }
         F[22] = 0.f; F[23] = 0.f;
         if (NFEAT == 45) {
@@ -109,19 +122,22 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X[t][r] = gamd_gelu(acc[t][r]);
+            for (int r = 0; r < 16; ++r) X[t][r] = (ABL & 1) ? acc[t][r] * 0.5f : gamd_gelu_hw(acc[t][r]);
         // ---- GEMM 2 ----
         load_bias_chain(vb2, half, acc);
         gemm128<false>((const f32x4*)w2, lane, X, acc);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X[t][r] = gamd_gelu(acc[t][r]);
+            for (int r = 0; r < 16; ++r) X[t][r] = (ABL & 1) ? acc[t][r] * 0.5f : gamd_gelu_hw(acc[t][r]);
         // ---- GEMM 3 + LayerNorm ----
         load_bias_chain(vb3, half, acc);
         gemm128<false>((const f32x4*)w3, lane, X, acc);
-        layernorm_chain(acc, vg, vbeta, half, 1e-5f);
+        if (!(ABL & 2)) layernorm_chain(acc, vg, vbeta, half, 1e-5f);
         // ---- store e fragment: 16 x 1 KiB coalesced ----
+        // next tile's positions (indices arrived long ago); consumed at the top of the next iteration
+        src_c = src_n; dst_c = dst_n;
+        ps = a.pos_s[src_c]; pd = a.pos_s[dst_c];
         f32x4* out = (f32x4*)a.e_frag + (size_t)tile * 16 * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -130,26 +146,40 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = acc[t][q * 4 + j];
-                out[(t * 4 + q) * 64 + lane] = v;
+                if (!(ABL & 4) || v[0] == 123.456f) out[(t * 4 + q) * 64 + lane] = v;
             }
     }
 }
 
 }  // namespace
 
-int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st) {
+template <int ABL>
+static int launch_abl(const EncArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * ENC_LDS_FLOATS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_edge_encode<44>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute((const void*)k_edge_encode<45>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_edge_encode<44, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute((const void*)k_edge_encode<45, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return (int)e1;
         if (e2 != hipSuccess) return (int)e2;
         attr_set = true;
     }
-    if (a.n_feat == 44) hipLaunchKernelGGL(k_edge_encode<44>, dim3(n_blocks), dim3(512), lds, st, a);
-    else if (a.n_feat == 45) hipLaunchKernelGGL(k_edge_encode<45>, dim3(n_blocks), dim3(512), lds, st, a);
+    if (a.n_feat == 44) hipLaunchKernelGGL((k_edge_encode<44, ABL>), dim3(n_blocks), dim3(512), lds, st, a);
+    else if (a.n_feat == 45) hipLaunchKernelGGL((k_edge_encode<45, ABL>), dim3(n_blocks), dim3(512), lds, st, a);
     else return -22;
     GAMD_CHECK_LAUNCH();
     return 0;
+}
+
+int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st) {
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("GAMD_ENC_VARIANT"); v = s ? atoi(s) : 0; }
+    switch (v) {                                   // non-zero: timing ablations for profiling only
+        case 1: return launch_abl<1>(a, n_blocks, st);
+        case 2: return launch_abl<2>(a, n_blocks, st);
+        case 4: return launch_abl<4>(a, n_blocks, st);
+        case 8: return launch_abl<8>(a, n_blocks, st);
+        case 15: return launch_abl<15>(a, n_blocks, st);
+        default: return launch_abl<0>(a, n_blocks, st);
+    }
 }

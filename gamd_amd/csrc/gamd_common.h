@@ -81,6 +81,27 @@ __device__ __forceinline__ float gamd_gelu(float x) {      // nn.GELU() default:
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// Hardware-transcendental forms used inside the MFMA kernels.  On gfx950 fp32 MFMA issues at the fp32
+// VALU rate and VALU work is NOT hidden behind it (measured: a software-pipelined SiLU costs the same
+// 8 % as a trailing one), so activations are written for the fewest VALU cycles that keep fp32 accuracy.
+__device__ __forceinline__ float gamd_silu_hw(float x) {    // v_exp_f32 + v_rcp_f32, ~1 ulp each
+    const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+// exact-erf GELU with erf from Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. ~2 ulp of the 1+erf
+// factor): one v_rcp, one v_exp, 5 FMAs; branch-free.
+__device__ __forceinline__ float gamd_gelu_hw(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float q = p * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);   // = 1 - erf(z) = erfc(z)
+    // 0.5 x (1 + erf(x/sqrt2)):  x >= 0: 0.5 x (2 - q);  x < 0: 0.5 x q
+    return 0.5f * x * (x >= 0.f ? 2.0f - q : q);
+}
+
 // torch.remainder for floats (result takes the sign of the divisor)
 __device__ __forceinline__ float gamd_remainder(float a, float b) {
     float m = fmodf(a, b);
@@ -91,6 +112,15 @@ __device__ __forceinline__ float gamd_remainder(float a, float b) {
 // minimum image exactly as nn_module.py:617-621: remainder(d + L/2, L) - L/2
 __device__ __forceinline__ float gamd_min_image(float d, float L, float halfL) {
     return gamd_remainder(d + halfL, L) - halfL;
+}
+
+// same for |d| <= L (differences of wrapped coordinates): fmod is exact, so this branch form is
+// bit-identical to gamd_min_image / torch.remainder on that range, without the fmod
+__device__ __forceinline__ float gamd_min_image_wrapped(float d, float L, float halfL) {
+    float t = d + halfL;
+    if (t < 0.0f) t += L;
+    else if (t >= L) t -= L;
+    return t - halfL;
 }
 
 // bias fragment in chain layout: 16 float4 (one per (t,q)), from a plain [128] vector

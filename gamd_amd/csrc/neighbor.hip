@@ -16,15 +16,6 @@
 
 namespace {
 
-// remainder(d + L/2, L) - L/2 for |d| <= L (differences of wrapped coordinates): fmod is exact, so the
-// branch form below is bit-identical to gamd_min_image / torch.remainder on that range
-__device__ __forceinline__ float min_image_wrapped(float d, float L, float halfL) {
-    float t = d + halfL;
-    if (t < 0.0f) t += L;
-    else if (t >= L) t -= L;
-    return t - halfL;
-}
-
 __device__ __forceinline__ int cell_coord(float p, float box, int nc) {
     int c = (int)floorf(p * ((float)nc / box));
     return c < 0 ? 0 : (c >= nc ? nc - 1 : c);     // remainder() may round up to exactly `box`
@@ -156,9 +147,9 @@ __device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit)
                     if (b < e) {
                         const float4 pb = a.pos_s[b];
                         // rel = pos[neigh] - pos[centre], min image (nn_module.py:615-621)
-                        const float rx = min_image_wrapped(pb.x - pc.x, a.box[0], a.half[0]);
-                        const float ry = min_image_wrapped(pb.y - pc.y, a.box[1], a.half[1]);
-                        const float rz = min_image_wrapped(pb.z - pc.z, a.box[2], a.half[2]);
+                        const float rx = gamd_min_image_wrapped(pb.x - pc.x, a.box[0], a.half[0]);
+                        const float ry = gamd_min_image_wrapped(pb.y - pc.y, a.box[1], a.half[1]);
+                        const float rz = gamd_min_image_wrapped(pb.z - pc.z, a.box[2], a.half[2]);
                         const float d2 = (rx * rx + ry * ry) + rz * rz;
                         if (a.flavour == 0) ok = d2 < a.rc2;                      // graph_utils.py:59, self kept
                         else ok = (sqrtf(d2) <= a.rc) && (b != ctr);              // md_module.py:111

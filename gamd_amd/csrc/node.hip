@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
         mine = load_slice(a.P_in + row, quarter, half);
         gemm_quarter(a.post.wpep, quarter, lane, X, mine);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] = gamd_silu(mine[r]);
+        for (int r = 0; r < 16; ++r) mine[r] = gamd_silu_hw(mine[r]);
         exchange(xbuf, quarter, slot, half, mine, X);            // X = SiLU(P + phi_edge(agg))
         mine = load_slice(a.post.bphi, quarter, half);
         gemm_quarter(a.post.wphip, quarter, lane, X, mine);
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
             const int f0 = 32 * quarter + 8 * q + 4 * half;
             f32x4 g;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = gamd_gelu(mine[q * 4 + j]);
+            for (int j = 0; j < 4; ++j) g[j] = gamd_gelu_hw(mine[q * 4 + j]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(a.dec_w2 + c * GAMD_H + f0);

@@ -30,6 +30,26 @@ __device__ __forceinline__ void gemm128_pf(WPtr W, int lane, const f32x16 (&X)[4
     }
 }
 
+// software-pipelined post-op as in conv_edge.hip
+template <bool F2, typename WPtr, typename Post>
+__device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post) {
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = W[((tp * 4 + t) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[tp] = mfma32(w[j], X[t][q * 4 + j], acc[tp]);
+                if (tp > 0) post(tp - 1, t * 4 + q);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) post(3, g);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* __restrict__ out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -53,7 +73,7 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
         for (int it = 0; it < iters; ++it) {
             float* cur = (it & 1) ? buf1 : buf0;
             float* nxt = (it & 1) ? buf0 : buf1;
-            if (MODE == 3 || MODE == 4 || MODE == 6) {
+            if (MODE == 3 || MODE == 4 || MODE == 6 || MODE == 9) {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const int chunk = kk * 8 + wave;
@@ -62,6 +82,13 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
                 }
             }
             for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.01f;
+            if (MODE == 8 || MODE == 9) {
+                gemm128_post<false>((const f32x4*)cur, lane, X, acc, [&](int tp, int g) { acc[tp][g] = silu_hw(acc[tp][g]); });
+#pragma unroll
+                for (int t = 0; t < 4; ++t) X[t] = acc[t];
+                if (MODE == 9) __syncthreads();
+                continue;
+            }
             if (MODE == 7) gemm128<true>((const f32x4*)cur, lane, X, acc);
             else if (MODE >= 5) gemm128_pf<false>((const f32x4*)cur, lane, X, acc);
             else gemm128<false>((const f32x4*)cur, lane, X, acc);
@@ -112,6 +139,9 @@ int main() {
         printf("mode5 prefetch gemm (8 waves)        : %.1f TF\n", run<5>(dW, dOut, iters));
         printf("mode6 prefetch + silu + barrier+stage: %.1f TF\n", run<6>(dW, dOut, iters));
         printf("mode7 gemm128 F2 orientation (8 waves): %.1f TF\n", run<7>(dW, dOut, iters));
+        printf("mode8 pipelined silu post-op, no barrier (8 waves): %.1f TF\n", run<8>(dW, dOut, iters));
+        printf("mode9 pipelined silu + barrier + stage (8 waves) : %.1f TF\n", run<9>(dW, dOut, iters));
+        printf("mode8 pipelined silu post-op (4 waves)           : %.1f TF\n", run<8>(dW, dOut, iters, 256));
         printf("mode1 4 waves/CU (1 per SIMD)        : %.1f TF\n", run<1>(dW, dOut, iters, 256));
         printf("mode5 4 waves/CU prefetch            : %.1f TF\n", run<5>(dW, dOut, iters, 256));
         printf("mode2 4 waves/CU + silu              : %.1f TF\n", run<2>(dW, dOut, iters, 256));
