@@ -38,6 +38,7 @@ SYMBOLS = {
     "gamd_forces_async": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp]),
     "gamd_sync_status": (_i32, [_vp, _vp]),
     "gamd_forces": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp]),
+    "gamd_forces_edges": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _i64, _vp, _vp, _vp]),
     "gamd_build_neighbors": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp]),
     "gamd_get_counts": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gamd_debug_get": (_i32, [_vp, _i32, _vp, C.c_size_t]),

@@ -30,6 +30,29 @@ def create_water_bond(total_atom_num: int) -> np.ndarray:
     return np.stack([np.repeat(o, 2), (o[:, None] + np.array([1, 2])).reshape(-1)], axis=1)
 
 
+class _ModelLevel:
+    """`self.pnet_model` of the reference wrappers: the nn.Module called as ``model([pos], [edge_idx])``
+    (SimpleMDNetNew.forward, nn_module.py:672-685) or ``model([pos], feat, [edge_idx])``
+    (WaterMDNetNew.forward, :545-558).  Single-graph (inference) form only; returns the NORMALISED output."""
+
+    def __init__(self, owner):
+        self._owner = owner
+
+    def __call__(self, pos_lst, *rest):
+        if len(pos_lst) != 1:
+            raise NotImplementedError("batched graphs (len(pos_lst) > 1) are the training path (dgl.batch)")
+        if len(rest) == 1:
+            feat, edge_lst = None, rest[0]
+        elif len(rest) == 2:
+            feat, edge_lst = rest
+        else:
+            raise TypeError("expected ([pos], [edge_idx]) or ([pos], feat, [edge_idx])")
+        species = None if feat is None else (feat.reshape(-1) != 0)
+        return self._owner._get_engine().forward_edges(pos_lst[0], edge_lst[0], species=species)
+
+    forward = __call__
+
+
 class _ForceFieldBase:
     def __init__(self, args=None, state_dict=None, *, num_atoms: int, box_size, cutoff: float,
                  bond=None, scaler_ckpt: Optional[str] = None, device: int = 0):
@@ -40,6 +63,7 @@ class _ForceFieldBase:
         self.training_var = np.array([1.])
         self._sd = state_dict
         self._engine: Optional[GamdForce] = None
+        self.pnet_model = _ModelLevel(self)        # attribute name of the reference (train_network_lj.py:95)
         if scaler_ckpt is not None:
             self.load_training_stats(scaler_ckpt)
 

@@ -84,7 +84,7 @@ struct gamd_handle {
     // edges
     long long e_cap = 0;
     DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg;
-    DevBuf counters, tdbg;
+    DevBuf counters, tdbg, tmp_eid;
     int* counters_host = nullptr;   // pinned
     bool has_bonds = false;
 
@@ -218,15 +218,21 @@ const HostTensor* find_w(gamd_handle* h, const std::string& name, std::initializ
 
 int ensure_stream_ok(hipStream_t st) { (void)st; return 0; }
 
+struct EdgeList { const int* centre; const int* neigh; long long n; };
+
 int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, float* out_norm_dev,
-                    float* out_denorm_dev, hipStream_t st, hipEvent_t* evs, int* n_ev, std::vector<std::string>* labels) {
+                    float* out_denorm_dev, hipStream_t st, hipEvent_t* evs, int* n_ev, std::vector<std::string>* labels,
+                    const EdgeList* el = nullptr) {
     auto mark = [&](const char* label) {
         if (evs) { (void)hipEventRecord(evs[*n_ev], st); ++*n_ev; labels->push_back(label); }
     };
     int r;
     mark("begin");
     NbrArgs na = nbr_args(h, pos_dev, species_dev);
-    if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);
+    if (el) {
+        if ((r = launch_csr_from_edges(na, el->centre, el->neigh, el->n, h->tmp_eid.as<int>(), st)))
+            return fail(-1, "edge-list CSR launch failed (%d)", r);
+    } else if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);
     mark("neighbor_build");
 
     EncArgs ea{};
@@ -384,7 +390,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     DevBuf* bufs[] = {&h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
-                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg};
+                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid};
     for (DevBuf* b : bufs) b->release();
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
@@ -577,6 +583,33 @@ int32_t gamd_forces(gamd_handle* h, const float* pos_dev, const uint8_t* species
         if (r != -34) return r;
     }
     return fail(-34, "neighbour buffers still overflow after regrowing");
+}
+
+int32_t gamd_forces_edges(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                          const int32_t* centre_dev, const int32_t* neigh_dev, int64_t n_edges, float* out_norm_dev,
+                          float* out_denorm_dev, void* stream) {
+    int r;
+    if ((r = check_ready(h))) return r;
+    if (!pos_dev || !box || n_edges < 0 || (n_edges > 0 && (!centre_dev || !neigh_dev))) return fail(-22, "bad argument");
+    if (h->cfg.kind == GAMD_KIND_WATER && !species_dev) return fail(-22, "water model needs species");
+    if (h->cfg.use_bond && !h->has_bonds) return fail(-22, "use_bond set but no bonds given (gamd_set_bonds)");
+    if (n_edges > 0x7fff0000ll) return fail(-22, "edge list too long");
+    if ((r = set_box(h, box))) return r;
+    int status = 0;
+    if (n_edges > h->e_cap) {                       // the count is known up front: grow before launching
+        if ((r = alloc_edges(h, n_edges + n_edges / 8 + 1024))) return r;
+        status = 1;
+    }
+    if (h->tmp_eid.ensure(sizeof(int) * ((size_t)std::max<long long>(n_edges, 1) + 64), false))
+        return fail(-12, "edge scratch allocation failed");
+    EdgeList el{centre_dev, neigh_dev, (long long)n_edges};
+    if ((r = enqueue_forward(h, pos_dev, species_dev, out_norm_dev, out_denorm_dev, (hipStream_t)stream, nullptr, nullptr,
+                             nullptr, &el)))
+        return r;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (h->counters_host[CNT_OVERFLOW] == 2) return fail(-22, "edge list references an atom index outside [0, n_atoms)");
+    if (h->counters_host[CNT_OVERFLOW]) return fail(-34, "edge buffers overflowed unexpectedly");
+    return status;
 }
 
 int32_t gamd_get_counts(gamd_handle* h, int64_t* n_edges, int64_t* n_pieces, int64_t* edge_capacity) {

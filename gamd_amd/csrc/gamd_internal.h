@@ -34,6 +34,10 @@ struct NbrArgs {
     int* counters;         // [CNT_COUNT]
 };
 int launch_neighbor_build(const NbrArgs& a, hipStream_t st);
+// CSR from a caller-supplied directed edge list (centre[e], neigh[e]); atoms keep the caller's order.
+// tmp_eid: [n_edges] scratch.  Rows keep the caller's edge order (deterministic).
+int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh, long long n_edges, int* tmp_eid,
+                          hipStream_t st);
 
 // ---- edge encoder -----------------------------------------------------------------------------
 struct EncArgs {

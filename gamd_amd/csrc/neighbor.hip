@@ -237,7 +237,92 @@ __global__ void k_chunk_meta(NbrArgs a) {
     a.chunk_mask[c] = mask;
 }
 
+// ---- CSR from an explicit edge list (model-level forward([pos],[edge_idx]), nn_module.py:636-653) ----
+__global__ void k_identity_sort(NbrArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float4 p;
+    p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);
+    p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
+    p.z = gamd_remainder(a.pos[3 * i + 2], a.box[2]);
+    p.w = a.species ? (float)a.species[i] : 0.f;
+    a.pos_w[i] = p;
+    a.pos_s[i] = p;
+    a.perm[i] = i;
+    a.inv_perm[i] = i;
+    a.deg[i] = 0;
+}
+
+__global__ void k_edges_count(NbrArgs a, const int* __restrict__ centre, const int* __restrict__ neigh, long long ne) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const int c = centre[e], j = neigh[e];
+    if (c >= 0 && c < a.n && j >= 0 && j < a.n) atomicAdd(&a.deg[c], 1);
+    else a.counters[CNT_OVERFLOW] = 2;                     // index out of range: edge dropped, call fails
+}
+
+__global__ void k_edges_fill(NbrArgs a, const int* __restrict__ centre, const int* __restrict__ neigh, long long ne,
+                             int* __restrict__ tmp_eid) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const int c = centre[e], j = neigh[e];
+    if (c < 0 || c >= a.n || j < 0 || j >= a.n) return;
+    const int s = atomicAdd(&a.cell_of[c], 1);             // cell_of doubles as the per-row cursor here
+    const long long at = (long long)a.row_ptr[c] + s;
+    if (at < a.e_cap) tmp_eid[at] = (int)e;
+}
+
+// one wave per destination row: order the row's edges by their position in the caller's list
+// (atomics above scatter them), then emit col / erow
+__global__ void __launch_bounds__(256) k_edges_sort_rows(NbrArgs a, const int* __restrict__ neigh,
+                                                         const int* __restrict__ tmp_eid) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= a.n) return;
+    const long long s = a.row_ptr[row];
+    long long e = a.row_ptr[row + 1];
+    if (e > a.e_cap) e = a.e_cap;
+    const int cnt = (int)(e - s);
+    if (cnt <= 0) return;
+    if (cnt <= 64) {
+        const int v = lane < cnt ? tmp_eid[s + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += (__shfl(v, j, 64) < v) ? 1 : 0;
+        if (lane < cnt) { a.col[s + rank] = neigh[v]; a.erow[s + rank] = row; }
+    } else {
+        for (int i = lane; i < cnt; i += 64) {                // rank by counting, O(cnt^2 / 64)
+            const int v = tmp_eid[s + i];
+            int rank = 0;
+            for (int j = 0; j < cnt; ++j) rank += (tmp_eid[s + j] < v) ? 1 : 0;
+            a.col[s + rank] = neigh[v];
+            a.erow[s + rank] = row;
+        }
+    }
+}
+
 }  // namespace
+
+int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh, long long n_edges, int* tmp_eid,
+                          hipStream_t st) {
+    hipError_t e;
+    e = hipMemsetAsync(a.counters, 0, sizeof(int) * CNT_COUNT, st); if (e) return (int)e;
+    e = hipMemsetAsync(a.cell_of, 0, sizeof(int) * (size_t)a.n, st); if (e) return (int)e;
+    const int tb = 256, gb = (a.n + tb - 1) / tb;
+    hipLaunchKernelGGL(k_identity_sort, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
+    if (n_edges > 0) {
+        const unsigned ge = (unsigned)((n_edges + tb - 1) / tb);
+        hipLaunchKernelGGL(k_edges_count, dim3(ge), dim3(tb), 0, st, a, centre, neigh, n_edges); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_edges_fill, dim3(ge), dim3(tb), 0, st, a, centre, neigh, n_edges, tmp_eid); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_edges_sort_rows, dim3((a.n + 3) / 4), dim3(256), 0, st, a, neigh, tmp_eid); GAMD_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();
+    }
+    const long long nchunk_cap = (a.e_cap + GAMD_TILE) / GAMD_CHUNK;
+    hipLaunchKernelGGL(k_chunk_meta, dim3((unsigned)((nchunk_cap + 255) / 256)), dim3(256), 0, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}
 
 int launch_neighbor_build(const NbrArgs& a, hipStream_t st) {
     hipError_t e;

@@ -147,6 +147,24 @@ class GamdForce:
 
     __call__ = forward
 
+    def forward_edges(self, pos: ArrayLike, edge_idx, box=None, species=None, denormalize: bool = False) -> torch.Tensor:
+        """Model-level call of the reference, ``pnet_model([pos], [edge_idx])``: edge_idx [2,E] with row 0 =
+        centre, row 1 = neighbour (LJ/train_network_lj.py:183-184); the built-in radius search is bypassed."""
+        p = self._dev_pos(pos)
+        s = self._dev_species(species)
+        if isinstance(edge_idx, np.ndarray):
+            edge_idx = torch.from_numpy(edge_idx)
+        e = edge_idx.to(device=self.device, dtype=torch.int32).contiguous()
+        if e.dim() != 2 or e.shape[0] != 2:
+            raise ValueError("edge_idx must be [2, E]")
+        st = self._lib.gamd_forces_edges(self._h, C.c_void_p(p.data_ptr()),
+                                         C.c_void_p(s.data_ptr()) if s is not None else None, self._box_arg(box),
+                                         C.c_void_p(e[0].data_ptr()), C.c_void_p(e[1].data_ptr()), int(e.shape[1]),
+                                         C.c_void_p(self._out.data_ptr()), C.c_void_p(self._out_den.data_ptr()),
+                                         self._stream())
+        self.last_status = check(st, "gamd_forces_edges")
+        return self._out_den if denormalize else self._out
+
     def build_neighbors(self, pos: ArrayLike, box=None, species=None) -> int:
         p = self._dev_pos(pos)
         s = self._dev_species(species)

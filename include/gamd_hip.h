@@ -90,6 +90,15 @@ int32_t gamd_sync_status(gamd_handle* h, void* stream);
 int32_t gamd_forces(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
                     float* out_norm_dev, float* out_denorm_dev, void* stream);
 
+/* Same network forward on a CALLER-SUPPLIED directed edge list instead of the built-in radius search:
+ * centre_dev[e] / neigh_dev[e] (int32, device) = rows 0 / 1 of the reference's edge_idx tensor; messages flow
+ * neigh -> centre.  Replaces the model-level call pnet_model([pos], [edge_idx]) / ([pos], feat, [edge_idx])
+ * (nn_module.py:672-685, :545-558, build_graph :636-653).  Atoms are NOT renumbered on this path; every row
+ * keeps the caller's edge order.  Synchronises; returns 0, or 1 if the edge buffers had to grow. */
+int32_t gamd_forces_edges(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
+                          const int32_t* centre_dev, const int32_t* neigh_dev, int64_t n_edges,
+                          float* out_norm_dev, float* out_denorm_dev, void* stream);
+
 /* Neighbour build only (stage entry point for parity tests / profiling). */
 int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
                              void* stream);

@@ -159,6 +159,8 @@ def bond_flags(center: Tensor, neigh: Tensor, bond: np.ndarray) -> Tensor:
     """nn_module.py:510 + :529-534: bond graph = bonds + reversed bonds;
     has_edges_between(center, neigh) -> bool[E]."""
     b = torch.as_tensor(np.asarray(bond)).long()
+    if center.numel() == 0:
+        return torch.zeros(0, dtype=torch.bool)
     n = int(max(b.max(), center.max(), neigh.max())) + 1
     key = torch.cat([b[:, 0] * n + b[:, 1], b[:, 1] * n + b[:, 0]])
     return torch.isin(center * n + neigh, key)

@@ -197,3 +197,35 @@ def test_c3_water_full_size_against_oracle():
     assert 25 * 4170 < edges.shape[1] < 40 * 4170
     assert rel_err(out, ref) < TOL
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["lj258_seed0", "tip3p774_seed3"])
+def test_model_level_forward_with_explicit_edges(name):
+    """pnet_model([pos], [edge_idx]) / ([pos], feat, [edge_idx]) with the REFERENCE's own edge list and
+    order (nn_module.py:672-685, :545-558): no radius search, atoms not renumbered."""
+    from gamd_amd.compat import ParticleNetLightningLJ, ParticleNetLightningWater
+    g, cfg, sd = load_golden(name)
+    box = float(g["box"])
+    posw = torch.from_numpy(np.mod(g["pos"], box)).float().cuda()
+    edge_idx = torch.from_numpy(g["edge_idx"]).long().cuda()
+    if "node_feat" in g:
+        m = ParticleNetLightningWater(state_dict=sd)
+        out = m.pnet_model([posw], torch.from_numpy(g["node_feat"]).cuda(), [edge_idx])
+    else:
+        m = ParticleNetLightningLJ(state_dict=sd)
+        out = m.pnet_model([posw], [edge_idx])
+    assert rel_err(out.cpu().numpy(), g["out_norm"]) < TOL
+    # a shuffled edge list gives the same forces (only the summation order inside a row changes)
+    perm = torch.randperm(edge_idx.shape[1], generator=torch.Generator().manual_seed(0)).cuda()
+    eng = m._get_engine()
+    species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
+    out2 = eng.forward_edges(posw, edge_idx[:, perm], species=species).cpu().numpy()
+    assert rel_err(out2, g["out_norm"]) < TOL
+    # an empty edge list: every atom isolated -> decoder of the residual stream only
+    out3 = eng.forward_edges(posw, torch.zeros((2, 0), dtype=torch.long), species=species).cpu().numpy()
+    feat = torch.from_numpy(g["node_feat"]) if "node_feat" in g else None
+    ref3 = orc.forward(sd, posw.cpu(), torch.zeros((2, 0), dtype=torch.long), box, feat=feat,
+                       bond=g["bond"] if "bond" in g else None).numpy()
+    assert rel_err(out3, ref3) < TOL
+    with pytest.raises(Exception, match="outside"):
+        eng.forward_edges(posw, torch.tensor([[0, 5], [1, 100000]]), species=species)
