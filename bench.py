@@ -75,11 +75,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    ctx = ens.init_ensemble("nccl")
+    # RCCL ("nccl") over xGMI in production; GAMD_BENCH_BACKEND=gloo + GAMD_BENCH_SHARE_GPU=1 let the N>1 control
+    # flow be dry-run with several ranks on a single-GPU box (the timing of such a run means nothing)
+    backend = os.environ.get("GAMD_BENCH_BACKEND", "nccl")
+    share = os.environ.get("GAMD_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        os.environ["LOCAL_RANK_FOR_DEVICE"] = "0"
+    ctx = ens.init_ensemble(backend, device_index=0 if share else None)
     if ctx.world != args.gpus and ctx.world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}")
-    dev = ctx.local_rank if ctx.distributed else 0
+    dev = 0 if share else (ctx.local_rank if ctx.distributed else 0)
     torch.cuda.set_device(dev)
+    ddev = f"cuda:{dev}" if (ctx.distributed and backend == "nccl") else "cpu"
 
     pos, box = lj_box(N_ATOMS, seed=ens.box_seed(1234, ctx))
     sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
@@ -103,10 +110,10 @@ def main():
     conv_ms, conv_n = eng.timing_read()
     eng.timing_enable(False)
     n_edges = eng.counts()[0]
-    dt_max = ens.max_over_ranks(dt, ctx, device=f"cuda:{dev}" if ctx.distributed else "cpu")
+    dt_max = ens.max_over_ranks(dt, ctx, device=ddev)
     summary = ens.gather_summary({"seconds": dt, "edges": float(n_edges), "fsum": float(f.abs().sum().item()),
                                   "finite": float(torch.isfinite(x).all().item() and torch.isfinite(f).all().item())},
-                                 ctx, device=f"cuda:{dev}" if ctx.distributed else "cpu")
+                                 ctx, device=ddev)
     if ctx.rank != 0:
         ens.shutdown(ctx)
         return

@@ -128,8 +128,8 @@ int set_box(gamd_handle* h, const float* box) {
     if (ncell > (1ll << 30)) return fail(-22, "cell grid too large");
     if ((int)ncell > h->ncell_cap) {
         int r = 0;
-        r |= h->cell_cnt.ensure(sizeof(int) * (size_t)ncell, true);
-        r |= h->cell_fill.ensure(sizeof(int) * (size_t)ncell, true);
+        // counters | cell_cnt | cell_fill in one buffer so the per-call clear is a single memset
+        r |= h->counters.ensure(sizeof(int) * (CNT_COUNT + 2 * (size_t)ncell), true);
         r |= h->cell_start.ensure(sizeof(int) * ((size_t)ncell + 1), true);
         if (r) return fail(-12, "cell buffer allocation failed");
         h->ncell_cap = (int)ncell;
@@ -155,8 +155,9 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
     a.pos_w = h->pos_w.as<float4>();
     a.pos_s = h->pos_s.as<float4>();
     a.cell_of = h->cell_of.as<int>();
-    a.cell_cnt = h->cell_cnt.as<int>();
-    a.cell_fill = h->cell_fill.as<int>();
+    a.ncell_cap = h->ncell_cap;
+    a.cell_cnt = h->counters.as<int>() + CNT_COUNT;
+    a.cell_fill = h->counters.as<int>() + CNT_COUNT + h->ncell_cap;
     a.cell_start = h->cell_start.as<int>();
     a.perm = h->perm.as<int>();
     a.inv_perm = h->inv_perm.as<int>();
@@ -365,7 +366,6 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->P.ensure(nh, true);
     r |= h->f_norm.ensure(sizeof(float) * 3 * n, true);
     r |= h->f_den.ensure(sizeof(float) * 3 * n, true);
-    r |= h->counters.ensure(sizeof(int) * CNT_COUNT, true);
     r |= h->tdbg.ensure(sizeof(long long) * 16 * 8 * 1024, true);
     if (r) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
     if (hipHostMalloc((void**)&h->counters_host, sizeof(int) * CNT_COUNT) != hipSuccess) {

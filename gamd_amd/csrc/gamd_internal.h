@@ -13,6 +13,7 @@ struct NbrArgs {
     float box[3], half[3]; // box and 0.5*box in fp32 (nn_module.py:617-621)
     float rc, rc2;
     int nc[3], ncell;
+    int ncell_cap;         // counters | cell_cnt[ncell_cap] | cell_fill[ncell_cap] are one allocation
     long long e_cap;       // edge capacity of col/erow/e_frag
     const float* pos;      // [n][3] caller positions (any image)
     const uint8_t* species;// [n] or null

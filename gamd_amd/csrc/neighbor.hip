@@ -36,7 +36,8 @@ __global__ void k_bin(NbrArgs a) {
     atomicAdd(&a.cell_cnt[c], 1);
 }
 
-// single-block exclusive scan, any length; out has n+1 entries (out[n] = total)
+// single-block exclusive scan, any length; out has n+1 entries (out[n] = total).  4 items per thread
+// per pass (4096 per pass), wave shuffles + one LDS hop.
 template <typename F>
 __device__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
     __shared__ int wave_tot[16];
@@ -44,10 +45,13 @@ __device__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const int v = i < n ? load(i) : 0;
-        int x = v;
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + tid * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? load(i0 + k) : 0;
+        const int mine = (v[0] + v[1]) + (v[2] + v[3]);
+        int x = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int y = __shfl_up(x, d, 64);
@@ -58,9 +62,14 @@ __device__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
         int woff = 0;
         for (int w = 0; w < wv; ++w) woff += wave_tot[w];
         const int carry = carry_s;
-        if (i < n) out[i] = carry + woff + x - v;
+        int run = carry + woff + x - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + x;
+        if (tid == 1023) carry_s = run;
         __syncthreads();
     }
     if (tid == 0) out[n] = carry_s;
@@ -326,9 +335,8 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
 
 int launch_neighbor_build(const NbrArgs& a, hipStream_t st) {
     hipError_t e;
-    e = hipMemsetAsync(a.cell_cnt, 0, sizeof(int) * (size_t)a.ncell, st); if (e) return (int)e;
-    e = hipMemsetAsync(a.cell_fill, 0, sizeof(int) * (size_t)a.ncell, st); if (e) return (int)e;
-    e = hipMemsetAsync(a.counters, 0, sizeof(int) * CNT_COUNT, st); if (e) return (int)e;
+    // counters | cell_cnt | cell_fill live in one allocation (gamd_api.hip): a single memset node
+    e = hipMemsetAsync(a.counters, 0, sizeof(int) * (CNT_COUNT + 2 * (size_t)a.ncell_cap), st); if (e) return (int)e;
     const int tb = 256, gb = (a.n + tb - 1) / tb;
     hipLaunchKernelGGL(k_bin, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();

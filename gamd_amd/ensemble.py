@@ -29,7 +29,7 @@ class EnsembleContext:
         return self.world > 1
 
 
-def init_ensemble(backend: str = "nccl") -> EnsembleContext:
+def init_ensemble(backend: str = "nccl", device_index=None) -> EnsembleContext:
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run contract) and join
     the process group when WORLD_SIZE > 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -40,8 +40,9 @@ def init_ensemble(backend: str = "nccl") -> EnsembleContext:
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            kw["device_id"] = torch.device("cuda", local)
+            d = local if device_index is None else device_index
+            torch.cuda.set_device(d)
+            kw["device_id"] = torch.device("cuda", d)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return EnsembleContext(rank, world, local, backend if world > 1 else "")
 
