@@ -19,6 +19,12 @@ class GamdConfig(C.Structure):
                 ("keep_stages", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GamdNhcParams(C.Structure):
+    _fields_ = [("dt_ps", C.c_float), ("mass_amu", C.c_float), ("temperature_k", C.c_float),
+                ("frequency_per_ps", C.c_float), ("chain_length", C.c_int32), ("num_mts", C.c_int32),
+                ("num_yoshidasuzuki", C.c_int32), ("reset", C.c_int32), ("ndf", C.c_double)]
+
+
 class GamdMdParams(C.Structure):
     _fields_ = [("dt_ps", C.c_float), ("mass_amu", C.c_float), ("temperature_k", C.c_float),
                 ("gamma_per_ps", C.c_float), ("seed", C.c_uint64), ("first_step", C.c_uint64)]
@@ -43,6 +49,7 @@ SYMBOLS = {
     "gamd_get_counts": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gamd_debug_get": (_i32, [_vp, _i32, _vp, C.c_size_t]),
     "gamd_md_run": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(GamdMdParams), _i64, _vp]),
+    "gamd_md_run_nhc": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(GamdNhcParams), _vp, _i64, _vp]),
     "gamd_profile": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, C.c_char_p, C.c_size_t,
                             C.POINTER(C.c_float), _i32, C.POINTER(_i32)]),
     "gamd_timing_enable": (_i32, [_vp, _i32]),

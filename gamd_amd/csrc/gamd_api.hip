@@ -84,7 +84,7 @@ struct gamd_handle {
     // edges
     long long e_cap = 0;
     DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg;
-    DevBuf counters, tdbg, tmp_eid;
+    DevBuf counters, tdbg, tmp_eid, ke_partial;
     int* counters_host = nullptr;   // pinned
     bool has_bonds = false;
 
@@ -390,7 +390,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     DevBuf* bufs[] = {&h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
-                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid};
+                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial};
     for (DevBuf* b : bufs) b->release();
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
@@ -666,6 +666,47 @@ int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, co
         if ((r = launch_baoab_first(m, st))) return fail(-1, "integrator launch failed (%d)", r);
         if ((r = enqueue_forward(h, x_dev, species_dev, nullptr, f_dev, st, nullptr, nullptr, nullptr))) return r;
         if ((r = launch_baoab_second(m, st))) return fail(-1, "integrator launch failed (%d)", r);
+    }
+    return 0;
+}
+
+int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
+                        const float* box, const gamd_nhc_params* p, double* chain_state_dev, int64_t n_steps, void* stream) {
+    int r;
+    if ((r = check_ready(h))) return r;
+    if (!x_dev || !v_dev || !f_dev || !box || !p || !chain_state_dev) return fail(-22, "null argument");
+    if (p->chain_length < 1 || p->chain_length > 16) return fail(-22, "chain_length must be in [1, 16]");
+    static const double YS1[] = {1.0};
+    static const double YS3[] = {0.8289815435887510, -0.6579630871775020, 0.8289815435887510};
+    static const double YS5[] = {0.2967324292201065, 0.2967324292201065, -0.1869297168804260, 0.2967324292201065,
+                                 0.2967324292201065};                       // hack_integrator.py:183-187
+    const double* ys = p->num_yoshidasuzuki == 1 ? YS1 : p->num_yoshidasuzuki == 3 ? YS3 : p->num_yoshidasuzuki == 5 ? YS5 : nullptr;
+    if (!ys) return fail(-22, "Invalid Yoshida-Suzuki value. Allowed values are: 1,3,5");
+    if ((r = set_box(h, box))) return r;
+    hipStream_t st = (hipStream_t)stream;
+    NhcArgs a{};
+    a.n = h->n; a.x = x_dev; a.v = v_dev; a.f = f_dev;
+    a.mass = p->mass_amu; a.dt = p->dt_ps;
+    for (int d = 0; d < 3; ++d) a.box[d] = box[d];
+    a.kT = 0.00831446261815324 * (double)p->temperature_k;
+    a.freq = p->frequency_per_ps;
+    a.ndf = p->ndf;
+    a.M = p->chain_length; a.n_c = p->num_mts; a.n_ys = p->num_yoshidasuzuki;
+    for (int i = 0; i < a.n_ys; ++i) a.w[i] = ys[i];
+    a.state = chain_state_dev;
+    a.n_blocks = std::min(256, (3 * h->n + 255) / 256);
+    if (h->ke_partial.ensure(sizeof(double) * 256, true)) return fail(-12, "allocation failed");
+    a.partial = h->ke_partial.as<double>();
+    if (p->reset) {
+        std::vector<double> init(3 * a.M + 2, 0.0);
+        for (int i = 0; i < a.M; ++i) init[2 * a.M + i] = -a.freq * a.freq;      // G_i = -frequency^2 (:255)
+        HIP_TRY(hipMemcpyAsync(chain_state_dev, init.data(), sizeof(double) * init.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (int64_t s = 0; s < n_steps; ++s) {
+        if ((r = launch_nhc_first(a, st))) return fail(-1, "integrator launch failed (%d)", r);
+        if ((r = enqueue_forward(h, x_dev, species_dev, nullptr, f_dev, st, nullptr, nullptr, nullptr))) return r;
+        if ((r = launch_nhc_second(a, st))) return fail(-1, "integrator launch failed (%d)", r);
     }
     return 0;
 }

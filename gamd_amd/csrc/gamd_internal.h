@@ -131,3 +131,22 @@ struct MdArgs {
 };
 int launch_baoab_first(const MdArgs& a, hipStream_t st);    // B A O A  (hack_integrator.py:141-165)
 int launch_baoab_second(const MdArgs& a, hipStream_t st);   // B        (hack_integrator.py:175-178)
+
+// Nose-Hoover chain of the reference drivers (hack_integrator.py:182-330 first half, :334-493 second half;
+// one chain state shared by both halves, as copy_state_from_integrator does every step)
+struct NhcArgs {
+    int n;
+    float* x; float* v;        // [n][3] Angstrom, Angstrom/ps
+    const float* f;            // [n][3] kJ/mol/nm
+    float mass;                // amu
+    float dt;                  // ps
+    float box[3];
+    double kT, freq, ndf;      // kJ/mol, 1/ps, degrees of freedom
+    int M, n_c, n_ys;          // chain length, multi-time-step count, Yoshida-Suzuki order
+    double w[5];
+    double* state;             // [3*M + 2]: xi[M], vxi[M], G[M], scale, KE2
+    double* partial;           // [n_blocks] per-block sums of m v^2
+    int n_blocks;
+};
+int launch_nhc_first(const NhcArgs& a, hipStream_t st);     // propagateNHC; v *= scale; v += dt/2 f/m; x += dt v
+int launch_nhc_second(const NhcArgs& a, hipStream_t st);    // v += dt/2 f/m; propagateNHC; v *= scale

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import GamdConfig, GamdMdParams, check
+from ._lib import GamdConfig, GamdMdParams, GamdNhcParams, check
 from .weights import ModelConfig, infer_config, validate_state_dict
 
 ArrayLike = Union[np.ndarray, torch.Tensor]
@@ -241,6 +241,29 @@ class GamdForce:
         check(st, "gamd_md_run")
         if sync:
             check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
+
+    def md_run_nhc(self, x: torch.Tensor, v: torch.Tensor, f: torch.Tensor, n_steps: int, chain_state: torch.Tensor = None,
+                   dt_ps=0.002, mass_amu=39.9, temperature_k=100.0, frequency_per_ps=25.0, chain_length=10, num_mts=5,
+                   num_yoshidasuzuki=5, ndf=None, box=None, species=None, sync: bool = True) -> torch.Tensor:
+        """Split Nose-Hoover-chain steps (hack_integrator.py:182-493).  Returns the chain state tensor
+        (float64 [3*chain_length+2] on the device); pass it back in to continue a trajectory."""
+        for t in (x, v, f):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n, 3)
+        reset = chain_state is None
+        if reset:
+            chain_state = torch.zeros(3 * chain_length + 2, dtype=torch.float64, device=self.device)
+        assert chain_state.dtype == torch.float64 and chain_state.numel() == 3 * chain_length + 2
+        s = self._dev_species(species)
+        p = GamdNhcParams(dt_ps, mass_amu, temperature_k, frequency_per_ps, chain_length, num_mts, num_yoshidasuzuki,
+                          int(reset), float(3 * self.n if ndf is None else ndf))
+        st = self._lib.gamd_md_run_nhc(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()),
+                                       C.c_void_p(f.data_ptr()), C.c_void_p(s.data_ptr()) if s is not None else None,
+                                       self._box_arg(box), C.byref(p), C.c_void_p(chain_state.data_ptr()), int(n_steps),
+                                       self._stream())
+        check(st, "gamd_md_run_nhc")
+        if sync:
+            check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
+        return chain_state
 
     def sync_status(self) -> int:
         return check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")

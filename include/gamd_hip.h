@@ -135,6 +135,27 @@ typedef struct gamd_md_params {
 int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
                     const float* box, const gamd_md_params* p, int64_t n_steps, void* stream);
 
+/* Split Nose-Hoover-chain step of the reference drivers, on device:
+ *   first half   propagateNHC; v += dt/2 f_last/m; x += dt v     HackNoseHooverIntegrator      hack_integrator.py:182-330
+ *   force eval                                                    predict_forces                LJ/test_script/test_nosehoover.py:113
+ *   second half  v += dt/2 f_gnn/m; propagateNHC                  HackHalfNoseHooverIntegrator  hack_integrator.py:334-493
+ * One chain state (xi, vxi, G) is shared by both halves (the drivers copy it across every step,
+ * test_nosehoover.py:104-118).  chain_state_dev: double [3*chain_length + 2] device buffer owned by the caller
+ * (xi[M], vxi[M], G[M], last scale, last 2*KE); pass reset != 0 to initialise it (xi = vxi = 0, G = -freq^2). */
+typedef struct gamd_nhc_params {
+    float dt_ps;              /* 0.002 */
+    float mass_amu;           /* 39.9 */
+    float temperature_k;      /* 100 */
+    float frequency_per_ps;   /* collision_frequency: 25 */
+    int32_t chain_length;     /* 10 in the drivers (<= 16) */
+    int32_t num_mts;          /* 5 */
+    int32_t num_yoshidasuzuki;/* 1, 3 or 5 */
+    int32_t reset;
+    double ndf;               /* degrees of freedom (3N for the unconstrained LJ system) */
+} gamd_nhc_params;
+int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
+                        const float* box, const gamd_nhc_params* p, double* chain_state_dev, int64_t n_steps, void* stream);
+
 /* Event-timed replay of one force evaluation: per-kernel milliseconds of the last gamd_profile call.
  * names: newline-separated kernel labels; ms: one float per label.  For bench.py's roofline block. */
 int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,

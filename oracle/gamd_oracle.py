@@ -273,3 +273,54 @@ def baoab_first_half(x, v, f_last, inv_m, dt, a, b_sigma, noise):
 def baoab_second_half(v, f, inv_m, dt):
     """HackHalfVelocityIntegrator, hack_integrator.py:171-178: v += dt/2 f/m."""
     return v + (0.5 * dt) * f * inv_m
+
+
+YS_WEIGHTS = {1: [1.0], 3: [0.8289815435887510, -0.6579630871775020, 0.8289815435887510],
+              5: [0.2967324292201065, 0.2967324292201065, -0.1869297168804260, 0.2967324292201065,
+                  0.2967324292201065]}                       # hack_integrator.py:183-187
+
+
+def nhc_init(chain_length, freq):
+    """xi = vxi = 0, G_i = -frequency^2 (hack_integrator.py:252-256)."""
+    return dict(xi=np.zeros(chain_length), vxi=np.zeros(chain_length), G=np.full(chain_length, -freq ** 2))
+
+
+def nhc_propagate(st, ke2, dt, kT, freq, ndf, n_c=5, n_ys=5):
+    """propagateNHC, hack_integrator.py:289-316 (float64 globals).  Returns the velocity scale."""
+    xi, vxi, G = st["xi"], st["vxi"], st["G"]
+    M = len(xi)
+    Q = kT / freq ** 2
+    Qs = np.full(M, Q); Qs[0] = ndf * Q                                   # :262-265
+    scale = 1.0
+    G[0] = (ke2 - ndf * kT) / Qs[0]
+    for _ in range(n_c):
+        for w in YS_WEIGHTS[n_ys]:
+            wdt = w * dt / n_c
+            vxi[M - 1] += 0.25 * wdt * G[M - 1]
+            for j in range(M - 2, -1, -1):
+                aa = np.exp(-0.125 * wdt * vxi[j + 1])
+                vxi[j] = aa * (aa * vxi[j] + 0.25 * wdt * G[j])
+            scale *= np.exp(-0.5 * wdt * vxi[0])
+            xi += 0.5 * wdt * vxi
+            G[0] = (scale * scale * ke2 - ndf * kT) / Qs[0]
+            for j in range(M - 1):
+                aa = np.exp(-0.125 * wdt * vxi[j + 1])
+                vxi[j] = aa * (aa * vxi[j] + 0.25 * wdt * G[j])
+                G[j + 1] = (Qs[j] * vxi[j] ** 2 - kT) / Qs[j + 1]
+            vxi[M - 1] += 0.25 * wdt * G[M - 1]
+    return scale
+
+
+def nhc_first_half(st, x, v, f_last, mass, dt, kT, freq, ndf):
+    """HackNoseHooverIntegrator step, hack_integrator.py:274-280 (x A, v A/ps, f kJ/mol/nm, no constraints)."""
+    ke2 = float(np.sum(mass * (0.1 * v) ** 2))
+    v = v * nhc_propagate(st, ke2, dt, kT, freq, ndf)
+    v = v + 0.5 * dt * f_last * 10.0 / mass
+    return x + dt * v, v
+
+
+def nhc_second_half(st, v, f, mass, dt, kT, freq, ndf):
+    """HackHalfNoseHooverIntegrator step, hack_integrator.py:427-430."""
+    v = v + 0.5 * dt * f * 10.0 / mass
+    ke2 = float(np.sum(mass * (0.1 * v) ** 2))
+    return v * nhc_propagate(st, ke2, dt, kT, freq, ndf)

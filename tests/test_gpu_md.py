@@ -63,3 +63,41 @@ def test_ou_noise_statistics():
     assert np.array_equal(v, run(11, 0))
     assert not np.array_equal(v, run(11, 1)) and not np.array_equal(v, run(12, 0))
     eng.close()
+
+
+def test_nose_hoover_chain_matches_oracle():
+    """Split NHC step of the reference drivers (hack_integrator.py:182-493, test_nosehoover.py:100-118):
+    chain_length 10, 5 multi-time-steps, Yoshida-Suzuki 5; deterministic, so comparable step by step."""
+    from gamd_amd.engine import GamdForce
+    from gamd_amd.workloads import KB
+    g, cfg, sd = load_golden("lj258_seed0")
+    box, rc, n = float(g["box"]), float(g["cutoff"]), 258
+    eng = GamdForce(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"])
+    x = torch.from_numpy(np.mod(g["pos"], box)).float().cuda()
+    v = torch.from_numpy(np.random.default_rng(3).normal(0, 1.44, (n, 3))).float().cuda()
+    f = eng.forward(x, denormalize=True).clone()
+    xr, vr, fr = x.cpu().double().numpy(), v.cpu().double().numpy(), f.cpu().double().numpy()
+    dt, m, freq, T, M = 0.002, 39.9, 25.0, 100.0, 10
+    steps = 3
+    chain = eng.md_run_nhc(x, v, f, steps, dt_ps=dt, mass_amu=m, temperature_k=T, frequency_per_ps=freq, chain_length=M)
+    st = orc.nhc_init(M, freq)
+    kT, ndf = KB * T, 3.0 * n
+    mean, var = SHIPPED_SCALERS["lj"]
+    for _ in range(steps):
+        xr, vr = orc.nhc_first_half(st, xr, vr, fr, m, dt, kT, freq, ndf)
+        xr = np.mod(xr, box)
+        fr = orc.predict_forces(sd, xr, box, rc, var=var, mean=mean)
+        vr = orc.nhc_second_half(st, vr, fr, m, dt, kT, freq, ndf)
+    assert rel_err(x.cpu().numpy(), xr) < 1e-5
+    assert rel_err(v.cpu().numpy(), vr) < 1e-4
+    c = chain.cpu().numpy()
+    assert rel_err(c[M:2 * M], st["vxi"]) < 1e-4 and rel_err(c[:M], st["xi"]) < 1e-4
+    assert abs(c[3 * M] - 1.0) < 0.05                       # last velocity scale stays close to 1
+    # continuing with the returned state is the same as one longer run
+    x2 = torch.from_numpy(np.mod(g["pos"], box)).float().cuda()
+    v2 = torch.from_numpy(np.random.default_rng(3).normal(0, 1.44, (n, 3))).float().cuda()
+    f2 = eng.forward(x2, denormalize=True).clone()
+    ch = eng.md_run_nhc(x2, v2, f2, 1, dt_ps=dt, mass_amu=m, temperature_k=T, frequency_per_ps=freq, chain_length=M)
+    eng.md_run_nhc(x2, v2, f2, 2, chain_state=ch, dt_ps=dt, mass_amu=m, temperature_k=T, frequency_per_ps=freq, chain_length=M)
+    assert np.array_equal(x2.cpu().numpy(), x.cpu().numpy()) and np.array_equal(v2.cpu().numpy(), v.cpu().numpy())
+    eng.close()
