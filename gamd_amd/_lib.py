@@ -16,7 +16,7 @@ class GamdConfig(C.Structure):
     _fields_ = [("n_atoms", C.c_int32), ("kind", C.c_int32), ("n_layers", C.c_int32),
                 ("use_bond", C.c_int32), ("nbr_flavour", C.c_int32), ("device", C.c_int32),
                 ("cutoff", C.c_float), ("box", C.c_float * 3), ("edge_capacity", C.c_int64),
-                ("keep_stages", C.c_int32), ("reserved", C.c_int32)]
+                ("keep_stages", C.c_int32), ("edge_dtype", C.c_int32)]
 
 
 class GamdNhcParams(C.Structure):

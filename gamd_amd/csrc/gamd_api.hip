@@ -195,6 +195,34 @@ void pack_enc1(const float* W, int n_feat, float* out) {
                 }
 }
 
+// ---- bf16 packing (config 5), layout of gamd_bf16.h --------------------------------------------
+uint16_t f2bf(float x) {                       // round to nearest even
+    uint32_t u; memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+void pack128_bf16(const float* W, uint16_t* out) {
+    for (int tp = 0; tp < 4; ++tp)
+        for (int t = 0; t < 4; ++t)
+            for (int u = 0; u < 2; ++u)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 8 * u + j, half = lane >> 5;
+                        const int n = 32 * tp + (lane & 31), k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        out[((((tp * 4 + t) * 2 + u) * 64 + lane) * 8) + j] = f2bf(W[n * 128 + k]);
+                    }
+}
+void pack_enc1_bf16(const float* W, int n_feat, uint16_t* out) {     // [tp][s][lane][8], K padded to 48
+    for (int tp = 0; tp < 4; ++tp)
+        for (int s = 0; s < 3; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * tp + (lane & 31), k = 16 * s + 8 * (lane >> 5) + j;
+                    out[(((tp * 3 + s) * 64 + lane) * 8) + j] = k < n_feat ? f2bf(W[n * n_feat + k]) : (uint16_t)0;
+                }
+}
+
 struct BlobBuilder {
     std::vector<float> host;
     size_t add(size_t n_floats) {
@@ -256,7 +284,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.e_frag = h->e_frag.as<float>();
     ea.e_cap = h->e_cap;
     ea.feat_dbg = h->cfg.keep_stages ? h->feat_dbg.as<float>() : nullptr;
-    if ((r = launch_edge_encode(ea, h->n_cu, st))) return fail(-1, "edge encode launch failed (%d)", r);
+    r = h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_edge_encode_bf16(ea, h->n_cu, st) : launch_edge_encode(ea, h->n_cu, st);
+    if (r) return fail(-1, "edge encode launch failed (%d)", r);
     mark("edge_encode");
 
     const size_t nh = (size_t)h->n * GAMD_H;
@@ -302,7 +331,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
             }
             HIP_TRY(hipEventRecord(h->tev[h->tev_used], st));
         }
-        if ((r = launch_conv_edge(ca, h->n_cu, st))) return fail(-1, "conv edge launch failed (%d)", r);
+        r = h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st) : launch_conv_edge(ca, h->n_cu, st);
+        if (r) return fail(-1, "conv edge launch failed (%d)", r);
         if (h->timing) { HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st)); h->tev_used += 2; }
         mark("conv_edge");
 
@@ -336,6 +366,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     if (cfg->n_atoms <= 0) return fail(-22, "n_atoms must be positive");
     if (cfg->n_layers <= 0 || cfg->n_layers > 16) return fail(-22, "n_layers out of range");
     if (!(cfg->cutoff > 0.f)) return fail(-22, "cutoff must be positive");
+    if (cfg->edge_dtype != GAMD_EDGE_F32 && cfg->edge_dtype != GAMD_EDGE_BF16) return fail(-22, "unknown edge_dtype");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(-19, "no HIP device available: libgamd_hip has no CPU fallback");
@@ -418,6 +449,15 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     auto get = [&](const std::string& nm, std::initializer_list<int64_t> shp) { return find_w(h, nm, shp); };
     auto put_vec = [&](const HostTensor* t) { size_t o = bb.add(t->data.size()); std::copy(t->data.begin(), t->data.end(), bb.host.begin() + o); return o; };
     auto put_packed = [&](const HostTensor* t) { size_t o = bb.add(GAMD_WFRAG_FLOATS); pack128(t->data.data(), bb.host.data() + o); return o; };
+    const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16;
+    // edge-side matrices (edge_affine, theta_edge, edge_encoder): fp32 or bf16 fragments (32 KiB, stored in the
+    // float blob as 8192 words)
+    auto put_edge = [&](const HostTensor* t) {
+        if (!bf16_edges) return put_packed(t);
+        size_t o = bb.add(GAMD_WFRAG_FLOATS / 2);
+        pack128_bf16(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));
+        return o;
+    };
 
     for (int l = 0; l < L; ++l) {
         const std::string p = "graph_conv.conv." + std::to_string(l);
@@ -436,10 +476,10 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             !pdb || !pew || !peb || !phw || !phb || !ng || !nb)
             return -2;
         Off& o = lo[l];
-        o.w1p = put_packed(ea0w); o.b1 = put_vec(ea0b);
-        o.w2p = put_packed(ea2w);
-        o.w3p = put_packed(t1w); o.b3 = put_vec(t1b);
-        o.w4p = put_packed(t3w); o.b4 = put_vec(t3b);
+        o.w1p = put_edge(ea0w); o.b1 = put_vec(ea0b);
+        o.w2p = put_edge(ea2w);
+        o.w3p = put_edge(t1w); o.b3 = put_vec(t1b);
+        o.w4p = put_edge(t3w); o.b4 = put_vec(t3b);
         o.lng = put_vec(ng); o.lnb = put_vec(nb);
         o.wsp = put_packed(sw); o.wdp = put_packed(dw); o.wpdp = put_packed(pdw);
         o.bS = bb.add(128);
@@ -459,8 +499,9 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     if (!e0w || !e0b || !e2w || !e2b || !e4w || !e4b || !elg || !elb || !cen || !lm || !ls || !d0w || !d0b || !d2w || !d2b)
         return -2;
     const size_t o_e1 = bb.add(4 * 6 * 64 * 4);
-    pack_enc1(e0w->data.data(), F, bb.host.data() + o_e1);
-    const size_t o_e2 = put_packed(e2w), o_e3 = put_packed(e4w);
+    if (bf16_edges) pack_enc1_bf16(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
+    else pack_enc1(e0w->data.data(), F, bb.host.data() + o_e1);
+    const size_t o_e2 = put_edge(e2w), o_e3 = put_edge(e4w);
     const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(e4b), o_elg = put_vec(elg), o_elb = put_vec(elb);
     const size_t o_cen = put_vec(cen);
     const size_t o_d1 = put_packed(d0w), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);

@@ -1,0 +1,55 @@
+// gamd_bf16.h — bf16 variant of the chain layout (BASELINE config 5: bf16 edge-MLP on MFMA, fp32 accumulate).
+//
+// Accumulators stay fp32 in the chain layout of gamd_common.h.  v_mfma_f32_32x32x16_bf16 consumes 8 bf16
+// per lane per operand (K = 16 per instruction), so the 16 features a lane owns in tile t,
+//     feat(t, r, half) = 32t + (r&3) + 8(r>>2) + 4half,   r = 0..15,
+// are fed as two K-steps u = 0,1 of 8 packed values (r = 8u..8u+7).  The weight fragment for
+// (output tile tp, input tile t, step u) is, for lane (n = lane&31, half):
+//     Wp[((tp*4 + t)*2 + u)*64 + lane][j] = bf16( W[32tp + n][feat(t, 8u + j, half)] ),  j = 0..7
+// (32 KiB per 128x128 matrix: all four matrices of a conv layer fit in LDS at once, so the bf16 kernel
+// needs no weight streaming and no barriers in its main loop).  Verified on hardware by
+// probes/mfma_bf16_layout_probe.hip.
+#pragma once
+#include "gamd_common.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gamd_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gamd_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gamd_u32x4 __attribute__((ext_vector_type(4)));
+
+#define GAMD_WFRAG_BF16_BYTES (GAMD_H * GAMD_H * 2)      // 32 KiB
+
+// two floats -> packed bf16 pair, round to nearest even (one v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned gamd_pk_bf16(float lo, float hi) {
+    const gamd_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gamd_bf16x2));
+}
+
+// chain-layout fp32 block -> packed MFMA operands P[t][u]
+__device__ __forceinline__ void pack_chain_bf16(const f32x16 (&X)[4], bf16x8 (&P)[4][2]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            gamd_u32x4 w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = gamd_pk_bf16(X[t][8 * u + 2 * k], X[t][8 * u + 2 * k + 1]);
+            P[t][u] = __builtin_bit_cast(bf16x8, w);
+        }
+}
+
+// acc (+)= W * P^T (F1, chain layout out) or P * W^T (F2, row layout out); 32 MFMAs, 4 independent
+// accumulators rotate inside every K-step
+template <bool F2, typename WPtr>
+__device__ __forceinline__ void gemm128_bf16(WPtr W, int lane, const bf16x8 (&P)[4][2], f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const bf16x8 w = W[((tp * 4 + t) * 2 + u) * 64 + lane];
+                acc[tp] = F2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(P[t][u], w, acc[tp], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, P[t][u], acc[tp], 0, 0, 0);
+            }
+}

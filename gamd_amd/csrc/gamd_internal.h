@@ -63,6 +63,7 @@ struct EncArgs {
     float* feat_dbg;           // optional [e_cap][48] raw features (debug/parity), or null
 };
 int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st);
+int launch_edge_encode_bf16(const EncArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
 
 // ---- conv layer, edge side --------------------------------------------------------------------
 struct ConvEdgeArgs {
@@ -82,6 +83,7 @@ struct ConvEdgeArgs {
     long long* tdbg;           // profiling only: [blocks][8 waves][16] cycle sums (GAMD_CONV_VARIANT bit 4), or null
 };
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
+int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
 
 // ---- node side --------------------------------------------------------------------------------
 struct NodeLayerW {            // one conv layer's node-side parameters (device pointers)

@@ -44,7 +44,7 @@ class GamdForce:
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_atoms: int, box, cutoff: float,
                  bond: Optional[np.ndarray] = None, scaler: Tuple[float, float] = (0.0, 1.0),
                  nbr_flavour: str = "jaxmd", device: int = 0, keep_stages: bool = False,
-                 edge_capacity: int = 0, cfg: Optional[ModelConfig] = None):
+                 edge_capacity: int = 0, cfg: Optional[ModelConfig] = None, edge_dtype: str = "f32"):
         self._h = C.c_void_p()
         self._lib = _lib.load()
         if not torch.cuda.is_available():
@@ -67,6 +67,8 @@ class GamdForce:
         for d in range(3):
             c.box[d] = float(self.box[d])
         c.edge_capacity, c.keep_stages = int(edge_capacity), int(keep_stages)
+        c.edge_dtype = {"f32": 0, "bf16": 1}[edge_dtype]
+        self.edge_dtype = edge_dtype
         check(self._lib.gamd_create(C.byref(c), C.byref(self._h)), "gamd_create")
         self.keep_stages = keep_stages
         for name, t in state_dict.items():

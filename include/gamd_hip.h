@@ -30,6 +30,8 @@ extern "C" {
 
 typedef struct gamd_handle gamd_handle;
 
+enum { GAMD_EDGE_F32 = 0, GAMD_EDGE_BF16 = 1 };
+
 enum { GAMD_KIND_LJ = 0, GAMD_KIND_WATER = 1 };        /* SimpleMDNetNew | WaterMDNetNew / WaterMDDynamicBoxNet */
 enum { GAMD_NBR_JAXMD = 0, GAMD_NBR_TORCH = 1 };        /* dr^2 < rc^2 + self pair | |dr| <= rc, no self */
 
@@ -48,7 +50,8 @@ typedef struct gamd_config {
     float box[3];            /* initial box (may change per call) */
     int64_t edge_capacity;   /* 0 = estimate from density */
     int32_t keep_stages;     /* 1 = keep per-stage tensors for the debug getters */
-    int32_t reserved;
+    int32_t edge_dtype;      /* GAMD_EDGE_F32 (bit-exact fp32 MFMA, default) | GAMD_EDGE_BF16 (BASELINE config 5: edge-MLP
+                                operands rounded to bf16, fp32 accumulate; node side, S/D adds, SiLU, sums stay fp32) */
 } gamd_config;
 
 const char* gamd_version(void);

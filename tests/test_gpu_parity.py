@@ -229,3 +229,40 @@ def test_model_level_forward_with_explicit_edges(name):
     assert rel_err(out3, ref3) < TOL
     with pytest.raises(Exception, match="outside"):
         eng.forward_edges(posw, torch.tensor([[0, 5], [1, 100000]]), species=species)
+
+
+BF16_TOL = 1e-2      # BASELINE config 5: tolerance re-stated for the bf16 edge-MLP; achieved ~4e-3
+
+
+def test_c5_bf16_edge_mlp_against_fp32_path_and_oracle():
+    """BASELINE config 5: TIP4P-Ew-sized water box (2 000 molecules = 6 000 network atoms, M-sites dropped,
+    train_utils.py:58-59), edge-MLP GEMMs on bf16 MFMA with fp32 accumulate.  Edge sets must be identical to the
+    fp32 path (the neighbour search stays fp32); forces within the restated tolerance of the fp32 path and of the
+    fp32 CPU oracle."""
+    pos, box, species, bonds = workloads.water_box(2000, mol_per_20A3=251.0, seed=3456)
+    cfg = ModelConfig(kind="water", use_bond=True)
+    sd = make_state_dict(cfg, 3, 2.9, 1.1)
+    p = torch.from_numpy(pos).float()
+    e32 = _engine(sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS["tip4p"])
+    e16 = _engine(sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS["tip4p"], edge_dtype="bf16")
+    a = e32.forward(p, species=species).cpu().numpy().copy()
+    b = e16.forward(p, species=species).cpu().numpy().copy()
+    assert np.array_equal(edge_set(e16.debug_edges()), edge_set(e32.debug_edges()))
+    err = rel_err(b, a)
+    assert 1e-5 < err < BF16_TOL, err            # really is the reduced-precision path, and within tolerance
+    edges = torch.from_numpy(e32.debug_edges()).long()
+    feat = torch.from_numpy(species.astype(np.float32)).view(-1, 1)
+    ref = orc.forward(sd, p, edges, box, feat=feat, bond=bonds).numpy()
+    assert rel_err(b, ref) < BF16_TOL and rel_err(a, ref) < TOL
+    b2 = e16.forward(p, species=species).cpu().numpy()
+    assert np.array_equal(b, b2)                 # still bit-reproducible
+    e32.close(); e16.close()
+
+
+def test_bf16_lj_golden_within_restated_tolerance():
+    g, cfg, sd = load_golden("lj258_seed0")
+    box = float(g["box"])
+    eng = _engine(sd, 258, box, float(g["cutoff"]), scaler=(g["scaler_mean"], g["scaler_var"]), edge_dtype="bf16")
+    out = eng.forward(torch.from_numpy(np.mod(g["pos"], box)).float()).cpu().numpy()
+    assert rel_err(out, g["out_norm"]) < BF16_TOL
+    eng.close()
