@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_bf16(ConvEdgeArgs a) {
     for (int wt = first; wt < end; wt += step) {
         const int tile = wt * 8 + wave;
         if (tile >= n_tiles) continue;
+        asm volatile("" ::: "memory");               // keep loop-invariant LDS reads (bias, weights) inside the loop
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
         const int src = valid ? a.col[x] : 0;
