@@ -25,17 +25,24 @@ namespace {
 
 constexpr int XLD = 132;                       // padded row stride of the exchange buffer (floats)
 
-// acc (this wave's 32 output features x 32 atoms, one C tile) += W[quarter] * X^T
-__device__ __forceinline__ void gemm_quarter(const float* __restrict__ Wp, int quarter, int lane,
-                                             const f32x16 (&X)[4], f32x16& acc) {
+// This wave's 16 KiB weight quarter (output features [32q, 32q+32)) as 16 float4 per lane, fetched from L2
+// in ONE batch: the kernel is latency-bound, so a GEMM must cost one L2 round trip, not sixteen.
+struct WQuarter { f32x4 w[16]; };
+
+__device__ __forceinline__ void load_wquarter(const float* __restrict__ Wp, int quarter, int lane, WQuarter& o) {
     const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 16 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o.w[i] = W[i * 64];
+}
+
+// acc (this wave's 32 output features x 32 atoms, one C tile) += W[quarter] * X^T
+__device__ __forceinline__ void gemm_quarter(const WQuarter& wq, const f32x16 (&X)[4], f32x16& acc) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 w = W[(t * 4 + q) * 64];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = mfma32(w[j], X[t][q * 4 + j], acc);
+            for (int j = 0; j < 4; ++j) acc = mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
         }
 }
 
@@ -84,6 +91,7 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
 
     f32x16 X[4];          // full activation row block (chain layout)
     f32x16 mine;          // this wave's output quarter
+    WQuarter wa, wb;      // double-buffered weight quarters
 
     if (a.mode == 0) {
         if (a.node_emb) {
@@ -96,26 +104,42 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
             for (int r = 0; r < 16; ++r) mine[r] = f * w[r] + mine[r];
         }
         if (valid) store_slice(a.h_out + row, quarter, half, mine);
+        load_wquarter(a.pre.wsp, quarter, lane, wa);
     } else {
         // ---- post(l-1): aggregate this quarter's slice of the pieces, in order ------------------
         const int rp0 = a.row_ptr[atom], dg = a.deg[atom];
         const int na_incl = a.na_excl[atom] + ((dg > 0 && (rp0 % GAMD_CHUNK) != 0) ? 1 : 0);
         const int p0 = rp0 / GAMD_CHUNK + na_incl;
         const int np = dg > 0 ? ((rp0 + dg - 1) / GAMD_CHUNK - rp0 / GAMD_CHUNK + 1) : 0;
+        // pieces are fetched in batches of 8 (one memory round trip for the usual 4-6 pieces per atom) and
+        // summed in piece order
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[r] = 0.f;
-        for (int k = 0; __any(k < np); ++k) {
-            if (k < np) mine += load_slice(a.partial + (size_t)(p0 + k) * GAMD_H, quarter, half);
+        const f32x16 p_in = load_slice(a.P_in + row, quarter, half);     // also in flight now
+        const f32x16 h_res = load_slice(a.h_in + row, quarter, half);
+        for (int k0 = 0; __any(k0 < np); k0 += 8) {
+            f32x16 pc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = (k0 + k < np) ? k0 + k : (np > 0 ? np - 1 : 0);
+                pc[k] = load_slice(a.partial + (size_t)(np > 0 ? p0 + kk : 0) * GAMD_H, quarter, half);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < np) mine += pc[k];
         }
+        load_wquarter(a.post.wpep, quarter, lane, wa);            // in flight during the exchange
         exchange(xbuf, quarter, slot, half, mine, X);            // X = agg
-        mine = load_slice(a.P_in + row, quarter, half);
-        gemm_quarter(a.post.wpep, quarter, lane, X, mine);
+        mine = p_in;
+        load_wquarter(a.post.wphip, quarter, lane, wb);           // next GEMM's weights behind this one
+        gemm_quarter(wa, X, mine);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[r] = gamd_silu_hw(mine[r]);
         exchange(xbuf, quarter, slot, half, mine, X);            // X = SiLU(P + phi_edge(agg))
         mine = load_slice(a.post.bphi, quarter, half);
-        gemm_quarter(a.post.wphip, quarter, lane, X, mine);
-        mine += load_slice(a.h_in + row, quarter, half);          // residual
+        if (a.mode != 2) load_wquarter(a.pre.wsp, quarter, lane, wa); else load_wquarter(a.dec_w1p, quarter, lane, wa);
+        gemm_quarter(wb, X, mine);
+        mine += h_res;                                            // residual
         if (valid) store_slice(a.h_out + row, quarter, half, mine);
     }
 
@@ -144,20 +168,22 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
         if (valid) store_slice(a.hn_out + row, quarter, half, mine);
         exchange(xbuf, quarter, slot, half, mine, X);            // X = hn
         mine = load_slice(a.pre.bS, quarter, half);
-        gemm_quarter(a.pre.wsp, quarter, lane, X, mine);
+        load_wquarter(a.pre.wdp, quarter, lane, wb);
+        gemm_quarter(wa, X, mine);
         if (valid) store_slice(a.S_out + row, quarter, half, mine);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mine[r] = 0.f;
-        gemm_quarter(a.pre.wdp, quarter, lane, X, mine);
+        load_wquarter(a.pre.wpdp, quarter, lane, wa);
+        gemm_quarter(wb, X, mine);
         if (valid) store_slice(a.D_out + row, quarter, half, mine);
         mine = load_slice(a.pre.bP, quarter, half);
-        gemm_quarter(a.pre.wpdp, quarter, lane, X, mine);
+        gemm_quarter(wa, X, mine);
         if (valid) store_slice(a.P_out + row, quarter, half, mine);
     } else {
         // ---- decoder: Lin(128,128) GELU Lin(128,3); denormalise -------------------------------
         exchange(xbuf, quarter, slot, half, mine, X);            // X = h'
         mine = load_slice(a.dec_b1, quarter, half);
-        gemm_quarter(a.dec_w1p, quarter, lane, X, mine);
+        gemm_quarter(wa, X, mine);
         float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
