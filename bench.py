@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+                    help="c2 (default, the headline metric): 10k-atom LJ fp32; c3: 4 170-atom TIP3P fp32; "
+                         "c5: 6 000-network-atom TIP4P-Ew-sized box, bf16 edge-MLP")
     args = ap.parse_args()
 
     # RCCL ("nccl") over xGMI in production; GAMD_BENCH_BACKEND=gloo + GAMD_BENCH_SHARE_GPU=1 let the N>1 control
@@ -88,14 +91,32 @@ def main():
     torch.cuda.set_device(dev)
     ddev = f"cuda:{dev}" if (ctx.distributed and backend == "nccl") else "cpu"
 
-    pos, box = lj_box(N_ATOMS, seed=ens.box_seed(1234, ctx))
-    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
-    eng = GamdForce(sd, N_ATOMS, box, CUTOFF, scaler=SHIPPED_SCALERS["lj"], device=dev)
+    species, mass, dtype_name = None, 39.9, "f32"
+    if args.workload == "c2":
+        pos, box = lj_box(N_ATOMS, seed=ens.box_seed(1234, ctx))
+        sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+        eng = GamdForce(sd, N_ATOMS, box, CUTOFF, scaler=SHIPPED_SCALERS["lj"], device=dev)
+        n_atoms = N_ATOMS
+        wl = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
+              "random-init weights (seed 0), 1 box per GPU")
+    else:
+        from gamd_amd.workloads import water_box
+        nmol, dens, scal, seed0 = (1390, 258.0, "tip3p", 2345) if args.workload == "c3" else (2000, 251.0, "tip4p", 3456)
+        pos, box, species, bonds = water_box(nmol, mol_per_20A3=dens, seed=ens.box_seed(seed0, ctx))
+        sd = make_state_dict(ModelConfig(kind="water", use_bond=True), 3, 2.9, 1.1)
+        dtype_name = "bf16" if args.workload == "c5" else "f32"
+        eng = GamdForce(sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS[scal], device=dev,
+                        edge_dtype=dtype_name)
+        n_atoms, mass = pos.shape[0], 6.0      # unconstrained integration of the network atoms (no SETTLE on device)
+        wl = (f"{args.workload.upper()}: {nmol} rigid-geometry water molecules = {n_atoms} network atoms, cutoff 4.2 A, "
+              f"bond feature, {'bf16 edge-MLP operands / fp32 accumulate' if dtype_name == 'bf16' else 'fp32'}, "
+              "random-init weights (seed 3), 1 box per GPU")
     x = torch.from_numpy(pos).float().cuda(dev)
-    v = torch.from_numpy(maxwell_boltzmann(N_ATOMS, seed=99 + ctx.rank)).float().cuda(dev)
-    f = eng.forward(x, denormalize=True).clone()
+    v = torch.from_numpy(maxwell_boltzmann(n_atoms, mass_amu=mass, seed=99 + ctx.rank)).float().cuda(dev)
+    f = eng.forward(x, species=species, denormalize=True).clone()
 
-    md = dict(dt_ps=0.002, mass_amu=39.9, temperature_k=100.0, gamma_per_ps=25.0, seed=ens.box_seed(7, ctx))
+    md = dict(dt_ps=0.002 if args.workload == "c2" else 0.0005, mass_amu=mass, temperature_k=100.0, gamma_per_ps=25.0,
+              seed=ens.box_seed(7, ctx), species=species)
     eng.md_run(x, v, f, args.warmup, first_step=0, **md)
     torch.cuda.synchronize(dev)
     ens.barrier(ctx)
@@ -120,31 +141,37 @@ def main():
     if not all(s["finite"] == 1.0 for s in summary):
         raise SystemExit("non-finite state after the timed run")
 
-    value = ens.aggregate_throughput(N_ATOMS * args.steps, dt_max, ctx)
+    value = ens.aggregate_throughput(n_atoms * args.steps, dt_max, ctx)
     avg_ms = conv_ms / max(conv_n, 1)
     achieved = n_edges * FLOP_PER_EDGE_CONV / (avg_ms * 1e-3) / 1e12
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_conv_edge.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.workload == "c2":        # the PMC passes were taken on the C2 workload
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     line = {
-        "metric": "atom-steps/sec (force eval + integrate), 10k-atom LJ box",
+        "metric": "atom-steps/sec (force eval + integrate), 10k-atom LJ box" if args.workload == "c2"
+                  else f"atom-steps/sec (force eval + integrate), {args.workload} water box",
         "value": value, "unit": "atom-steps/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, "
-                               "4 conv layers x 128, random-init weights (seed 0), 1 box per GPU",
-                   "n_atoms": N_ATOMS, "edges_per_step": n_edges, "boxes": ctx.world,
+        "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+        "config": {"workload": wl, "n_atoms": n_atoms, "edges_per_step": n_edges, "boxes": ctx.world,
                    "step": "BAOAB half + neighbour build + GNN forces + BAOAB half, on device"},
         "roofline": {"kernel": "k_conv_edge", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "avg_launch_ms": avg_ms, "launches": conv_n,
                      "flop_per_launch": n_edges * FLOP_PER_EDGE_CONV},
     }
-    if ctx.world == 1 and not args.no_cpu_baseline:
+    if dtype_name == "bf16":
+        # the bf16 kernel is gather-bound, not matrix-bound: report the neighbour-gather bytes of SURVEY.md §8d
+        # (per edge: 4 B index + 512 B h[src] row + 512 B S[src] row) against HBM peak
+        gbytes = n_edges * 1028.0
+        line["roofline"] = {"kernel": "k_conv_edge_bf16", "bound": "hbm", "achieved": gbytes / (avg_ms * 1e-3) / 1e9,
+                            "peak": 8000.0, "unit": "GB/s", "frac": gbytes / (avg_ms * 1e-3) / 8e12, "traffic": None,
+                            "avg_launch_ms": avg_ms, "launches": conv_n, "bytes_per_launch": gbytes}
+    if ctx.world == 1 and not args.no_cpu_baseline and args.workload == "c2":
         cpu_s, thr, cpu_edges, err, same_edges = cpu_baseline(sd, dev)
         line["cpu_baseline"] = {"value": CPU_SAMPLE_ATOMS / cpu_s, "unit": "atom-steps/s", "cores": thr,
                                 "kind": "port",
