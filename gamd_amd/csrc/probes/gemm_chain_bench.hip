@@ -50,6 +50,24 @@ __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)
     for (int g = 0; g < 16; ++g) post(3, g);
 }
 
+// pipelined post-op + explicit one-group-ahead weight prefetch
+template <bool F2, typename WPtr, typename Post>
+__device__ __forceinline__ void gemm128_post_pf(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post) {
+    f32x4 w = W[lane];
+#pragma unroll
+    for (int g = 0; g < 64; ++g) {
+        const int tp = g >> 4, t = (g >> 2) & 3, q = g & 3;
+        f32x4 wn = w;
+        if (g + 1 < 64) wn = W[(g + 1) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tp] = mfma32(w[j], X[t][q * 4 + j], acc[tp]);
+        if (tp > 0) post(tp - 1, t * 4 + q);
+        w = wn;
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) post(3, g);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* __restrict__ out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -82,6 +100,12 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
                 }
             }
             for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.01f;
+            if (MODE == 10) {
+                gemm128_post_pf<false>((const f32x4*)cur, lane, X, acc, [&](int tp, int g) { acc[tp][g] = silu_hw(acc[tp][g]); });
+#pragma unroll
+                for (int t = 0; t < 4; ++t) X[t] = acc[t];
+                continue;
+            }
             if (MODE == 8 || MODE == 9) {
                 gemm128_post<false>((const f32x4*)cur, lane, X, acc, [&](int tp, int g) { acc[tp][g] = silu_hw(acc[tp][g]); });
 #pragma unroll
@@ -142,6 +166,8 @@ int main() {
         printf("mode8 pipelined silu post-op, no barrier (8 waves): %.1f TF\n", run<8>(dW, dOut, iters));
         printf("mode9 pipelined silu + barrier + stage (8 waves) : %.1f TF\n", run<9>(dW, dOut, iters));
         printf("mode8 pipelined silu post-op (4 waves)           : %.1f TF\n", run<8>(dW, dOut, iters, 256));
+        printf("mode10 pipelined silu + w prefetch (8 waves)     : %.1f TF\n", run<10>(dW, dOut, iters));
+        printf("mode10 pipelined silu + w prefetch (4 waves)     : %.1f TF\n", run<10>(dW, dOut, iters, 256));
         printf("mode1 4 waves/CU (1 per SIMD)        : %.1f TF\n", run<1>(dW, dOut, iters, 256));
         printf("mode5 4 waves/CU prefetch            : %.1f TF\n", run<5>(dW, dOut, iters, 256));
         printf("mode2 4 waves/CU + silu              : %.1f TF\n", run<2>(dW, dOut, iters, 256));

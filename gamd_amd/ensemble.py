@@ -38,6 +38,8 @@ def init_ensemble(backend: str = "nccl", device_index=None) -> EnsembleContext:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # the host driver only supports dmabuf IPC; without this RCCL fails with hipIpcGetMemHandle errors
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = {}
         if backend == "nccl":
             d = local if device_index is None else device_index
