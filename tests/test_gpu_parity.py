@@ -266,3 +266,66 @@ def test_bf16_lj_golden_within_restated_tolerance():
     out = eng.forward(torch.from_numpy(np.mod(g["pos"], box)).float()).cpu().numpy()
     assert rel_err(out, g["out_norm"]) < BF16_TOL
     eng.close()
+
+
+def test_tiny_and_crowded_systems():
+    """Edge cases of the neighbour build: fewer atoms than one 32-row tile; a single over-full cell
+    (> 64 atoms: serial sort fallback) with rows longer than a wave."""
+    sd = make_state_dict(ModelConfig(kind="lj"), 11, 3.0, 1.0)
+    # 3 atoms, far apart: only the self edges remain
+    pos = np.array([[1.0, 1.0, 1.0], [10.0, 10.0, 10.0], [19.0, 3.0, 7.0]])
+    eng = _engine(sd, 3, 25.0, 3.0)
+    out = eng.forward(torch.from_numpy(pos).float()).cpu().numpy()
+    edges = eng.debug_edges()
+    assert edges.shape[1] == 3 and np.array_equal(edges[0], edges[1])
+    ref = orc.forward(sd, torch.from_numpy(pos).float(), torch.from_numpy(edges).long(), 25.0).numpy()
+    assert rel_err(out, ref) < TOL
+    eng.close()
+    # 200 atoms in a box smaller than 2 cutoffs: one cell, every pair within the cutoff is an edge (degree ~120)
+    rng = np.random.default_rng(21)
+    pos = rng.uniform(0, 9.0, (200, 3))
+    eng = _engine(sd, 200, 9.0, 4.4)
+    p = torch.from_numpy(pos).float()
+    out = eng.forward(p).cpu().numpy()
+    edges = eng.debug_edges()
+    ref_e = orc.neighbor_edges(p, 9.0, 4.4, "jaxmd").numpy()
+    assert np.array_equal(edge_set(edges), edge_set(ref_e))
+    assert np.bincount(edges[0]).max() > 64
+    ref = orc.forward(sd, p, torch.from_numpy(edges).long(), 9.0).numpy()
+    assert rel_err(out, ref) < TOL
+    eng.close()
+
+
+def test_box_changes_between_calls():
+    """WaterMDDynamicBoxNet takes the box per call (nn_module.py:391-396): the cell grid is rebuilt when it changes."""
+    g, cfg, sd = load_golden("dynbox384_seed4")
+    n = g["pos"].shape[0]
+    eng = _engine(sd, n, g["box"], float(g["cutoff"]), nbr_flavour="torch", cfg=ModelConfig(kind="water", use_bond=False))
+    species = g["node_feat"].reshape(-1) != 0
+    feat = torch.from_numpy(g["node_feat"])
+    for scale in (1.0, 1.6, 0.8, 1.0):
+        box = (g["box"] * scale).astype(np.float32)
+        pos = torch.from_numpy(g["pos"] * scale)
+        out = eng.forward(pos, box=box, species=species).cpu().numpy()
+        ref = orc.forward_dynamic_box(sd, pos, feat, box, float(g["cutoff"])).numpy()
+        assert rel_err(out, ref) < TOL, scale
+    eng.close()
+
+
+def test_error_conventions():
+    """Errors come back as negative status + message (GamdError), never as a crash."""
+    from gamd_amd._lib import GamdError
+    sdw = make_state_dict(ModelConfig(kind="water", use_bond=True), 1)
+    with pytest.raises(ValueError, match="bond"):
+        _engine(sdw, 30, 12.0, 3.0)                                  # use_bond model without a bond list
+    eng = _engine(sdw, 30, 12.0, 3.0, bond=np.array([[0, 1], [0, 2]]))
+    pos = torch.rand(30, 3) * 12
+    with pytest.raises(GamdError, match="species"):
+        eng.forward(pos)                                             # water model needs species
+    with pytest.raises(ValueError, match=r"\[30, 3\]"):
+        eng.forward(torch.rand(31, 3))
+    with pytest.raises(GamdError, match="positive"):
+        eng.forward(pos, box=[12.0, -1.0, 12.0], species=np.zeros(30))
+    with pytest.raises(GamdError, match="4 bonded"):
+        _engine(sdw, 30, 12.0, 3.0, bond=np.array([[0, k] for k in range(1, 7)]))
+    eng.close()
