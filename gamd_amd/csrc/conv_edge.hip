@@ -58,14 +58,6 @@ __device__ __forceinline__ void stage_weight(const float* __restrict__ gw, float
 // already complete, output tile.  Only tile 3's post-op trails the last MFMA.
 template <bool F2, typename WPtr, typename Post>
 __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post) {
-#ifdef GAMD_TRAILING_POST
-    gemm128<F2>(W, lane, X, acc);
-#pragma unroll
-    for (int tp = 0; tp < 4; ++tp)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) post(tp, g);
-    return;
-#endif
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
 #pragma unroll
