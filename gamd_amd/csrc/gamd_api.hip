@@ -99,8 +99,6 @@ struct gamd_handle {
 
 namespace {
 
-size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
 int alloc_edges(gamd_handle* h, long long e_cap) {
     const size_t ec = (size_t)e_cap + 2 * GAMD_TILE;
     int r = 0;
@@ -244,8 +242,6 @@ const HostTensor* find_w(gamd_handle* h, const std::string& name, std::initializ
     }
     return &it->second;
 }
-
-int ensure_stream_ok(hipStream_t st) { (void)st; return 0; }
 
 struct EdgeList { const int* centre; const int* neigh; long long n; };
 

@@ -38,11 +38,6 @@ __device__ __forceinline__ int gamd_pi(int rho) {
     return 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
 }
 
-// feature index of chain-layout register (t, r) for a lane in `half`
-__device__ __forceinline__ int gamd_feat(int t, int r, int half) {
-    return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-}
-
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -73,14 +68,7 @@ __device__ __forceinline__ void gemm128(WPtr W, int lane, const f32x16 (&X)[4], 
     for (int tp = 0; tp < 4; ++tp) gemm128_tile<F2>(W, lane, X, acc[tp], tp);
 }
 
-// ---- activations, written to match torch's fp32 CPU kernels op for op -------------------------
-__device__ __forceinline__ float gamd_silu(float x) {      // nn.SiLU: x * sigmoid(x) = x / (1 + exp(-x))
-    return x / (1.0f + expf(-x));
-}
-__device__ __forceinline__ float gamd_gelu(float x) {      // nn.GELU() default: exact erf form
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
-
+// ---- activations ---------------------------------------------------------------------------------
 // Hardware-transcendental forms used inside the MFMA kernels.  On gfx950 fp32 MFMA issues at the fp32
 // VALU rate and VALU work is NOT hidden behind it (measured: a software-pipelined SiLU costs the same
 // 8 % as a trailing one), so activations are written for the fewest VALU cycles that keep fp32 accuracy.
@@ -109,13 +97,8 @@ __device__ __forceinline__ float gamd_remainder(float a, float b) {
     return m;
 }
 
-// minimum image exactly as nn_module.py:617-621: remainder(d + L/2, L) - L/2
-__device__ __forceinline__ float gamd_min_image(float d, float L, float halfL) {
-    return gamd_remainder(d + halfL, L) - halfL;
-}
-
-// same for |d| <= L (differences of wrapped coordinates): fmod is exact, so this branch form is
-// bit-identical to gamd_min_image / torch.remainder on that range, without the fmod
+// minimum image of nn_module.py:617-621, remainder(d + L/2, L) - L/2, for |d| <= L (differences of wrapped
+// coordinates): fmod is exact, so this branch form is bit-identical to torch.remainder on that range
 __device__ __forceinline__ float gamd_min_image_wrapped(float d, float L, float halfL) {
     float t = d + halfL;
     if (t < 0.0f) t += L;
