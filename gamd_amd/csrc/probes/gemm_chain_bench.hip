@@ -69,10 +69,11 @@ __device__ __forceinline__ void gemm128_post_pf(WPtr W, int lane, const f32x16 (
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* __restrict__ out, int iters) {
+__global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* __restrict__ out, int iters, const float* __restrict__ G) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    (void)G;
     f32x16 X[4], acc[4];
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) { X[t][r] = 0.001f * (lane + r + t); acc[t][r] = 0.f; }
     if (MODE == 0) {
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
         for (int it = 0; it < iters; ++it) {
             float* cur = (it & 1) ? buf1 : buf0;
             float* nxt = (it & 1) ? buf0 : buf1;
-            if (MODE == 3 || MODE == 4 || MODE == 6 || MODE == 9) {
+            if (MODE == 3 || MODE == 4 || MODE == 6 || MODE == 9 || MODE == 11 || MODE == 12) {
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const int chunk = kk * 8 + wave;
@@ -100,6 +101,33 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
                 }
             }
             for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.01f;
+            if (MODE == 11 || MODE == 12) {
+                // mode 9 + per-GEMM streamed loads consumed by the post-op (like e / S / D): 16 x b128 per lane
+                const size_t tilebase = ((size_t)(blockIdx.x * 8 + wave) * 64 + (it & 63)) * 4096;
+                f32x16 S[4];
+                const f32x4* gp = (const f32x4*)(G + tilebase);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = gp[(t * 4 + q) * 64 + lane];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) S[t][q * 4 + j] = v[j];
+                    }
+                if (MODE == 12) {      // plus 64 dword gathers (hn-like), row chosen pseudo-randomly
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned row = ((it * 16 + r) * 2654435761u + blockIdx.x * 97u) % 10000u;
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) S[tp][r] += G[(size_t)row * 128 + 32 * tp + (lane & 31)];
+                    }
+                }
+                gemm128_post<false>((const f32x4*)cur, lane, X, acc, [&](int tp, int g) { acc[tp][g] = silu_hw(acc[tp][g] + S[tp][g]); });
+#pragma unroll
+                for (int t = 0; t < 4; ++t) X[t] = acc[t];
+                __syncthreads();
+                continue;
+            }
             if (MODE == 10) {
                 gemm128_post_pf<false>((const f32x4*)cur, lane, X, acc, [&](int tp, int g) { acc[tp][g] = silu_hw(acc[tp][g]); });
 #pragma unroll
@@ -133,15 +161,17 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ W, float* 
     out[blockIdx.x * 512 + tid] = s;
 }
 
+static float* g_stream = nullptr;
 template <int MODE>
 double run(const float* dW, float* dOut, int iters, int threads = 512) {
+    const float* dG = g_stream;
     const size_t ldsb = sizeof(float) * 2 * GAMD_WFRAG_FLOATS;
     hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<MODE><<<256, threads, ldsb>>>(dW, dOut, 4);
+    k<MODE><<<256, threads, ldsb>>>(dW, dOut, 4, dG);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<MODE><<<256, threads, ldsb>>>(dW, dOut, iters);
+    k<MODE><<<256, threads, ldsb>>>(dW, dOut, iters, dG);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = 256.0 * (threads / 64) * iters * 256 * 4096.0;   // blocks*waves*iters*MFMAs*flop
@@ -154,6 +184,9 @@ int main() {
     float *dW, *dOut; hipMalloc(&dW, W.size() * 4); hipMalloc(&dOut, 256 * 512 * 4);
     hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
     const int iters = 400;
+    float* dG; hipMalloc(&dG, (size_t)256 * 8 * 64 * 4096 * 4);     // 2 GiB streamed region
+    hipMemset(dG, 0, (size_t)256 * 8 * 64 * 4096 * 4);
+    g_stream = dG;
     for (int rep = 0; rep < 2; ++rep) {
         printf("mode0 pure mfma        : %.1f TF\n", run<0>(dW, dOut, iters));
         printf("mode1 gemm128 from LDS : %.1f TF\n", run<1>(dW, dOut, iters));
@@ -168,6 +201,8 @@ int main() {
         printf("mode8 pipelined silu post-op (4 waves)           : %.1f TF\n", run<8>(dW, dOut, iters, 256));
         printf("mode10 pipelined silu + w prefetch (8 waves)     : %.1f TF\n", run<10>(dW, dOut, iters));
         printf("mode10 pipelined silu + w prefetch (4 waves)     : %.1f TF\n", run<10>(dW, dOut, iters, 256));
+        printf("mode11 hooks+barrier+stage + 16 KB streamed load per GEMM: %.1f TF\n", run<11>(dW, dOut, iters));
+        printf("mode12 mode11 + 64 dword gathers per GEMM               : %.1f TF\n", run<12>(dW, dOut, iters));
         printf("mode1 4 waves/CU (1 per SIMD)        : %.1f TF\n", run<1>(dW, dOut, iters, 256));
         printf("mode5 4 waves/CU prefetch            : %.1f TF\n", run<5>(dW, dOut, iters, 256));
         printf("mode2 4 waves/CU + silu              : %.1f TF\n", run<2>(dW, dOut, iters, 256));
