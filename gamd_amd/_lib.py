@@ -16,7 +16,9 @@ class GamdConfig(C.Structure):
     _fields_ = [("n_atoms", C.c_int32), ("kind", C.c_int32), ("n_layers", C.c_int32),
                 ("use_bond", C.c_int32), ("nbr_flavour", C.c_int32), ("device", C.c_int32),
                 ("cutoff", C.c_float), ("box", C.c_float * 3), ("edge_capacity", C.c_int64),
-                ("keep_stages", C.c_int32), ("edge_dtype", C.c_int32)]
+                ("keep_stages", C.c_int32), ("edge_dtype", C.c_int32),
+                ("encoding_size", C.c_int32), ("edge_embedding_dim", C.c_int32), ("hidden_dim", C.c_int32),
+                ("no_expand_edge", C.c_int32)]
 
 
 class GamdNhcParams(C.Structure):

@@ -6,6 +6,7 @@
     model.load_training_stats(SCALER_CKPT); model.cuda(); model.eval()
     force = model.predict_forces(pos)            # LJ    (np f64 [N,3] -> np f64 [N,3])
     force = model.predict_forces(feat, pos)      # water (feat: torch [N,1], O=1/H=0)
+    force = model.predict_forces(feat, pos, box_size)   # DFT water (bohr; box_size np [3] per call)
 
 Physics constants that are module-level in the reference (BOX_SIZE, CUTOFF_RADIUS,
 NUM_OF_ATOMS; LJ/train_network_lj.py:26-29, water/train_network_tip3p.py:24-29) are
@@ -33,7 +34,8 @@ def create_water_bond(total_atom_num: int) -> np.ndarray:
 class _ModelLevel:
     """`self.pnet_model` of the reference wrappers: the nn.Module called as ``model([pos], [edge_idx])``
     (SimpleMDNetNew.forward, nn_module.py:672-685) or ``model([pos], feat, [edge_idx])``
-    (WaterMDNetNew.forward, :545-558).  Single-graph (inference) form only; returns the NORMALISED output."""
+    (WaterMDNetNew.forward, :545-558) or ``model([pos], feat, [box_size], cutoff)`` (WaterMDDynamicBoxNet.forward,
+    :391-407, which searches neighbours itself).  Single-graph (inference) form only; returns the NORMALISED output."""
 
     def __init__(self, owner):
         self._owner = owner
@@ -45,8 +47,14 @@ class _ModelLevel:
             feat, edge_lst = None, rest[0]
         elif len(rest) == 2:
             feat, edge_lst = rest
+        elif len(rest) == 3:
+            feat, box_lst, cutoff = rest
+            eng = self._owner._get_engine()
+            if abs(float(cutoff) - eng.cutoff) > 1e-6 * eng.cutoff:
+                raise ValueError(f"cutoff {cutoff} differs from the one the engine was built with ({eng.cutoff})")
+            return eng.forward(pos_lst[0], box=np.asarray(box_lst[0], dtype=np.float32), species=feat.reshape(-1) != 0)
         else:
-            raise TypeError("expected ([pos], [edge_idx]) or ([pos], feat, [edge_idx])")
+            raise TypeError("expected ([pos], [edge_idx]), ([pos], feat, [edge_idx]) or ([pos], feat, [box], cutoff)")
         species = None if feat is None else (feat.reshape(-1) != 0)
         return self._owner._get_engine().forward_edges(pos_lst[0], edge_lst[0], species=species)
 
@@ -59,6 +67,7 @@ class _ForceFieldBase:
         self.args = args or SimpleNamespace()
         self.num_atoms, self.box_size, self.cutoff = int(num_atoms), box_size, float(cutoff)
         self.bond, self.device_index = bond, device
+        self._nbr_flavour = "jaxmd"                  # graph_utils.NeighborSearcher semantics ('<' on r^2, self edge kept)
         self.training_mean = np.array([0.])          # LJ/train_network_lj.py:105-106
         self.training_var = np.array([1.])
         self._sd = state_dict
@@ -96,7 +105,8 @@ class _ForceFieldBase:
             if self._sd is None:
                 raise RuntimeError("no weights loaded: call load_from_checkpoint / load_state_dict first")
             self._engine = GamdForce(self._sd, self.num_atoms, self.box_size, self.cutoff, bond=self.bond,
-                                     scaler=(self.training_mean, self.training_var), device=self.device_index)
+                                     scaler=(self.training_mean, self.training_var), device=self.device_index,
+                                     nbr_flavour=self._nbr_flavour)
         return self._engine
 
     def denormalize(self, normalized_force, var, mean):
@@ -138,3 +148,30 @@ class ParticleNetLightningWater(_ForceFieldBase):
 
     def predict_forces(self, feat: torch.Tensor, pos: np.ndarray) -> np.ndarray:
         return self._predict(pos, feat)
+
+
+# test_nosehoover_hb.py:109: predict_forces returns hartree/bohr; the driver converts to kJ/mol/nm
+HARTREE_PER_BOHR_TO_KJ_PER_MOL_NM = 2625.5 / 0.0529177
+
+
+class ParticleNetLightningDFT(_ForceFieldBase):
+    """DFT-water flavour (code/water/train_network_real_large.py:103-162, driver
+    water/test_script/test_nosehoover_hb.py:64-113): WaterMDDynamicBoxNet with encoding 256 / edge embedding 256 /
+    hidden 128 / 5 layers, cutoff ``args.cutoff`` (9.5 bohr), positions and box in bohr, the box handed over per
+    call; neighbour semantics of md_module.get_neighbor ('<=' on the norm, no self edges)."""
+
+    def __init__(self, args=None, state_dict=None, *, num_atoms=258 * 3, box_size=None, cutoff=None, **kw):
+        if cutoff is None:
+            cutoff = getattr(args, "cutoff", 9.5)
+        if box_size is None:                         # only sizes the first neighbour buffers; the real box comes per call
+            box_size = 20.0 / 0.529177
+        super().__init__(args, state_dict, num_atoms=num_atoms, box_size=box_size, cutoff=cutoff, **kw)
+        self._nbr_flavour = "torch"
+
+    def predict_forces(self, feat: torch.Tensor, pos: np.ndarray, box_size) -> np.ndarray:
+        eng = self._get_engine()
+        box = np.asarray(box_size, dtype=np.float64).reshape(-1)
+        posw = np.mod(np.asarray(pos, dtype=np.float64), box)                 # train_network_real_large.py:150
+        pred = eng.forward(torch.from_numpy(posw).float(), box=box.astype(np.float32), species=(feat.reshape(-1) != 0))
+        pred = pred.detach().cpu().numpy()
+        return self.denormalize(pred, self.training_var, self.training_mean)  # :160

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -62,6 +63,8 @@ struct LayerDev {
 struct gamd_handle {
     gamd_config cfg{};
     int n = 0, L = 0, n_feat = 44, n_cu = 256;
+    int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width and their 128-blocks
+    bool wide_enc = false, wide_conv = false;    // generic-width kernels of wide.hip
     std::map<std::string, HostTensor> host_w;
     bool finalized = false;
     double scaler_mean = 0.0, scaler_var = 1.0;
@@ -106,8 +109,8 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
     r |= h->erow.ensure(sizeof(int) * ec, true);
     r |= h->chunk_piece.ensure(sizeof(int) * (ec / GAMD_CHUNK + 2), true);
     r |= h->chunk_mask.ensure(sizeof(unsigned) * (ec / GAMD_CHUNK + 2), true);
-    r |= h->e_frag.ensure(sizeof(float) * 4096 * (ec / GAMD_TILE + 1), false);
-    r |= h->partial.ensure(sizeof(float) * GAMD_H * (ec / GAMD_CHUNK + (size_t)h->n + 2), false);
+    r |= h->e_frag.ensure(sizeof(float) * 4096 * (size_t)h->EHT * (ec / GAMD_TILE + 1), false);
+    r |= h->partial.ensure(sizeof(float) * (size_t)h->H * (ec / GAMD_CHUNK + (size_t)h->n + 2), false);
     if (h->cfg.keep_stages) r |= h->feat_dbg.ensure(sizeof(float) * 48 * ec, true);
     if (r) return fail(-12, "edge buffer allocation failed for capacity %lld", e_cap);
     h->e_cap = e_cap;
@@ -171,15 +174,15 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
 }
 
 // ---- weight packing ---------------------------------------------------------------------------
-// W [128 out][128 in] row-major -> fragment order of gamd_common.h
-void pack128(const float* W, float* out) {
+// W [128 out][128 in] block of a row-major matrix with row stride ld -> fragment order of gamd_common.h
+void pack128(const float* W, float* out, int ld = 128) {
     for (int tp = 0; tp < 4; ++tp)
         for (int t = 0; t < 4; ++t)
             for (int q = 0; q < 4; ++q)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 4; ++j) {
                         const int n = 32 * tp + (lane & 31), k = 32 * t + 8 * q + 4 * (lane >> 5) + j;
-                        out[((((tp * 4 + t) * 4 + q) * 64 + lane) * 4) + j] = W[n * 128 + k];
+                        out[((((tp * 4 + t) * 4 + q) * 64 + lane) * 4) + j] = W[(size_t)n * ld + k];
                     }
 }
 // encoder first layer W [128][n_feat]: MFMA step s covers features (2s, 2s+1); K padded to 48
@@ -236,8 +239,10 @@ const HostTensor* find_w(gamd_handle* h, const std::string& name, std::initializ
     if (it->second.shape != std::vector<int64_t>(shape)) {
         std::string got;
         for (auto d : it->second.shape) got += std::to_string(d) + ",";
-        fail(-22, "weight '%s' has shape (%s), expected a %zu-d tensor of the 128-wide architecture",
-             name.c_str(), got.c_str(), shape.size());
+        std::string want;
+        for (auto d : shape) want += std::to_string(d) + ",";
+        fail(-22, "weight '%s' has shape (%s), expected (%s) for this configuration", name.c_str(), got.c_str(),
+             want.c_str());
         return nullptr;
     }
     return &it->second;
@@ -280,11 +285,13 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.e_frag = h->e_frag.as<float>();
     ea.e_cap = h->e_cap;
     ea.feat_dbg = h->cfg.keep_stages ? h->feat_dbg.as<float>() : nullptr;
-    r = h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_edge_encode_bf16(ea, h->n_cu, st) : launch_edge_encode(ea, h->n_cu, st);
+    r = h->wide_enc ? launch_edge_encode_wide(ea, h->EHT, h->n_cu, st)
+        : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_edge_encode_bf16(ea, h->n_cu, st) : launch_edge_encode(ea, h->n_cu, st);
     if (r) return fail(-1, "edge encode launch failed (%d)", r);
     mark("edge_encode");
 
-    const size_t nh = (size_t)h->n * GAMD_H;
+    const size_t nh = (size_t)h->n * (size_t)h->H;
+    auto node = [&](const NodeArgs& na_) { return h->wide_conv ? launch_node_wide(na_, h->HT, st) : launch_node(na_, st); };
     auto hptr = [&](int l) { return h->hbuf.as<float>() + (h->cfg.keep_stages ? (size_t)l * nh : (size_t)(l & 1) * nh); };
 
     NodeArgs no{};
@@ -305,7 +312,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     no.mode = 0;
     no.pre = h->layers[0].node;
     no.h_out = hptr(0);
-    if ((r = launch_node(no, st))) return fail(-1, "node(0) launch failed (%d)", r);
+    if ((r = node(no))) return fail(-1, "node(0) launch failed (%d)", r);
     mark("node_first");
 
     for (int l = 0; l < h->L; ++l) {
@@ -327,7 +334,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
             }
             HIP_TRY(hipEventRecord(h->tev[h->tev_used], st));
         }
-        r = h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st) : launch_conv_edge(ca, h->n_cu, st);
+        r = h->wide_conv ? launch_conv_edge_wide(ca, h->EHT, h->HT, h->n_cu, st)
+            : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st) : launch_conv_edge(ca, h->n_cu, st);
         if (r) return fail(-1, "conv edge launch failed (%d)", r);
         if (h->timing) { HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st)); h->tev_used += 2; }
         mark("conv_edge");
@@ -337,7 +345,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         if (l + 1 < h->L) no.pre = h->layers[l + 1].node;
         no.h_in = hptr(l);
         no.h_out = hptr(l + 1);
-        if ((r = launch_node(no, st))) return fail(-1, "node launch failed (%d)", r);
+        if ((r = node(no))) return fail(-1, "node launch failed (%d)", r);
         mark(no.mode == 2 ? "node_last_decode" : "node_mid");
     }
     HIP_TRY(hipMemcpyAsync(h->counters_host, h->counters.p, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
@@ -369,11 +377,23 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     HIP_TRY(hipSetDevice(cfg->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    const int H = cfg->encoding_size ? cfg->encoding_size : 128, Eh = cfg->edge_embedding_dim ? cfg->edge_embedding_dim : 128;
+    if ((H != 128 && H != 256) || (Eh != 128 && Eh != 256))
+        return fail(-22, "encoding_size and edge_embedding_dim must be 128 or 256 (got %d, %d)", H, Eh);
+    if (cfg->hidden_dim != 0 && cfg->hidden_dim != 128) return fail(-22, "hidden_dim must be 128 (got %d)", cfg->hidden_dim);
+    const bool generic = H != 128 || Eh != 128 || cfg->no_expand_edge;
+    if (generic && cfg->edge_dtype == GAMD_EDGE_BF16)
+        return fail(-22, "the bf16 edge-MLP is built for the 128-wide RBF-expanded configuration only");
     gamd_handle* h = new gamd_handle();
     h->cfg = *cfg;
     h->n = cfg->n_atoms;
     h->L = cfg->n_layers;
-    h->n_feat = 44 + (cfg->use_bond ? 1 : 0);
+    h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
+    const char* force_wide = getenv("GAMD_FORCE_WIDE");      // test hook: run the 128-wide config on wide.hip
+    const bool forced = force_wide && force_wide[0] == '1' && cfg->edge_dtype != GAMD_EDGE_BF16;
+    h->wide_enc = generic || forced;
+    h->wide_conv = H != 128 || Eh != 128 || forced;
+    h->n_feat = (cfg->no_expand_edge ? 4 : 44) + (cfg->use_bond ? 1 : 0);
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t n = (size_t)h->n;
     int r = 0;
@@ -385,12 +405,12 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->deg.ensure(sizeof(int) * n, true);
     r |= h->row_ptr.ensure(sizeof(int) * (n + 1), true);
     r |= h->na_excl.ensure(sizeof(int) * (n + 1), true);
-    const size_t nh = n * GAMD_H * sizeof(float);
+    const size_t nh = n * (size_t)H * sizeof(float), nd = n * 128 * sizeof(float);
     r |= h->hbuf.ensure(nh * (cfg->keep_stages ? (size_t)h->L + 1 : 2), true);
     r |= h->hn.ensure(nh, true);
-    r |= h->S.ensure(nh, true);
-    r |= h->D.ensure(nh, true);
-    r |= h->P.ensure(nh, true);
+    r |= h->S.ensure(nd, true);
+    r |= h->D.ensure(nd, true);
+    r |= h->P.ensure(nd, true);
     r |= h->f_norm.ensure(sizeof(float) * 3 * n, true);
     r |= h->f_den.ensure(sizeof(float) * 3 * n, true);
     r |= h->tdbg.ensure(sizeof(long long) * 16 * 8 * 1024, true);
@@ -439,17 +459,24 @@ int32_t gamd_load_weight(gamd_handle* h, const char* name, const float* data, co
 int32_t gamd_finalize_weights(gamd_handle* h) {
     if (!h) return fail(-22, "null handle");
     const int F = h->n_feat, L = h->L;
+    const int64_t H = h->H, Eh = h->Eh, HT = h->HT, EHT = h->EHT;
+    const bool expand = !h->cfg.no_expand_edge;
     BlobBuilder bb;
     struct Off { size_t w1p, w2p, w3p, w4p, b1, b3, b4, lng, lnb, wsp, wdp, wpdp, bS, bP, wpep, wphip, bphi; };
     std::vector<Off> lo(L);
     auto get = [&](const std::string& nm, std::initializer_list<int64_t> shp) { return find_w(h, nm, shp); };
     auto put_vec = [&](const HostTensor* t) { size_t o = bb.add(t->data.size()); std::copy(t->data.begin(), t->data.end(), bb.host.begin() + o); return o; };
-    auto put_packed = [&](const HostTensor* t) { size_t o = bb.add(GAMD_WFRAG_FLOATS); pack128(t->data.data(), bb.host.data() + o); return o; };
-    const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16;
-    // edge-side matrices (edge_affine, theta_edge, edge_encoder): fp32 or bf16 fragments (32 KiB, stored in the
-    // float blob as 8192 words)
-    auto put_edge = [&](const HostTensor* t) {
-        if (!bf16_edges) return put_packed(t);
+    // [128 OB][128 KB] matrix -> OB*KB packed 128x128 blocks, block (ob, kb) at index ob*KB + kb
+    auto put_blocks = [&](const HostTensor* t, int OB, int KB) {
+        size_t o = bb.add((size_t)OB * KB * GAMD_WFRAG_FLOATS);
+        for (int ob = 0; ob < OB; ++ob)
+            for (int kb = 0; kb < KB; ++kb)
+                pack128(t->data.data() + (size_t)128 * ob * 128 * KB + 128 * kb,
+                        bb.host.data() + o + (size_t)(ob * KB + kb) * GAMD_WFRAG_FLOATS, 128 * KB);
+        return o;
+    };
+    const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16;       // 128-wide only (gamd_create)
+    auto put_edge_bf16 = [&](const HostTensor* t) {
         size_t o = bb.add(GAMD_WFRAG_FLOATS / 2);
         pack128_bf16(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));
         return o;
@@ -457,57 +484,66 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
 
     for (int l = 0; l < L; ++l) {
         const std::string p = "graph_conv.conv." + std::to_string(l);
-        const HostTensor *ea0w = get(p + ".edge_affine.mlp_layer.0.weight", {128, 128}), *ea0b = get(p + ".edge_affine.mlp_layer.0.bias", {128});
+        // edge_affine = MLP(Eh, hidden_dim, hidden_layer=2): its inner width is MLP's default 128 (nn_module.py:25,95)
+        const HostTensor *ea0w = get(p + ".edge_affine.mlp_layer.0.weight", {128, Eh}), *ea0b = get(p + ".edge_affine.mlp_layer.0.bias", {128});
         const HostTensor *ea2w = get(p + ".edge_affine.mlp_layer.2.weight", {128, 128}), *ea2b = get(p + ".edge_affine.mlp_layer.2.bias", {128});
-        const HostTensor *sw = get(p + ".src_affine.weight", {128, 128}), *sb = get(p + ".src_affine.bias", {128});
-        const HostTensor *dw = get(p + ".dst_affine.weight", {128, 128}), *db = get(p + ".dst_affine.bias", {128});
+        const HostTensor *sw = get(p + ".src_affine.weight", {128, H}), *sb = get(p + ".src_affine.bias", {128});
+        const HostTensor *dw = get(p + ".dst_affine.weight", {128, H}), *db = get(p + ".dst_affine.bias", {128});
         const HostTensor *t1w = get(p + ".theta_edge.mlp_layer.1.weight", {128, 128}), *t1b = get(p + ".theta_edge.mlp_layer.1.bias", {128});
-        const HostTensor *t3w = get(p + ".theta_edge.mlp_layer.3.weight", {128, 128}), *t3b = get(p + ".theta_edge.mlp_layer.3.bias", {128});
-        const HostTensor *pdw = get(p + ".phi_dst.weight", {128, 128}), *pdb = get(p + ".phi_dst.bias", {128});
-        const HostTensor *pew = get(p + ".phi_edge.weight", {128, 128}), *peb = get(p + ".phi_edge.bias", {128});
-        const HostTensor *phw = get(p + ".phi.mlp_layer.1.weight", {128, 128}), *phb = get(p + ".phi.mlp_layer.1.bias", {128});
-        const HostTensor *ng = get("graph_conv.norm_layers." + std::to_string(l) + ".weight", {128});
-        const HostTensor *nb = get("graph_conv.norm_layers." + std::to_string(l) + ".bias", {128});
+        const HostTensor *t3w = get(p + ".theta_edge.mlp_layer.3.weight", {H, 128}), *t3b = get(p + ".theta_edge.mlp_layer.3.bias", {H});
+        const HostTensor *pdw = get(p + ".phi_dst.weight", {128, H}), *pdb = get(p + ".phi_dst.bias", {128});
+        const HostTensor *pew = get(p + ".phi_edge.weight", {128, H}), *peb = get(p + ".phi_edge.bias", {128});
+        const HostTensor *phw = get(p + ".phi.mlp_layer.1.weight", {H, 128}), *phb = get(p + ".phi.mlp_layer.1.bias", {H});
+        const HostTensor *ng = get("graph_conv.norm_layers." + std::to_string(l) + ".weight", {H});
+        const HostTensor *nb = get("graph_conv.norm_layers." + std::to_string(l) + ".bias", {H});
         if (!ea0w || !ea0b || !ea2w || !ea2b || !sw || !sb || !dw || !db || !t1w || !t1b || !t3w || !t3b || !pdw ||
             !pdb || !pew || !peb || !phw || !phb || !ng || !nb)
             return -2;
         Off& o = lo[l];
-        o.w1p = put_edge(ea0w); o.b1 = put_vec(ea0b);
-        o.w2p = put_edge(ea2w);
-        o.w3p = put_edge(t1w); o.b3 = put_vec(t1b);
-        o.w4p = put_edge(t3w); o.b4 = put_vec(t3b);
+        if (bf16_edges) {
+            o.w1p = put_edge_bf16(ea0w); o.w2p = put_edge_bf16(ea2w); o.w3p = put_edge_bf16(t1w); o.w4p = put_edge_bf16(t3w);
+        } else {
+            // one contiguous run of blocks: W1[:, kb] (EHT) | W2 | W3 | W4[ob, :] (HT) -- the order the kernels stream them
+            o.w1p = put_blocks(ea0w, 1, (int)EHT);
+            o.w2p = put_blocks(ea2w, 1, 1);
+            o.w3p = put_blocks(t1w, 1, 1);
+            o.w4p = put_blocks(t3w, (int)HT, 1);
+        }
+        o.b1 = put_vec(ea0b); o.b3 = put_vec(t1b); o.b4 = put_vec(t3b);
         o.lng = put_vec(ng); o.lnb = put_vec(nb);
-        o.wsp = put_packed(sw); o.wdp = put_packed(dw); o.wpdp = put_packed(pdw);
+        o.wsp = put_blocks(sw, 1, (int)HT); o.wdp = put_blocks(dw, 1, (int)HT); o.wpdp = put_blocks(pdw, 1, (int)HT);
         o.bS = bb.add(128);
         for (int i = 0; i < 128; ++i) bb.host[o.bS + i] = (sb->data[i] + db->data[i]) + ea2b->data[i];
         o.bP = bb.add(128);
         for (int i = 0; i < 128; ++i) bb.host[o.bP + i] = pdb->data[i] + peb->data[i];
-        o.wpep = put_packed(pew); o.wphip = put_packed(phw); o.bphi = put_vec(phb);
+        o.wpep = put_blocks(pew, 1, (int)HT); o.wphip = put_blocks(phw, (int)HT, 1); o.bphi = put_vec(phb);
     }
     const HostTensor *e0w = get("edge_encoder.mlp_layer.0.weight", {128, (int64_t)F}), *e0b = get("edge_encoder.mlp_layer.0.bias", {128});
     const HostTensor *e2w = get("edge_encoder.mlp_layer.2.weight", {128, 128}), *e2b = get("edge_encoder.mlp_layer.2.bias", {128});
-    const HostTensor *e4w = get("edge_encoder.mlp_layer.4.weight", {128, 128}), *e4b = get("edge_encoder.mlp_layer.4.bias", {128});
-    const HostTensor *elg = get("edge_layer_norm.weight", {128}), *elb = get("edge_layer_norm.bias", {128});
-    const HostTensor *cen = get("edge_expand.centers", {40});
+    const HostTensor *e4w = get("edge_encoder.mlp_layer.4.weight", {Eh, 128}), *e4b = get("edge_encoder.mlp_layer.4.bias", {Eh});
+    const HostTensor *elg = get("edge_layer_norm.weight", {Eh}), *elb = get("edge_layer_norm.bias", {Eh});
+    const HostTensor *cen = expand ? get("edge_expand.centers", {40}) : nullptr;
     const HostTensor *lm = get("length_mean", {1}), *ls = get("length_std", {1});
-    const HostTensor *d0w = get("graph_decoder.mlp_layer.0.weight", {128, 128}), *d0b = get("graph_decoder.mlp_layer.0.bias", {128});
+    const HostTensor *d0w = get("graph_decoder.mlp_layer.0.weight", {128, H}), *d0b = get("graph_decoder.mlp_layer.0.bias", {128});
     const HostTensor *d2w = get("graph_decoder.mlp_layer.2.weight", {3, 128}), *d2b = get("graph_decoder.mlp_layer.2.bias", {3});
-    if (!e0w || !e0b || !e2w || !e2b || !e4w || !e4b || !elg || !elb || !cen || !lm || !ls || !d0w || !d0b || !d2w || !d2b)
+    if (!e0w || !e0b || !e2w || !e2b || !e4w || !e4b || !elg || !elb || (expand && !cen) || !lm || !ls || !d0w || !d0b ||
+        !d2w || !d2b)
         return -2;
     const size_t o_e1 = bb.add(4 * 6 * 64 * 4);
     if (bf16_edges) pack_enc1_bf16(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
     else pack_enc1(e0w->data.data(), F, bb.host.data() + o_e1);
-    const size_t o_e2 = put_edge(e2w), o_e3 = put_edge(e4w);
+    const size_t o_e2 = bf16_edges ? put_edge_bf16(e2w) : put_blocks(e2w, 1, 1);
+    const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : put_blocks(e4w, (int)EHT, 1);
     const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(e4b), o_elg = put_vec(elg), o_elb = put_vec(elb);
-    const size_t o_cen = put_vec(cen);
-    const size_t o_d1 = put_packed(d0w), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
+    const size_t o_cen = expand ? put_vec(cen) : bb.add(64);
+    const size_t o_d1 = put_blocks(d0w, 1, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
     size_t o_emb = 0, o_nw = 0, o_nb = 0;
     if (h->cfg.kind == GAMD_KIND_LJ) {
-        const HostTensor* emb = get("node_emb", {1, 128});
+        const HostTensor* emb = get("node_emb", {1, H});
         if (!emb) return -2;
         o_emb = put_vec(emb);
     } else {
-        const HostTensor *nw = get("node_encoder.weight", {128, 1}), *nb = get("node_encoder.bias", {128});
+        const HostTensor *nw = get("node_encoder.weight", {H, 1}), *nb = get("node_encoder.bias", {H});
         if (!nw || !nb) return -2;
         o_nw = put_vec(nw); o_nb = put_vec(nb);
     }
@@ -667,13 +703,13 @@ int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t byte
     if (what == GAMD_DBG_PERM) { src = h->perm.p; avail = sizeof(int) * n; }
     else if (what == GAMD_DBG_ROWPTR) { src = h->row_ptr.p; avail = sizeof(int) * (n + 1); }
     else if (what == GAMD_DBG_COL) { src = h->col.p; avail = sizeof(int) * E; }
-    else if (what == GAMD_DBG_EFRAG) { src = h->e_frag.p; avail = sizeof(float) * 4096 * ((E + 31) / 32); }
+    else if (what == GAMD_DBG_EFRAG) { src = h->e_frag.p; avail = sizeof(float) * 4096 * (size_t)h->EHT * ((E + 31) / 32); }
     else if (what == GAMD_DBG_FEAT) {
         if (!h->cfg.keep_stages) return fail(-22, "FEAT needs keep_stages=1");
         src = h->feat_dbg.p; avail = sizeof(float) * 48 * E;
     } else if (what >= GAMD_DBG_H0 && what <= GAMD_DBG_H0 + h->L) {
         if (!h->cfg.keep_stages) return fail(-22, "H_l needs keep_stages=1");
-        src = h->hbuf.as<float>() + (size_t)(what - GAMD_DBG_H0) * n * GAMD_H; avail = sizeof(float) * n * GAMD_H;
+        src = h->hbuf.as<float>() + (size_t)(what - GAMD_DBG_H0) * n * (size_t)h->H; avail = sizeof(float) * n * (size_t)h->H;
     } else if (what == 5) { src = h->tdbg.p; avail = sizeof(long long) * 16 * 8 * (size_t)h->n_cu;
     } else return fail(-22, "unknown debug tensor %d", what);
     if (bytes < avail) return fail(-22, "host buffer too small: %zu < %zu", bytes, avail);

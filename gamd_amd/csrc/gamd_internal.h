@@ -64,6 +64,9 @@ struct EncArgs {
 };
 int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st);
 int launch_edge_encode_bf16(const EncArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
+// generic widths (wide.hip): n_feat in {4, 5, 44, 45}; w3p = eht packed blocks W3[128 ob : 128 ob + 128, :],
+// b3 / ln_g / ln_b are [128 eht]; e_frag is [tiles][eht][4][4][64][4]
+int launch_edge_encode_wide(const EncArgs& a, int eht, int n_blocks, hipStream_t st);
 
 // ---- conv layer, edge side --------------------------------------------------------------------
 struct ConvEdgeArgs {
@@ -84,6 +87,9 @@ struct ConvEdgeArgs {
 };
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
+// generic widths (wide.hip): Eh = 128 eht, H = 128 ht.  w1p points at eht + 2 + ht contiguous packed blocks
+// W1[:, kb] | W2 | W3 | W4[ob, :]; b4 is [H]; hn and partial rows are H wide, S and D stay 128 wide
+int launch_conv_edge_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
 
 // ---- node side --------------------------------------------------------------------------------
 struct NodeLayerW {            // one conv layer's node-side parameters (device pointers)
@@ -119,6 +125,9 @@ struct NodeArgs {
     float* forces;             // [n][3] denormalised fp32 (device MD loop), original order, or null
 };
 int launch_node(const NodeArgs& a, hipStream_t st);
+// generic widths (wide.hip): h / hn / partial rows and node_emb, enc_w, enc_b, ln_*, bphi are H = 128 ht wide;
+// wsp, wdp, wpdp, wpep, dec_w1p are ht K-blocks, wphip is ht output blocks; S, D, P stay 128 wide
+int launch_node_wide(const NodeArgs& a, int ht, hipStream_t st);
 
 // ---- integrator -------------------------------------------------------------------------------
 struct MdArgs {

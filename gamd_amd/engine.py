@@ -51,9 +51,12 @@ class GamdForce:
             raise _lib.GamdError("GamdForce needs a HIP device (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
         cfg = cfg or infer_config(state_dict)
-        if (cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim) != (128, 128, 128):
-            raise ValueError("the gfx950 kernels are built for the 128-wide shipped configs "
-                             f"(got enc={cfg.encoding_size} hidden={cfg.hidden_dim} edge={cfg.edge_embedding_dim})")
+        if (cfg.encoding_size not in (128, 256) or cfg.edge_embedding_dim not in (128, 256) or cfg.hidden_dim != 128
+                or cfg.n_rbf not in (0, 40)):
+            raise ValueError("the gfx950 kernels cover encoding_size / edge_embedding_dim in {128, 256}, hidden_dim 128 "
+                             "and the RBF expansion on (40 centres) or off "
+                             f"(got enc={cfg.encoding_size} hidden={cfg.hidden_dim} edge={cfg.edge_embedding_dim} "
+                             f"n_rbf={cfg.n_rbf})")
         validate_state_dict(state_dict, cfg)
         self.cfg = cfg
         self.n = int(n_atoms)
@@ -68,6 +71,8 @@ class GamdForce:
             c.box[d] = float(self.box[d])
         c.edge_capacity, c.keep_stages = int(edge_capacity), int(keep_stages)
         c.edge_dtype = {"f32": 0, "bf16": 1}[edge_dtype]
+        c.encoding_size, c.edge_embedding_dim, c.hidden_dim = cfg.encoding_size, cfg.edge_embedding_dim, cfg.hidden_dim
+        c.no_expand_edge = int(cfg.n_rbf == 0)
         self.edge_dtype = edge_dtype
         check(self._lib.gamd_create(C.byref(c), C.byref(self._h)), "gamd_create")
         self.keep_stages = keep_stages
@@ -201,20 +206,22 @@ class GamdForce:
         return np.stack([perm[dst], perm[col]])
 
     def debug_e(self) -> np.ndarray:
-        """e [E,128] de-fragmented to CSR edge order."""
+        """e [E, edge_embedding_dim] de-fragmented to CSR edge order."""
         e = self.counts()[0]
         nt = (e + 31) // 32
-        frag = self._dbg(3, (nt, 4, 4, 64, 4), np.float32)
+        nb = self.cfg.edge_embedding_dim // 128
+        frag = self._dbg(3, (nt, nb, 4, 4, 64, 4), np.float32)
         lane = np.arange(64)
         slot, half = lane & 31, lane >> 5
         pi = 16 * ((slot >> 2) & 1) + (slot & 3) + 4 * (slot >> 3)
-        out = np.zeros((nt * 32, 128), dtype=np.float32)
-        for t in range(4):
-            for q in range(4):
-                for j in range(4):
-                    feat = 32 * t + 8 * q + 4 * half + j           # per lane
-                    rows = (np.arange(nt)[:, None] * 32 + pi[None, :])
-                    out[rows, feat[None, :]] = frag[:, t, q, :, j]
+        out = np.zeros((nt * 32, 128 * nb), dtype=np.float32)
+        rows = (np.arange(nt)[:, None] * 32 + pi[None, :])
+        for b in range(nb):
+            for t in range(4):
+                for q in range(4):
+                    for j in range(4):
+                        feat = 128 * b + 32 * t + 8 * q + 4 * half + j           # per lane
+                        out[rows, feat[None, :]] = frag[:, b, t, q, :, j]
         return out[:e]
 
     def debug_feat(self, n_feat: int) -> np.ndarray:
@@ -222,8 +229,8 @@ class GamdForce:
         return self._dbg(4, (e, 48), np.float32)[:, :n_feat]
 
     def debug_h(self, layer: int) -> np.ndarray:
-        """residual stream h_layer [N,128] in ORIGINAL atom order."""
-        hs = self._dbg(16 + layer, (self.n, 128), np.float32)
+        """residual stream h_layer [N, encoding_size] in ORIGINAL atom order."""
+        hs = self._dbg(16 + layer, (self.n, self.cfg.encoding_size), np.float32)
         out = np.empty_like(hs)
         out[self.debug_perm()] = hs
         return out

@@ -37,7 +37,8 @@ class ModelConfig:
     in_feats: int = 1             # water / dynbox: node feature width
     out_feats: int = 3
     use_bond: bool = False        # water: 45th edge feature (bond flag)
-    n_rbf: int = 40               # RBFExpansion(high=1, gap=0.025) -> ceil(1/0.025) = 40
+    n_rbf: int = 40               # RBFExpansion(high=1, gap=0.025) -> ceil(1/0.025) = 40; 0 = expand_edge=False
+                                  # (WaterMDDynamicBoxNet only, nn_module.py:278,296-297,329-336)
 
     @property
     def edge_in(self) -> int:
@@ -73,7 +74,8 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     for l in range(cfg.conv_layer):
         spec[f"graph_conv.norm_layers.{l}.weight"] = (H,)
         spec[f"graph_conv.norm_layers.{l}.bias"] = (H,)
-    spec["edge_expand.centers"] = (cfg.n_rbf,)
+    if cfg.n_rbf > 0:
+        spec["edge_expand.centers"] = (cfg.n_rbf,)
     if cfg.kind != "lj":
         lin("node_encoder", H, cfg.in_feats)
     lin("edge_encoder.mlp_layer.0", D, cfg.edge_in)
@@ -131,7 +133,7 @@ def infer_config(sd: Dict[str, torch.Tensor]) -> ModelConfig:
         raise ValueError("state_dict has no graph_conv.conv.* layers")
     D, H = sd["graph_conv.conv.0.src_affine.weight"].shape
     Eh = sd["edge_layer_norm.weight"].shape[0]
-    n_rbf = sd["edge_expand.centers"].shape[0]
+    n_rbf = sd["edge_expand.centers"].shape[0] if "edge_expand.centers" in sd else 0
     edge_in = sd["edge_encoder.mlp_layer.0.weight"].shape[1]
     if "node_emb" in sd:
         kind, in_feats = "lj", 1

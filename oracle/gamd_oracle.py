@@ -150,6 +150,8 @@ def edge_features_from_dist(sd, distance: Tensor, distance_norm: Tensor) -> Tens
     nrm = distance_norm.view(-1, 1)
     unit = -distance / (nrm + 1e-8)
     d = (nrm - sd["length_mean"]) / sd["length_std"]
+    if "edge_expand.centers" not in sd:                      # expand_edge=False, nn_module.py:333-335
+        return torch.cat((unit, d), dim=1)
     radial = d - sd["edge_expand.centers"]
     rbf = torch.exp(-(1.0 / 0.025) * (radial ** 2))
     return torch.cat((unit, d, rbf), dim=1)

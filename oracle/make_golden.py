@@ -123,7 +123,7 @@ def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, l
     m = nn_module.WaterMDDynamicBoxNet(in_feats=1, encoding_size=cfg.encoding_size, out_feats=3,
                                        bond=None, hidden_dim=cfg.hidden_dim, conv_layer=cfg.conv_layer,
                                        edge_embedding_dim=cfg.edge_embedding_dim, drop_edge=False,
-                                       use_layer_norm=True, update_edge=False, expand_edge=True)
+                                       use_layer_norm=True, update_edge=False, expand_edge=cfg.n_rbf > 0)
     m.load_state_dict(sd, strict=True)
     m.eval()
     pos32 = torch.from_numpy(np.asarray(pos)).float()
@@ -141,7 +141,7 @@ def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, l
                         edge_idx=edge_idx.numpy().astype(np.int32), dist_norm=dist_norm.numpy(),
                         node_feat=feat.numpy(), out_norm=out,
                         cfg=np.array([cfg.kind, str(cfg.encoding_size), str(cfg.hidden_dim),
-                                      str(cfg.edge_embedding_dim), str(cfg.conv_layer), "0"]))
+                                      str(cfg.edge_embedding_dim), str(cfg.conv_layer), "0", str(cfg.n_rbf)]))
     print(f"{name}: N={n} E={edge_idx.shape[1]}")
 
 
@@ -179,6 +179,15 @@ def main():
     run_dynbox(nn_module, md_module, "dynbox384_dftcfg_seed5",
                ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256,
                            conv_layer=5), 5, sub, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
+    # expand_edge=False (--disable_expand_edge, water/train_network_real_large.py:363) and mixed widths
+    run_dynbox(nn_module, md_module, "dynbox384_noexpand_seed6", ModelConfig(kind="dynbox", n_rbf=0, **full), 6,
+               sub, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
+    run_dynbox(nn_module, md_module, "dynbox384_h256_e128_seed7",
+               ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=128, conv_layer=3),
+               7, sub, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
+    run_dynbox(nn_module, md_module, "dynbox384_h128_e256_noexpand_seed8",
+               ModelConfig(kind="dynbox", encoding_size=128, hidden_dim=128, edge_embedding_dim=256, conv_layer=3,
+                           n_rbf=0), 8, sub, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
 
 
 if __name__ == "__main__":

@@ -11,9 +11,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def load_golden(name):
     g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
-    kind, H, D, Eh, L, bond = [str(x) for x in g["cfg"]]
+    kind, H, D, Eh, L, bond = [str(x) for x in g["cfg"]][:6]
+    n_rbf = int(g["cfg"][6]) if len(g["cfg"]) > 6 else 40
     cfg = ModelConfig(kind=kind, encoding_size=int(H), hidden_dim=int(D), edge_embedding_dim=int(Eh),
-                      conv_layer=int(L), use_bond=bool(int(bond)))
+                      conv_layer=int(L), use_bond=bool(int(bond)), n_rbf=n_rbf)
     sd = make_state_dict(cfg, int(g["seed"]), float(g["length_mean"]), float(g["length_std"]))
     return g, cfg, sd
 

@@ -43,7 +43,8 @@ def test_version_and_error_strings(lib):
 
 def test_struct_layout_matches_header():
     from gamd_amd._lib import GamdConfig, GamdMdParams, GamdNhcParams
-    assert ctypes.sizeof(GamdConfig) == 56 and GamdConfig.edge_capacity.offset == 40 and GamdConfig.edge_dtype.offset == 52
+    assert ctypes.sizeof(GamdConfig) == 72 and GamdConfig.edge_capacity.offset == 40 and GamdConfig.edge_dtype.offset == 52
+    assert GamdConfig.encoding_size.offset == 56 and GamdConfig.no_expand_edge.offset == 68
     assert ctypes.sizeof(GamdMdParams) == 32 and GamdMdParams.seed.offset == 16
     assert ctypes.sizeof(GamdNhcParams) == 40 and GamdNhcParams.ndf.offset == 32
 

@@ -72,6 +72,34 @@ def test_compat_predict_forces_matches_reference_api():
     assert fw.dtype == np.float64 and rel_err(fw, g["forces"]) < TOL
 
 
+def test_compat_dft_predict_forces_takes_the_box_per_call():
+    """DFT-water wrapper (water/train_network_real_large.py:148-162): predict_forces(feat, pos, box_size) with the
+    shipped widths (256/256/128, 5 layers), and the model-level call pnet_model([pos], feat, [box], cutoff)."""
+    from gamd_amd.compat import ParticleNetLightningDFT
+    from types import SimpleNamespace
+    g, cfg, sd = load_golden("dynbox384_dftcfg_seed5")
+    n = g["pos"].shape[0]
+    m = ParticleNetLightningDFT(SimpleNamespace(cutoff=float(g["cutoff"])), sd, num_atoms=n).cuda().eval()
+    mean, var = SHIPPED_SCALERS["dft"]
+    m.training_mean, m.training_var = mean, var
+    feat = torch.from_numpy(g["node_feat"]).cuda()
+    shift = np.array([g["box"][0], -2 * g["box"][1], 0.0])            # un-wrapped input: np.mod happens inside
+    f = m.predict_forces(feat, g["pos"].astype(np.float64) + shift, g["box"])
+    assert f.dtype == np.float64 and f.shape == (n, 3)
+    assert rel_err(f, g["out_norm"].astype(np.float64) * np.sqrt(var) + mean) < TOL
+    out = m.pnet_model([torch.from_numpy(g["pos"])], feat, [g["box"]], float(g["cutoff"])).cpu().numpy()
+    assert rel_err(out, g["out_norm"]) < TOL
+    with pytest.raises(ValueError):
+        m.pnet_model([torch.from_numpy(g["pos"])], feat, [g["box"]], 3.0)
+    # a different box on the next call (NPT-style): matches the oracle on that box
+    box2 = g["box"] * np.float32(1.03)
+    pos2 = (g["pos"] * np.float32(1.03)).astype(np.float32)
+    f2 = m.predict_forces(feat, pos2.astype(np.float64), box2)
+    ref2 = orc.forward_dynamic_box(sd, torch.from_numpy(pos2), torch.from_numpy(g["node_feat"]), box2,
+                                   float(g["cutoff"])).numpy().astype(np.float64) * np.sqrt(var) + mean
+    assert rel_err(f2, ref2) < TOL
+
+
 @pytest.mark.parametrize("n,box,rc,flavour", [
     (300, 30.0, 7.5, "jaxmd"),           # 4 cells / axis
     (200, 14.0, 6.0, "jaxmd"),           # 2 cells / axis  (all-cells sweep)
@@ -114,6 +142,52 @@ def test_dynamic_box_flavour_matches_reference_golden():
     assert np.array_equal(edge_set(edges), edge_set(g["edge_idx"]))
     assert rel_err(out, g["out_norm"]) < TOL
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["dynbox384_dftcfg_seed5", "dynbox384_noexpand_seed6", "dynbox384_h256_e128_seed7",
+                                  "dynbox384_h128_e256_noexpand_seed8"])
+def test_wide_and_unexpanded_configs_match_reference_golden(name):
+    """The DFT-water configuration of WaterMDDynamicBoxNet (encoding 256 / edge embedding 256 / hidden 128, 5 layers,
+    water/test_script/test_nosehoover_hb.py:69-81), expand_edge=False (nn_module.py:333-335) and mixed widths:
+    the generic-width kernels (csrc/wide.hip) against outputs of the reference module."""
+    g, cfg, sd = load_golden(name)
+    n = g["pos"].shape[0]
+    eng = _engine(sd, n, g["box"], float(g["cutoff"]), nbr_flavour="torch", cfg=cfg, keep_stages=True)
+    species = g["node_feat"].reshape(-1) != 0
+    out = eng.forward(torch.from_numpy(g["pos"]), box=g["box"], species=species).cpu().numpy()
+    edges = eng.debug_edges()
+    assert np.array_equal(edge_set(edges), edge_set(g["edge_idx"]))
+    # per-stage check against the oracle (itself pinned to this golden in test_oracle_golden.py)
+    st = {}
+    ref = orc.forward_dynamic_box(sd, torch.from_numpy(g["pos"]), torch.from_numpy(g["node_feat"]), g["box"],
+                                  float(g["cutoff"]), stages=st).numpy()
+    key = lambda e: np.asarray(e[0]).astype(np.int64) * n + np.asarray(e[1]).astype(np.int64)
+    o_dev, o_ref = np.argsort(key(edges), kind="stable"), np.argsort(key(st["edge_idx"].numpy()), kind="stable")
+    assert rel_err(eng.debug_feat(cfg.edge_in)[o_dev], st["feat"].numpy()[o_ref]) < TOL
+    assert rel_err(eng.debug_e()[o_dev], st["e"].numpy()[o_ref]) < TOL
+    for l, h_ref in enumerate(st["h"]):
+        assert rel_err(eng.debug_h(l), h_ref.numpy()) < TOL, f"h_{l}"
+    assert rel_err(out, ref) < TOL
+    assert rel_err(out, g["out_norm"]) < TOL
+    eng.close()
+
+
+def test_wide_kernels_reproduce_the_128_wide_path(monkeypatch):
+    """GAMD_FORCE_WIDE=1 routes the shipped 128-wide configuration through csrc/wide.hip: same goldens, same bar."""
+    g, cfg, sd = load_golden("tip3p774_seed3")
+    box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+    posw = torch.from_numpy(np.mod(g["pos"], box).astype(np.float32))
+    species = g["node_feat"].reshape(-1) != 0
+    monkeypatch.setenv("GAMD_FORCE_WIDE", "1")
+    eng = _engine(sd, n, box, rc, bond=g["bond"], scaler=(g["scaler_mean"], g["scaler_var"]))
+    out = eng.forward(posw, species=species).cpu().numpy()
+    eng.close()
+    monkeypatch.delenv("GAMD_FORCE_WIDE")
+    assert rel_err(out, g["out_norm"]) < TOL
+    eng = _engine(sd, n, box, rc, bond=g["bond"], scaler=(g["scaler_mean"], g["scaler_var"]))
+    out0 = eng.forward(posw, species=species).cpu().numpy()
+    eng.close()
+    assert rel_err(out, out0) < TOL
 
 
 def test_isolated_atoms_and_regrow():
