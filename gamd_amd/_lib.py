@@ -21,15 +21,20 @@ class GamdConfig(C.Structure):
                 ("no_expand_edge", C.c_int32)]
 
 
+# common tail of both integrator parameter blocks (masses per species, length unit, rigid water)
+_MD_EXT = [("mass_h_amu", C.c_float), ("length_per_nm", C.c_float), ("rigid_water", C.c_int32),
+           ("r_oh", C.c_float), ("r_hh", C.c_float), ("reserved", C.c_int32)]
+
+
 class GamdNhcParams(C.Structure):
     _fields_ = [("dt_ps", C.c_float), ("mass_amu", C.c_float), ("temperature_k", C.c_float),
                 ("frequency_per_ps", C.c_float), ("chain_length", C.c_int32), ("num_mts", C.c_int32),
-                ("num_yoshidasuzuki", C.c_int32), ("reset", C.c_int32), ("ndf", C.c_double)]
+                ("num_yoshidasuzuki", C.c_int32), ("reset", C.c_int32), ("ndf", C.c_double)] + _MD_EXT
 
 
 class GamdMdParams(C.Structure):
     _fields_ = [("dt_ps", C.c_float), ("mass_amu", C.c_float), ("temperature_k", C.c_float),
-                ("gamma_per_ps", C.c_float), ("seed", C.c_uint64), ("first_step", C.c_uint64)]
+                ("gamma_per_ps", C.c_float), ("seed", C.c_uint64), ("first_step", C.c_uint64)] + _MD_EXT
 
 
 # every symbol include/gamd_hip.h declares: name -> (restype, argtypes)

@@ -250,6 +250,23 @@ const HostTensor* find_w(gamd_handle* h, const std::string& name, std::initializ
 
 struct EdgeList { const int* centre; const int* neigh; long long n; };
 
+// rigid-water block shared by both integrators; returns 0 or an error code (message set)
+int fill_rigid(const gamd_handle* h, int rigid_water, float mass_o, float mass_h, float r_oh, float r_hh, const uint8_t* species,
+               int* use_rigid, RigidWater* g) {
+    *use_rigid = 0;
+    if (!rigid_water) return 0;
+    if (h->n % 3 != 0) return fail(-22, "rigid_water needs O,H,H triples: n_atoms = %d is not a multiple of 3", h->n);
+    if (!(mass_h > 0.f) || !(mass_o > 0.f)) return fail(-22, "rigid_water needs mass_amu (O) and mass_h_amu (H)");
+    if (!(r_oh > 0.f) || !(r_hh > 0.f) || !(r_hh < 2.f * r_oh)) return fail(-22, "rigid_water needs 0 < r_hh < 2 r_oh");
+    (void)species;
+    const double rc = 0.5 * (double)r_hh, t = std::sqrt((double)r_oh * r_oh - rc * rc);
+    const double ra = t * 2.0 * mass_h / ((double)mass_o + 2.0 * mass_h);
+    g->m_o = mass_o; g->m_h = mass_h;
+    g->rc = (float)rc; g->ra = (float)ra; g->rb = (float)(t - ra);
+    *use_rigid = 1;
+    return 0;
+}
+
 int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, float* out_norm_dev,
                     float* out_denorm_dev, hipStream_t st, hipEvent_t* evs, int* n_ev, std::vector<std::string>* labels,
                     const EdgeList* el = nullptr) {
@@ -726,12 +743,18 @@ int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, co
     hipStream_t st = (hipStream_t)stream;
     MdArgs m{};
     m.n = h->n; m.x = x_dev; m.v = v_dev; m.f = f_dev;
+    if (!(p->mass_amu > 0.f)) return fail(-22, "mass_amu must be positive");
+    m.species = species_dev;
     m.inv_mass = 1.0f / p->mass_amu;
+    m.inv_mass_h = p->mass_h_amu > 0.f ? 1.0f / p->mass_h_amu : 0.f;
+    m.len = p->length_per_nm > 0.f ? p->length_per_nm : 10.0f;
     m.dt = p->dt_ps;
     const double kB = 0.00831446261815324;                       // kJ/mol/K
     const double a = std::exp(-(double)p->gamma_per_ps * p->dt_ps);
     m.a = (float)a;
-    m.b_sigma = (float)(std::sqrt(1.0 - a * a) * 10.0 * std::sqrt(kB * p->temperature_k / p->mass_amu));
+    m.b_len_kT = (float)(std::sqrt(1.0 - a * a) * (double)m.len * std::sqrt(kB * p->temperature_k));
+    if ((r = fill_rigid(h, p->rigid_water, p->mass_amu, p->mass_h_amu, p->r_oh, p->r_hh, species_dev, &m.use_rigid, &m.rigid)))
+        return r;
     for (int d = 0; d < 3; ++d) m.box[d] = box[d];
     m.seed = p->seed;
     for (int64_t s = 0; s < n_steps; ++s) {
@@ -759,7 +782,13 @@ int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev
     hipStream_t st = (hipStream_t)stream;
     NhcArgs a{};
     a.n = h->n; a.x = x_dev; a.v = v_dev; a.f = f_dev;
-    a.mass = p->mass_amu; a.dt = p->dt_ps;
+    if (!(p->mass_amu > 0.f)) return fail(-22, "mass_amu must be positive");
+    a.species = species_dev;
+    a.mass = p->mass_amu; a.mass_h = p->mass_h_amu > 0.f ? p->mass_h_amu : 0.f;
+    a.len = p->length_per_nm > 0.f ? p->length_per_nm : 10.0f;
+    a.dt = p->dt_ps;
+    if ((r = fill_rigid(h, p->rigid_water, p->mass_amu, p->mass_h_amu, p->r_oh, p->r_hh, species_dev, &a.use_rigid, &a.rigid)))
+        return r;
     for (int d = 0; d < 3; ++d) a.box[d] = box[d];
     a.kT = 0.00831446261815324 * (double)p->temperature_k;
     a.freq = p->frequency_per_ps;

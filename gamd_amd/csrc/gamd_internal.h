@@ -130,14 +130,21 @@ int launch_node(const NodeArgs& a, hipStream_t st);
 int launch_node_wide(const NodeArgs& a, int ht, hipStream_t st);
 
 // ---- integrator -------------------------------------------------------------------------------
+// rigid 3-site water (atoms O,H,H): masses and the SETTLE canonical triangle (Miyamoto & Kollman 1992):
+// rc = d_HH/2, ra = distance O - centre of mass, rb = distance centre of mass - HH midpoint
+struct RigidWater { float m_o, m_h, ra, rb, rc; };
 struct MdArgs {
     int n;
-    float* x; float* v;        // [n][3] Angstrom, Angstrom/ps
+    float* x; float* v;        // [n][3] length unit L (Angstrom | bohr), L/ps
     const float* f;            // [n][3] kJ/mol/nm
-    float inv_mass;            // 1/amu
+    const uint8_t* species;    // [n] or null: species-0 atoms use inv_mass_h when it is > 0
+    float inv_mass, inv_mass_h;// 1/amu
+    float len;                 // L per nm (10 for Angstrom)
     float dt;                  // ps
-    float a, b_sigma;          // exp(-gamma dt), sqrt(1-a^2)*sqrt(kT/m) [Angstrom/ps]
+    float a, b_len_kT;         // exp(-gamma dt), sqrt(1-a^2)*len*sqrt(kT): O-step sigma = b_len_kT*sqrt(1/m)
     float box[3];
+    int use_rigid;             // 1: O,H,H triples are rigid (one thread per molecule)
+    RigidWater rigid;
     unsigned long long seed; unsigned long long step;
 };
 int launch_baoab_first(const MdArgs& a, hipStream_t st);    // B A O A  (hack_integrator.py:141-165)
@@ -149,9 +156,13 @@ struct NhcArgs {
     int n;
     float* x; float* v;        // [n][3] Angstrom, Angstrom/ps
     const float* f;            // [n][3] kJ/mol/nm
-    float mass;                // amu
+    const uint8_t* species;    // [n] or null
+    float mass, mass_h;        // amu; species-0 atoms use mass_h when it is > 0
+    float len;                 // length units per nm
     float dt;                  // ps
     float box[3];
+    int use_rigid;
+    RigidWater rigid;
     double kT, freq, ndf;      // kJ/mol, 1/ps, degrees of freedom
     int M, n_c, n_ys;          // chain length, multi-time-step count, Yoshida-Suzuki order
     double w[5];

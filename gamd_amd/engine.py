@@ -238,12 +238,19 @@ class GamdForce:
     # -- on-device MD (split BAOAB of hack_integrator.py) ----------------------------------------
     def md_run(self, x: torch.Tensor, v: torch.Tensor, f: torch.Tensor, n_steps: int, dt_ps=0.002,
                mass_amu=39.9, temperature_k=100.0, gamma_per_ps=25.0, seed=0, first_step=0,
-               box=None, species=None, sync: bool = True) -> None:
-        """Advance (x, v, f) in place by n_steps; f holds denormalised forces (kJ/mol/nm) at x."""
+               box=None, species=None, sync: bool = True, mass_h_amu=0.0, length_per_nm=0.0,
+               rigid_water: bool = False, r_oh=0.0, r_hh=0.0) -> None:
+        """Advance (x, v, f) in place by n_steps; f holds denormalised forces (kJ/mol/nm) at x.
+
+        Water: ``mass_amu`` is the oxygen mass and ``mass_h_amu`` the mass of the species-0 atoms;
+        ``rigid_water`` holds every O,H,H triple rigid at (r_oh, r_hh) like OpenMM's constrained water
+        (positions must then be whole molecules; they are kept whole).  ``length_per_nm`` is the length
+        unit of x/v/box (10 = Angstrom, the default; 18.8972613 = bohr for the DFT model)."""
         for t in (x, v, f):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n, 3)
         s = self._dev_species(species)
-        p = GamdMdParams(dt_ps, mass_amu, temperature_k, gamma_per_ps, seed, first_step)
+        p = GamdMdParams(dt_ps, mass_amu, temperature_k, gamma_per_ps, seed, first_step, mass_h_amu, length_per_nm,
+                         int(rigid_water), r_oh, r_hh, 0)
         st = self._lib.gamd_md_run(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()),
                                    C.c_void_p(f.data_ptr()), C.c_void_p(s.data_ptr()) if s is not None else None,
                                    self._box_arg(box), C.byref(p), int(n_steps), self._stream())
@@ -253,9 +260,12 @@ class GamdForce:
 
     def md_run_nhc(self, x: torch.Tensor, v: torch.Tensor, f: torch.Tensor, n_steps: int, chain_state: torch.Tensor = None,
                    dt_ps=0.002, mass_amu=39.9, temperature_k=100.0, frequency_per_ps=25.0, chain_length=10, num_mts=5,
-                   num_yoshidasuzuki=5, ndf=None, box=None, species=None, sync: bool = True) -> torch.Tensor:
+                   num_yoshidasuzuki=5, ndf=None, box=None, species=None, sync: bool = True, mass_h_amu=0.0,
+                   length_per_nm=0.0, rigid_water: bool = False, r_oh=0.0, r_hh=0.0) -> torch.Tensor:
         """Split Nose-Hoover-chain steps (hack_integrator.py:182-493).  Returns the chain state tensor
-        (float64 [3*chain_length+2] on the device); pass it back in to continue a trajectory."""
+        (float64 [3*chain_length+2] on the device); pass it back in to continue a trajectory.
+        ``ndf`` defaults to 3N, or 3N - N (three constraints per molecule) with ``rigid_water``
+        (hack_integrator.py:226-235: particles*3 - constraints [- 3 with a CMMotionRemover])."""
         for t in (x, v, f):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n, 3)
         reset = chain_state is None
@@ -264,7 +274,8 @@ class GamdForce:
         assert chain_state.dtype == torch.float64 and chain_state.numel() == 3 * chain_length + 2
         s = self._dev_species(species)
         p = GamdNhcParams(dt_ps, mass_amu, temperature_k, frequency_per_ps, chain_length, num_mts, num_yoshidasuzuki,
-                          int(reset), float(3 * self.n if ndf is None else ndf))
+                          int(reset), float((2 * self.n if rigid_water else 3 * self.n) if ndf is None else ndf),
+                          mass_h_amu, length_per_nm, int(rigid_water), r_oh, r_hh, 0)
         st = self._lib.gamd_md_run_nhc(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()),
                                        C.c_void_p(f.data_ptr()), C.c_void_p(s.data_ptr()) if s is not None else None,
                                        self._box_arg(box), C.byref(p), C.c_void_p(chain_state.data_ptr()), int(n_steps),

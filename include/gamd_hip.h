@@ -142,6 +142,15 @@ typedef struct gamd_md_params {
     float gamma_per_ps;      /* 25 */
     uint64_t seed;
     uint64_t first_step;     /* RNG counter of the first step */
+    /* zero-initialised = the LJ behaviour (one mass, Angstrom, no constraints) */
+    float mass_h_amu;        /* > 0 and species given: mass of the species-0 atoms (H, 1.008); mass_amu is then the O mass */
+    float length_per_nm;     /* length unit of x, v, box per nm: 0 or 10 = Angstrom; 18.8972613 = bohr (DFT model:
+                                positions in bohr, water/test_script/test_nosehoover_hb.py:106-109) */
+    int32_t rigid_water;     /* 1 = atoms are O,H,H triples held rigid, as OpenMM does for the constrained water systems
+                                of the water drivers at every addConstrainPositions / addConstrainVelocities of
+                                hack_integrator.py:145-164,178,277-280,427-428 (SETTLE + analytic velocity constraint) */
+    float r_oh, r_hh;        /* constraint lengths in the length unit (TIP3P: 0.9572, 1.5139 A) */
+    int32_t reserved;
 } gamd_md_params;
 int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
                     const float* box, const gamd_md_params* p, int64_t n_steps, void* stream);
@@ -162,7 +171,16 @@ typedef struct gamd_nhc_params {
     int32_t num_mts;          /* 5 */
     int32_t num_yoshidasuzuki;/* 1, 3 or 5 */
     int32_t reset;
-    double ndf;               /* degrees of freedom (3N for the unconstrained LJ system) */
+    double ndf;               /* degrees of freedom (3N for the unconstrained LJ system; 6 per rigid water) */
+    /* zero-initialised = the LJ behaviour (one mass, Angstrom, no constraints) */
+    float mass_h_amu;        /* > 0 and species given: mass of the species-0 atoms (H, 1.008); mass_amu is then the O mass */
+    float length_per_nm;     /* length unit of x, v, box per nm: 0 or 10 = Angstrom; 18.8972613 = bohr (DFT model:
+                                positions in bohr, water/test_script/test_nosehoover_hb.py:106-109) */
+    int32_t rigid_water;     /* 1 = atoms are O,H,H triples held rigid, as OpenMM does for the constrained water systems
+                                of the water drivers at every addConstrainPositions / addConstrainVelocities of
+                                hack_integrator.py:145-164,178,277-280,427-428 (SETTLE + analytic velocity constraint) */
+    float r_oh, r_hh;        /* constraint lengths in the length unit (TIP3P: 0.9572, 1.5139 A) */
+    int32_t reserved;
 } gamd_nhc_params;
 int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
                         const float* box, const gamd_nhc_params* p, double* chain_state_dev, int64_t n_steps, void* stream);

@@ -326,3 +326,107 @@ def nhc_second_half(st, v, f, mass, dt, kT, freq, ndf):
     v = v + 0.5 * dt * f * 10.0 / mass
     ke2 = float(np.sum(mass * (0.1 * v) ** 2))
     return v * nhc_propagate(st, ke2, dt, kT, freq, ndf)
+
+
+# --------------------------------------------------------------------------
+# rigid water: the water drivers build their systems with rigid TIP3P/TIP4P-Ew molecules and
+# the hacked integrators call addConstrainPositions / addConstrainVelocities (hack_integrator.py:145-164,178,
+# 277-280,427-428).  OpenMM (third-party, absent here) solves those constraints with SETTLE for 3-site water;
+# the constrained update is the unique solution of the SHAKE / RATTLE equations (displacements along the bonds
+# of the reference geometry, weighted by 1/m), so the oracle iterates those equations to convergence in float64.
+# --------------------------------------------------------------------------
+def water_constraints(n_atoms, r_oh, r_hh):
+    """O,H,H triples (water/train_utils.py:25-26 order): bonds O-H1, O-H2, H1-H2 and their lengths."""
+    o = np.arange(0, n_atoms, 3)
+    pairs = np.concatenate([np.stack([o, o + 1], 1), np.stack([o, o + 2], 1), np.stack([o + 1, o + 2], 1)])
+    lengths = np.concatenate([np.full(len(o), r_oh), np.full(len(o), r_oh), np.full(len(o), r_hh)])
+    return pairs, lengths
+
+
+def shake_positions(x_ref, x_new, inv_m, pairs, lengths, tol=1e-13, max_iter=2000):
+    """ConstrainPositions: move x_new along the bonds of the reference geometry x_ref (which satisfies the
+    constraints) until |x_i - x_j| = d for every pair."""
+    x = np.array(x_new, dtype=np.float64)
+    x_ref = np.asarray(x_ref, dtype=np.float64)
+    i, j = pairs[:, 0], pairs[:, 1]
+    r_ref = x_ref[i] - x_ref[j]
+    wi, wj = inv_m[i].reshape(-1, 1), inv_m[j].reshape(-1, 1)
+    n_mol_pairs = len(pairs) // 3
+    for _ in range(max_iter):
+        worst = 0.0
+        for k in range(3):                      # the three bond families touch disjoint atom pairs: Gauss-Seidel over families
+            sl = slice(k * n_mol_pairs, (k + 1) * n_mol_pairs)
+            r = x[i[sl]] - x[j[sl]]
+            diff = lengths[sl] ** 2 - np.sum(r * r, axis=1)
+            worst = max(worst, float(np.max(np.abs(diff) / lengths[sl] ** 2)))
+            g = diff / (2.0 * np.sum(r * r_ref[sl], axis=1) * (wi[sl, 0] + wj[sl, 0]))
+            x[i[sl]] += (g * wi[sl, 0])[:, None] * r_ref[sl]
+            x[j[sl]] -= (g * wj[sl, 0])[:, None] * r_ref[sl]
+        if worst < tol:
+            break
+    return x
+
+
+def rattle_velocities(x, v, inv_m, pairs, tol=1e-14, max_iter=2000):
+    """ConstrainVelocities: remove the relative velocity along every constrained bond."""
+    v = np.array(v, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    i, j = pairs[:, 0], pairs[:, 1]
+    r = x[i] - x[j]
+    r2 = np.sum(r * r, axis=1)
+    wi, wj = inv_m[i], inv_m[j]
+    n_mol_pairs = len(pairs) // 3
+    for _ in range(max_iter):
+        worst = 0.0
+        for k in range(3):
+            sl = slice(k * n_mol_pairs, (k + 1) * n_mol_pairs)
+            rv = np.sum(r[sl] * (v[i[sl]] - v[j[sl]]), axis=1)
+            worst = max(worst, float(np.max(np.abs(rv))))
+            g = -rv / (r2[sl] * (wi[sl] + wj[sl]))
+            v[i[sl]] += (g * wi[sl])[:, None] * r[sl]
+            v[j[sl]] -= (g * wj[sl])[:, None] * r[sl]
+        if worst < tol:
+            break
+    return v
+
+
+def baoab_first_half_rigid(x, v, f_last, inv_m, dt, a, b_sigma, noise, pairs, lengths, acc_unit=10.0):
+    """HackLangevinIntegrator with constraints, hack_integrator.py:141-165, line by line.
+    b_sigma: per-atom b*sqrt(kT/m) in the length unit; acc_unit: length units per nm (force is kJ/mol/nm)."""
+    w = inv_m.reshape(-1)
+    v = v + (0.5 * dt) * acc_unit * f_last * inv_m                      # :145
+    v = rattle_velocities(x, v, w, pairs)                                # :146
+    for stage in range(2):
+        x1 = x + (0.5 * dt) * v                                          # :149 / :160
+        xc = shake_positions(x, x1, w, pairs, lengths)                   # :150-151 / :161-162
+        v = v + (xc - x1) / (0.5 * dt)                                   # :152 / :163
+        x = xc
+        v = rattle_velocities(x, v, w, pairs)                            # :153 / :164
+        if stage == 0:
+            v = a * v + b_sigma * noise                                  # :157
+            v = rattle_velocities(x, v, w, pairs)                        # :158
+    return x, v
+
+
+def baoab_second_half_rigid(x, v, f, inv_m, dt, pairs, acc_unit=10.0):
+    """HackHalfVelocityIntegrator, hack_integrator.py:177-178."""
+    return rattle_velocities(x, v + (0.5 * dt) * acc_unit * f * inv_m, inv_m.reshape(-1), pairs)
+
+
+def nhc_first_half_rigid(st, x, v, f_last, mass, dt, kT, freq, ndf, pairs, lengths, acc_unit=10.0):
+    """HackNoseHooverIntegrator with constraints, hack_integrator.py:274-280: propagateNHC, v kick, x += dt v,
+    ConstrainPositions, v += (x - x1)/dt (no ConstrainVelocities in this half)."""
+    ke2 = float(np.sum(mass * (v / acc_unit) ** 2))
+    v = v * nhc_propagate(st, ke2, dt, kT, freq, ndf)
+    v = v + 0.5 * dt * f_last * acc_unit / mass
+    x1 = x + dt * v
+    xc = shake_positions(x, x1, (1.0 / mass).reshape(-1), pairs, lengths)
+    return xc, v + (xc - x1) / dt
+
+
+def nhc_second_half_rigid(st, x, v, f, mass, dt, kT, freq, ndf, pairs, acc_unit=10.0):
+    """HackHalfNoseHooverIntegrator with constraints, hack_integrator.py:427-430."""
+    v = v + 0.5 * dt * f * acc_unit / mass
+    v = rattle_velocities(x, v, (1.0 / mass).reshape(-1), pairs)
+    ke2 = float(np.sum(mass * (v / acc_unit) ** 2))
+    return v * nhc_propagate(st, ke2, dt, kT, freq, ndf)

@@ -101,3 +101,157 @@ def test_nose_hoover_chain_matches_oracle():
     eng.md_run_nhc(x2, v2, f2, 2, chain_state=ch, dt_ps=dt, mass_amu=m, temperature_k=T, frequency_per_ps=freq, chain_length=M)
     assert np.array_equal(x2.cpu().numpy(), x.cpu().numpy()) and np.array_equal(v2.cpu().numpy(), v.cpu().numpy())
     eng.close()
+
+
+# ---- rigid water (SETTLE) and per-species masses ---------------------------------------------------
+def _water_setup(n_mol=64, seed=5):
+    from gamd_amd.engine import GamdForce
+    from gamd_amd import workloads as wl
+    g, cfg, sd = load_golden("tip3p774_seed3")               # water weights with the bond feature
+    pos, box, species, bonds = wl.water_box(n_mol, seed=seed, jitter=0.0, wrap=False)
+    n = 3 * n_mol
+    eng = GamdForce(sd, n, box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS["tip3p"])
+    mass = np.where(species == 1, wl.MASS_O, wl.MASS_H).astype(np.float64).reshape(-1, 1)
+    pairs, lengths = orc.water_constraints(n, wl.TIP3P_R_OH, wl.TIP3P_R_HH)
+    rng = np.random.default_rng(seed + 1)
+    v0 = rng.normal(0, 1.0, (n, 3)) * 10.0 * np.sqrt(wl.KB * 300.0 / mass)
+    v0 = orc.rattle_velocities(pos, v0, (1.0 / mass).reshape(-1), pairs)       # start on the constraint manifold
+    return eng, sd, pos, box, species, bonds, mass, pairs, lengths, v0
+
+
+def _oracle_water_forces(sd, x, box, species, bonds):
+    mean, var = SHIPPED_SCALERS["tip3p"]
+    feat = torch.from_numpy(species.astype(np.float32)).view(-1, 1)
+    return orc.predict_forces(sd, x, box, 4.2, var=var, mean=mean, feat=feat, bond=bonds)
+
+
+def _bond_errors(x, v, pairs, lengths):
+    r = x[pairs[:, 0]] - x[pairs[:, 1]]
+    d = np.linalg.norm(r, axis=1)
+    rv = np.sum(r * (v[pairs[:, 0]] - v[pairs[:, 1]]), axis=1) / d
+    return np.abs(d / lengths - 1.0).max(), np.abs(rv).max()
+
+
+def test_rigid_water_langevin_matches_shake_rattle_oracle():
+    """The water drivers integrate rigid molecules (OpenMM constraints at hack_integrator.py:145-164,178).
+    Device: SETTLE + analytic velocity constraint, one molecule per thread; oracle: SHAKE/RATTLE iterated to
+    convergence in f64 (the constrained update is unique).  The device noise of each step is recovered from an
+    unconstrained run with the same (seed, step) so the stochastic step is compared too."""
+    from gamd_amd import workloads as wl
+    eng, sd, pos, box, species, bonds, mass, pairs, lengths, v0 = _water_setup()
+    n = pos.shape[0]
+    dt, gamma, T, seed = 0.002, 25.0, 300.0, 17
+    a = np.exp(-gamma * dt)
+    bs = np.sqrt(1.0 - a * a) * 10.0 * np.sqrt(wl.KB * T / mass)
+    kw = dict(dt_ps=dt, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, temperature_k=T, gamma_per_ps=gamma, seed=seed,
+              species=species)
+
+    def device_noise(step):
+        x = torch.from_numpy(pos).float().cuda()
+        v = torch.zeros(n, 3, device="cuda")
+        f = torch.zeros(n, 3, device="cuda")
+        eng.md_run(x, v, f, 1, first_step=step, **kw)                  # v = bs*xi + (dt/2)(10/m) f_new
+        return (v.cpu().double().numpy() - 0.5 * dt * 10.0 / mass * f.cpu().double().numpy()) / bs
+
+    x = torch.from_numpy(pos).float().cuda()
+    v = torch.from_numpy(v0).float().cuda()
+    f = eng.forward(x, species=species, denormalize=True).clone()
+    xr, vr, fr = x.cpu().double().numpy(), v.cpu().double().numpy(), f.cpu().double().numpy()
+    steps = 2
+    eng.md_run(x, v, f, steps, rigid_water=True, r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH, **kw)
+    for s in range(steps):
+        xr, vr = orc.baoab_first_half_rigid(xr, vr, fr, 1.0 / mass, dt, a, bs, device_noise(s), pairs, lengths)
+        fr = _oracle_water_forces(sd, xr, box, species, bonds)
+        vr = orc.baoab_second_half_rigid(xr, vr, fr, 1.0 / mass, dt, pairs)
+    xd, vd = x.cpu().double().numpy(), v.cpu().double().numpy()
+    # device keeps molecules whole but may translate them by a lattice vector
+    shift = np.round((xd - xr) / box) * box
+    assert np.abs(shift.reshape(-1, 3, 3) - shift.reshape(-1, 3, 3)[:, :1]).max() == 0.0
+    assert np.abs(xd - shift - xr).max() < 2e-5                      # Angstrom (fp32 ulp at 12 A is 1e-6)
+    assert rel_err(vd, vr) < 2e-4
+    assert rel_err(f.cpu().numpy(), fr) < 1e-4
+    eng.close()
+
+
+def test_rigid_water_stays_rigid_over_many_steps():
+    from gamd_amd import workloads as wl
+    eng, sd, pos, box, species, bonds, mass, pairs, lengths, v0 = _water_setup(n_mol=125, seed=9)
+    x = torch.from_numpy(pos).float().cuda()
+    v = torch.from_numpy(v0).float().cuda()
+    f = eng.forward(x, species=species, denormalize=True).clone()
+    eng.md_run(x, v, f, 200, dt_ps=0.002, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, temperature_k=300.0,
+               gamma_per_ps=25.0, seed=3, species=species, rigid_water=True, r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH)
+    xd, vd = x.cpu().double().numpy(), v.cpu().double().numpy()
+    assert np.isfinite(xd).all() and np.isfinite(vd).all()
+    d_err, rv = _bond_errors(xd, vd, pairs, lengths)
+    assert d_err < 2e-5                                               # no drift: SETTLE re-solves from the target lengths
+    assert rv < 2e-3 * np.abs(vd).max()
+    o = xd[0::3]
+    assert (o >= 0).all() and (o < box).all()                         # molecules are wrapped by their oxygen, kept whole
+    assert np.abs(xd[1::3] - o).max() < 1.0 and np.abs(xd[2::3] - o).max() < 1.0
+    eng.close()
+
+
+def test_rigid_water_nose_hoover_matches_oracle():
+    """HackNoseHooverIntegrator / HackHalfNoseHooverIntegrator with constraints (hack_integrator.py:274-280,
+    427-430), ndf = 3N - N constraints (:226-235)."""
+    from gamd_amd import workloads as wl
+    eng, sd, pos, box, species, bonds, mass, pairs, lengths, v0 = _water_setup()
+    n = pos.shape[0]
+    dt, freq, T, M = 0.002, 25.0, 300.0, 10
+    x = torch.from_numpy(pos).float().cuda()
+    v = torch.from_numpy(v0).float().cuda()
+    f = eng.forward(x, species=species, denormalize=True).clone()
+    xr, vr, fr = x.cpu().double().numpy(), v.cpu().double().numpy(), f.cpu().double().numpy()
+    steps = 3
+    chain = eng.md_run_nhc(x, v, f, steps, dt_ps=dt, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, temperature_k=T,
+                           frequency_per_ps=freq, chain_length=M, species=species, rigid_water=True,
+                           r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH)
+    st = orc.nhc_init(M, freq)
+    kT, ndf = wl.KB * T, 2.0 * n
+    for _ in range(steps):
+        xr, vr = orc.nhc_first_half_rigid(st, xr, vr, fr, mass, dt, kT, freq, ndf, pairs, lengths)
+        fr = _oracle_water_forces(sd, xr, box, species, bonds)
+        vr = orc.nhc_second_half_rigid(st, xr, vr, fr, mass, dt, kT, freq, ndf, pairs)
+    xd, vd = x.cpu().double().numpy(), v.cpu().double().numpy()
+    shift = np.round((xd - xr) / box) * box
+    assert np.abs(xd - shift - xr).max() < 2e-5
+    assert rel_err(vd, vr) < 2e-4
+    c = chain.cpu().numpy()
+    assert rel_err(c[M:2 * M], st["vxi"]) < 1e-3 and rel_err(c[:M], st["xi"]) < 1e-3
+    eng.close()
+
+
+def test_species_masses_and_bohr_units_with_the_dft_model():
+    """DFT-water rollouts (water/test_script/test_nosehoover_hb.py:106-123) hand the network positions in bohr and
+    convert its output with 2625.5/0.0529177 to kJ/mol/nm: on device that is length_per_nm = bohr per nm, the
+    conversion folded into the scaler, and O/H masses by species.  T = 0, unconstrained, against the oracle."""
+    from gamd_amd.engine import GamdForce
+    from gamd_amd import workloads as wl
+    from gamd_amd.compat import HARTREE_PER_BOHR_TO_KJ_PER_MOL_NM as CONV
+    g, cfg, sd = load_golden("dynbox384_dftcfg_seed5")
+    n, box, rc = g["pos"].shape[0], g["box"], float(g["cutoff"])
+    mean, var = SHIPPED_SCALERS["dft"]
+    eng = GamdForce(sd, n, box, rc, nbr_flavour="torch", cfg=cfg, scaler=(mean * CONV, var * CONV ** 2))
+    species = g["node_feat"].reshape(-1) != 0
+    mass = np.where(species, wl.MASS_O, wl.MASS_H).astype(np.float64).reshape(-1, 1)
+    x = torch.from_numpy(g["pos"]).float().cuda()
+    v = torch.from_numpy(np.random.default_rng(2).normal(0, 8.0, (n, 3))).float().cuda()
+    f = eng.forward(x, box=box, species=species, denormalize=True).clone()
+    xr, vr, fr = x.cpu().double().numpy(), v.cpu().double().numpy(), f.cpu().double().numpy()
+    dt, gamma, L = 0.0005, 25.0, wl.BOHR_PER_NM
+    steps = 2
+    eng.md_run(x, v, f, steps, dt_ps=dt, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, temperature_k=0.0, gamma_per_ps=gamma,
+               species=species, box=box, length_per_nm=L)
+    a = np.exp(-gamma * dt)
+    feat = torch.from_numpy(g["node_feat"])
+    for _ in range(steps):
+        xr, vr = orc.baoab_first_half(xr, vr, fr, L / mass, dt, a, 0.0, 0.0)
+        xr = np.mod(xr, box.astype(np.float64))
+        out = orc.forward_dynamic_box(sd, torch.from_numpy(xr).float(), feat, box, rc).numpy().astype(np.float64)
+        fr = (out * np.sqrt(var) + mean) * CONV
+        vr = orc.baoab_second_half(vr, fr, L / mass, dt)
+    assert rel_err(x.cpu().numpy(), xr) < 1e-5
+    assert rel_err(v.cpu().numpy(), vr) < 1e-4
+    assert rel_err(f.cpu().numpy(), fr) < 1e-4
+    eng.close()
