@@ -73,9 +73,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "dft"],
                     help="c2 (default, the headline metric): 10k-atom LJ fp32; c3: 4 170-atom TIP3P fp32; "
-                         "c5: 6 000-network-atom TIP4P-Ew-sized box, bf16 edge-MLP")
+                         "c5: 6 000-network-atom TIP4P-Ew-sized box, bf16 edge-MLP; dft: the 774-atom DFT-water "
+                         "configuration (256/256/128 x 5 layers, bohr, cutoff 9.5)")
     args = ap.parse_args()
 
     # RCCL ("nccl") over xGMI in production; GAMD_BENCH_BACKEND=gloo + GAMD_BENCH_SHARE_GPU=1 let the N>1 control
@@ -92,7 +93,27 @@ def main():
     ddev = f"cuda:{dev}" if (ctx.distributed and backend == "nccl") else "cpu"
 
     species, mass, dtype_name = None, 39.9, "f32"
-    if args.workload == "c2":
+    md_extra, flop_per_edge, kernel_name = {}, FLOP_PER_EDGE_CONV, "k_conv_edge"
+    if args.workload == "dft":
+        # water/test_script/test_nosehoover_hb.py:64-113: 258 molecules, (20 A)^3 box and positions in bohr, cutoff 9.5
+        from gamd_amd import workloads as wk
+        from gamd_amd.compat import HARTREE_PER_BOHR_TO_KJ_PER_MOL_NM as CONV
+        bohr = wk.BOHR_PER_NM / 10.0
+        pos, box, species, bonds = wk.water_box(258, seed=ens.box_seed(4567, ctx), jitter=0.0, wrap=False)
+        pos, box = pos * bohr, box * bohr
+        cfg = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
+        sd = make_state_dict(cfg, 5, 3.1 * bohr, 1.2 * bohr)
+        mean, var = SHIPPED_SCALERS["dft"]
+        eng = GamdForce(sd, pos.shape[0], box, 9.5, nbr_flavour="torch", cfg=cfg, device=dev,
+                        scaler=(mean * CONV, var * CONV ** 2))        # hartree/bohr -> kJ/mol/nm folded into the scaler
+        n_atoms, mass = pos.shape[0], wk.MASS_O
+        md_extra = dict(mass_h_amu=wk.MASS_H, length_per_nm=wk.BOHR_PER_NM, rigid_water=True,
+                        r_oh=wk.TIP3P_R_OH * bohr, r_hh=wk.TIP3P_R_HH * bohr)
+        flop_per_edge, kernel_name = 2 * 128 * 128 * (2 + 2 + 2), "k_conv_edge_wide<2,2>"
+        wl = ("DFT-water configuration: 258 rigid molecules = 774 atoms, positions/box in bohr (L = 37.8), cutoff 9.5, "
+              "WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, fp32, random-init weights (seed 5), SETTLE on "
+              "device, 1 box per GPU")
+    elif args.workload == "c2":
         pos, box = lj_box(N_ATOMS, seed=ens.box_seed(1234, ctx))
         sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
         eng = GamdForce(sd, N_ATOMS, box, CUTOFF, scaler=SHIPPED_SCALERS["lj"], device=dev)
@@ -102,21 +123,25 @@ def main():
     else:
         from gamd_amd.workloads import water_box
         nmol, dens, scal, seed0 = (1390, 258.0, "tip3p", 2345) if args.workload == "c3" else (2000, 251.0, "tip4p", 3456)
-        pos, box, species, bonds = water_box(nmol, mol_per_20A3=dens, seed=ens.box_seed(seed0, ctx))
+        from gamd_amd import workloads as wk
+        pos, box, species, bonds = water_box(nmol, mol_per_20A3=dens, seed=ens.box_seed(seed0, ctx), jitter=0.0, wrap=False)
         sd = make_state_dict(ModelConfig(kind="water", use_bond=True), 3, 2.9, 1.1)
         dtype_name = "bf16" if args.workload == "c5" else "f32"
         eng = GamdForce(sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS[scal], device=dev,
                         edge_dtype=dtype_name)
-        n_atoms, mass = pos.shape[0], 6.0      # unconstrained integration of the network atoms (no SETTLE on device)
-        wl = (f"{args.workload.upper()}: {nmol} rigid-geometry water molecules = {n_atoms} network atoms, cutoff 4.2 A, "
+        n_atoms, mass = pos.shape[0], wk.MASS_O
+        md_extra = dict(mass_h_amu=wk.MASS_H, rigid_water=True, r_oh=wk.TIP3P_R_OH, r_hh=wk.TIP3P_R_HH)
+        wl = (f"{args.workload.upper()}: {nmol} rigid water molecules (SETTLE on device) = {n_atoms} network atoms, cutoff 4.2 A, "
               f"bond feature, {'bf16 edge-MLP operands / fp32 accumulate' if dtype_name == 'bf16' else 'fp32'}, "
               "random-init weights (seed 3), 1 box per GPU")
     x = torch.from_numpy(pos).float().cuda(dev)
     v = torch.from_numpy(maxwell_boltzmann(n_atoms, mass_amu=mass, seed=99 + ctx.rank)).float().cuda(dev)
+    if args.workload == "dft":
+        v *= float(wk.BOHR_PER_NM / 10.0)
     f = eng.forward(x, species=species, denormalize=True).clone()
 
     md = dict(dt_ps=0.002 if args.workload == "c2" else 0.0005, mass_amu=mass, temperature_k=100.0, gamma_per_ps=25.0,
-              seed=ens.box_seed(7, ctx), species=species)
+              seed=ens.box_seed(7, ctx), species=species, **md_extra)
     eng.md_run(x, v, f, args.warmup, first_step=0, **md)
     torch.cuda.synchronize(dev)
     ens.barrier(ctx)
@@ -143,7 +168,7 @@ def main():
 
     value = ens.aggregate_throughput(n_atoms * args.steps, dt_max, ctx)
     avg_ms = conv_ms / max(conv_n, 1)
-    achieved = n_edges * FLOP_PER_EDGE_CONV / (avg_ms * 1e-3) / 1e12
+    achieved = n_edges * flop_per_edge / (avg_ms * 1e-3) / 1e12
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_conv_edge.json")
     if os.path.exists(pmc) and args.workload == "c2":        # the PMC passes were taken on the C2 workload
@@ -153,16 +178,16 @@ def main():
             traffic = None
     line = {
         "metric": "atom-steps/sec (force eval + integrate), 10k-atom LJ box" if args.workload == "c2"
-                  else f"atom-steps/sec (force eval + integrate), {args.workload} water box",
+                  else f"atom-steps/sec (force eval + constrained integrate), {args.workload} water box",
         "value": value, "unit": "atom-steps/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": wl, "n_atoms": n_atoms, "edges_per_step": n_edges, "boxes": ctx.world,
                    "step": "BAOAB half + neighbour build + GNN forces + BAOAB half, on device"},
-        "roofline": {"kernel": "k_conv_edge", "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+        "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "avg_launch_ms": avg_ms, "launches": conv_n,
-                     "flop_per_launch": n_edges * FLOP_PER_EDGE_CONV},
+                     "flop_per_launch": n_edges * flop_per_edge},
     }
     if dtype_name == "bf16":
         # the bf16 kernel is gather-bound, not matrix-bound: report the neighbour-gather bytes of SURVEY.md §8d
