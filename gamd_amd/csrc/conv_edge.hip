@@ -116,10 +116,19 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     int E = a.counters[CNT_E];
     if ((long long)E > a.e_cap) E = (int)a.e_cap;
     const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
-    const int n_wg_tiles = (n_tiles + 7) / 8;
+    // Work unit = 4 tiles, one per SIMD.  Waves 0-3 and 4-7 of the workgroup take successive units of its list, so
+    // the work is balanced to half an iteration (an iteration with only waves 0-3 active takes about half the
+    // time: the two waves of a SIMD serialise their MFMA streams anyway).
+    const int n_units = (n_tiles + 3) / 4;
     int first, end, step;
-    gamd_xcd_range(n_wg_tiles, blockIdx.x, gridDim.x, first, end, step);
+    gamd_xcd_range(n_units, blockIdx.x, gridDim.x, first, end, step);
     if (first >= end) return;
+    const int n_iter = ((end - first + step - 1) / step + 1) / 2;
+    const int wsub = wave & 3, whalf = wave >> 2;
+    auto tile_of = [&](int it) {              // this wave's tile in iteration `it`, or n_tiles (inactive)
+        const int u = first + (2 * it + whalf) * step;
+        return (it < n_iter && u < end) ? u * 4 + wsub : n_tiles;
+    };
 
     long long tacc[12];
 #pragma unroll
@@ -134,7 +143,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     f32x16 RA[4], RB[4], RC[4];
 
     // per-lane edge of the current tile (slot order) and prefetch for the first tile
-    int tile = first * 8 + wave;
+    int tile = tile_of(0);
     bool active = tile < n_tiles;
     int src = 0, dst = 0;
     {
@@ -150,13 +159,13 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     unsigned pend_ends = 0;           // piece stores of the tile just finished (issued after its last barrier)
     int pend_p = 0;
 
-    for (int wt = first; wt < end; wt += step) {
+    for (int it = 0; it < n_iter; ++it) {
         const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
         int nvalid = E - x0;
         nvalid = !active ? 0 : (nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid));
         // next tile of this wave (indices prefetched during phase 3)
-        const int tile_n = (wt + step) * 8 + wave;
-        const bool active_n = (wt + step < end) && tile_n < n_tiles;
+        const int tile_n = tile_of(it + 1);
+        const bool active_n = tile_n < n_tiles;
         int src_n = 0, dst_n = 0;
 
         // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====

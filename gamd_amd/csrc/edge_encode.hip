@@ -48,9 +48,16 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
     long long E = a.counters[CNT_E];
     if (E > a.e_cap) E = a.e_cap;
     const int n_tiles = (int)((E + GAMD_TILE - 1) / GAMD_TILE);
-    const int n_wg_tiles = (n_tiles + 7) / 8;
+    // work unit = 4 tiles (one per SIMD); waves 0-3 and 4-7 take successive units of the workgroup's list, which
+    // balances the launch to half a round (the two waves of a SIMD share its matrix pipe)
+    const int n_units = (n_tiles + 3) / 4;
     int first, end, step;
-    gamd_xcd_range(n_wg_tiles, blockIdx.x, gridDim.x, first, end, step);
+    gamd_xcd_range(n_units, blockIdx.x, gridDim.x, first, end, step);
+    const int n_iter = first < end ? ((end - first + step - 1) / step + 1) / 2 : 0;
+    auto tile_of = [&](int it) {
+        const int u = first + (2 * it + (wave >> 2)) * step;
+        return (it < n_iter && u < end) ? u * 4 + (wave & 3) : n_tiles;
+    };
 
     constexpr int KSTEPS = (NFEAT + 1) / 2;      // 22 (LJ) or 23 (water + bond flag)
 
@@ -63,13 +70,13 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         if (tile < n_tiles && x < E32) { src = a.col[x]; dst = a.erow[x]; }
     };
     int src_c, dst_c;
-    fetch_idx(first * 8 + wave, src_c, dst_c);
+    fetch_idx(tile_of(0), src_c, dst_c);
     float4 ps = a.pos_s[src_c], pd = a.pos_s[dst_c];
 
-    for (int wt = first; wt < end; wt += step) {
-        const int tile = wt * 8 + wave;
+    for (int it = 0; it < n_iter; ++it) {
+        const int tile = tile_of(it);
         int src_n, dst_n;
-        fetch_idx((wt + step < end) ? (wt + step) * 8 + wave : n_tiles, src_n, dst_n);
+        fetch_idx(tile_of(it + 1), src_n, dst_n);
         if (tile >= n_tiles) continue;
         const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
