@@ -403,3 +403,31 @@ def test_error_conventions():
     with pytest.raises(GamdError, match="4 bonded"):
         _engine(sdw, 30, 12.0, 3.0, bond=np.array([[0, k] for k in range(1, 7)]))
     eng.close()
+
+
+def test_error_conventions_for_widths_and_constraints():
+    """Unsupported widths and inconsistent integrator parameters are refused with a message, not run."""
+    from gamd_amd._lib import GamdError
+    with pytest.raises(ValueError, match="hidden_dim"):
+        cfg = ModelConfig(kind="water", hidden_dim=256, encoding_size=256, edge_embedding_dim=256)
+        _engine(make_state_dict(cfg, 1), 30, 12.0, 3.0, cfg=cfg)
+    wide = ModelConfig(kind="water", encoding_size=256, edge_embedding_dim=256, conv_layer=2)
+    with pytest.raises(GamdError, match="bf16"):
+        _engine(make_state_dict(wide, 1), 30, 12.0, 3.0, cfg=wide, edge_dtype="bf16")
+    # a 128-wide state_dict handed to a 256-wide configuration: strict shape check (load_state_dict semantics)
+    with pytest.raises(KeyError, match="shape"):
+        _engine(make_state_dict(ModelConfig(kind="water", conv_layer=2), 1), 30, 12.0, 3.0, cfg=wide)
+    eng = _engine(make_state_dict(ModelConfig(kind="water"), 1), 31, 12.0, 3.0)
+    x, v, f = (torch.rand(31, 3, device="cuda") for _ in range(3))
+    sp = np.arange(31) % 3 == 0
+    with pytest.raises(GamdError, match="multiple of 3"):
+        eng.md_run(x, v, f, 1, mass_amu=16.0, mass_h_amu=1.0, species=sp, rigid_water=True, r_oh=0.96, r_hh=1.51)
+    eng.close()
+    eng = _engine(make_state_dict(ModelConfig(kind="water"), 1), 30, 12.0, 3.0)
+    x, v, f = (torch.rand(30, 3, device="cuda") for _ in range(3))
+    sp = np.arange(30) % 3 == 0
+    with pytest.raises(GamdError, match="mass_h_amu"):
+        eng.md_run(x, v, f, 1, mass_amu=16.0, species=sp, rigid_water=True, r_oh=0.96, r_hh=1.51)
+    with pytest.raises(GamdError, match="r_hh"):
+        eng.md_run(x, v, f, 1, mass_amu=16.0, mass_h_amu=1.0, species=sp, rigid_water=True, r_oh=0.96, r_hh=2.0)
+    eng.close()
