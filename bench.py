@@ -77,6 +77,10 @@ def main():
                     help="c2 (default, the headline metric): 10k-atom LJ fp32; c3: 4 170-atom TIP3P fp32; "
                          "c5: 6 000-network-atom TIP4P-Ew-sized box, bf16 edge-MLP; dft: the 774-atom DFT-water "
                          "configuration (256/256/128 x 5 layers, bohr, cutoff 9.5)")
+    ap.add_argument("--skin", type=float, default=1.0 / 6.0,
+                    help="Verlet-skin reuse of the neighbour candidates, in units of the cutoff (the reference's jax-md "
+                         "list uses 1/6, graph_utils.py:24, and so does the default here); 0 = exact cell-list rebuild "
+                         "every step.  The edge set is identical either way (c2 workload only)")
     args = ap.parse_args()
 
     # RCCL ("nccl") over xGMI in production; GAMD_BENCH_BACKEND=gloo + GAMD_BENCH_SHARE_GPU=1 let the N>1 control
@@ -116,7 +120,8 @@ def main():
     elif args.workload == "c2":
         pos, box = lj_box(N_ATOMS, seed=ens.box_seed(1234, ctx))
         sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
-        eng = GamdForce(sd, N_ATOMS, box, CUTOFF, scaler=SHIPPED_SCALERS["lj"], device=dev)
+        eng = GamdForce(sd, N_ATOMS, box, CUTOFF, scaler=SHIPPED_SCALERS["lj"], device=dev,
+                        neighbor_skin=args.skin * CUTOFF)
         n_atoms = N_ATOMS
         wl = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
               "random-init weights (seed 0), 1 box per GPU")
@@ -183,6 +188,9 @@ def main():
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
         "config": {"workload": wl, "n_atoms": n_atoms, "edges_per_step": n_edges, "boxes": ctx.world,
+                   "neighbour_list": ("exact cell-list rebuild every step" if args.skin == 0 or args.workload != "c2" else
+                                      f"Verlet skin {args.skin:.3f} x cutoff, exact re-filter every step, "
+                                      f"{eng.skin_stats()[0]} candidate rebuilds in warm-up + timed steps"),
                    "step": "BAOAB half + neighbour build + GNN forces + BAOAB half, on device"},
         "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,

@@ -18,7 +18,7 @@ class GamdConfig(C.Structure):
                 ("cutoff", C.c_float), ("box", C.c_float * 3), ("edge_capacity", C.c_int64),
                 ("keep_stages", C.c_int32), ("edge_dtype", C.c_int32),
                 ("encoding_size", C.c_int32), ("edge_embedding_dim", C.c_int32), ("hidden_dim", C.c_int32),
-                ("no_expand_edge", C.c_int32)]
+                ("no_expand_edge", C.c_int32), ("neighbor_skin", C.c_float), ("reserved", C.c_int32)]
 
 
 # common tail of both integrator parameter blocks (masses per species, length unit, rigid water)
@@ -54,6 +54,7 @@ SYMBOLS = {
     "gamd_forces_edges": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _i64, _vp, _vp, _vp]),
     "gamd_build_neighbors": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp]),
     "gamd_get_counts": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "gamd_get_skin_stats": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "gamd_debug_get": (_i32, [_vp, _i32, _vp, C.c_size_t]),
     "gamd_md_run": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(GamdMdParams), _i64, _vp]),
     "gamd_md_run_nhc": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(GamdNhcParams), _vp, _i64, _vp]),

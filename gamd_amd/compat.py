@@ -68,6 +68,8 @@ class _ForceFieldBase:
         self.num_atoms, self.box_size, self.cutoff = int(num_atoms), box_size, float(cutoff)
         self.bond, self.device_index = bond, device
         self._nbr_flavour = "jaxmd"                  # graph_utils.NeighborSearcher semantics ('<' on r^2, self edge kept)
+        self._skin = self.cutoff / 6.0               # its dr_threshold (graph_utils.py:24): candidate list reused
+                                                     # between calls, exact cutoff re-applied every call
         self.training_mean = np.array([0.])          # LJ/train_network_lj.py:105-106
         self.training_var = np.array([1.])
         self._sd = state_dict
@@ -106,7 +108,7 @@ class _ForceFieldBase:
                 raise RuntimeError("no weights loaded: call load_from_checkpoint / load_state_dict first")
             self._engine = GamdForce(self._sd, self.num_atoms, self.box_size, self.cutoff, bond=self.bond,
                                      scaler=(self.training_mean, self.training_var), device=self.device_index,
-                                     nbr_flavour=self._nbr_flavour)
+                                     nbr_flavour=self._nbr_flavour, neighbor_skin=self._skin)
         return self._engine
 
     def denormalize(self, normalized_force, var, mean):
@@ -167,6 +169,7 @@ class ParticleNetLightningDFT(_ForceFieldBase):
             box_size = 20.0 / 0.529177
         super().__init__(args, state_dict, num_atoms=num_atoms, box_size=box_size, cutoff=cutoff, **kw)
         self._nbr_flavour = "torch"
+        self._skin = 0.0                             # md_module.get_neighbor searches from scratch every call
 
     def predict_forces(self, feat: torch.Tensor, pos: np.ndarray, box_size) -> np.ndarray:
         eng = self._get_engine()

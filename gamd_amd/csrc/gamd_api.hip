@@ -89,7 +89,14 @@ struct gamd_handle {
     DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg;
     DevBuf counters, tdbg, tmp_eid, ke_partial;
     int* counters_host = nullptr;   // pinned
+    int* sticky_host = nullptr;     // pinned + mapped: overflow flags and rebuild count, written by kernels directly
+    int* sticky_dev = nullptr;
     bool has_bonds = false;
+    // Verlet-skin reuse (cfg.neighbor_skin > 0)
+    float skin = 0.f;
+    DevBuf ref_pos, cand_deg, cand_ptr, cand_col;
+    long long cand_cap = 0;
+    bool cand_valid = false;
 
     float box[3] = {0, 0, 0};
     int nc[3] = {1, 1, 1};
@@ -101,6 +108,13 @@ struct gamd_handle {
 };
 
 namespace {
+
+int alloc_candidates(gamd_handle* h, long long cap) {
+    if (h->cand_col.ensure(sizeof(int) * ((size_t)cap + 64), true)) return fail(-12, "candidate buffer allocation failed");
+    h->cand_cap = cap;
+    h->cand_valid = false;
+    return 0;
+}
 
 int alloc_edges(gamd_handle* h, long long e_cap) {
     const size_t ec = (size_t)e_cap + 2 * GAMD_TILE;
@@ -114,6 +128,11 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
     if (h->cfg.keep_stages) r |= h->feat_dbg.ensure(sizeof(float) * 48 * ec, true);
     if (r) return fail(-12, "edge buffer allocation failed for capacity %lld", e_cap);
     h->e_cap = e_cap;
+    if (h->skin > 0.f) {
+        const double grow = std::pow(((double)h->cfg.cutoff + h->skin) / (double)h->cfg.cutoff, 3.0);
+        const long long want = (long long)((double)e_cap * grow * 1.1) + 1024;
+        if (want > h->cand_cap) return alloc_candidates(h, want);
+    }
     return 0;
 }
 
@@ -121,8 +140,9 @@ int set_box(gamd_handle* h, const float* box) {
     long long ncell = 1;
     for (int d = 0; d < 3; ++d) {
         if (!(box[d] > 0.f)) return fail(-22, "box[%d] = %g is not positive", d, (double)box[d]);
+        if (h->box[d] != box[d]) h->cand_valid = false;            // candidates were built for another box
         h->box[d] = box[d];
-        int nc = (int)std::floor((double)box[d] / ((double)h->cfg.cutoff * 1.0001));
+        int nc = (int)std::floor((double)box[d] / (((double)h->cfg.cutoff + (double)h->skin) * 1.0001));
         h->nc[d] = std::max(1, nc);
         ncell *= h->nc[d];
     }
@@ -170,6 +190,16 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
     a.chunk_piece = h->chunk_piece.as<int>();
     a.chunk_mask = h->chunk_mask.as<unsigned>();
     a.counters = h->counters.as<int>();
+    a.sticky = h->sticky_dev;
+    if (h->skin > 0.f) {
+        a.skin_half2 = 0.25f * h->skin * h->skin;
+        a.rc_build = h->cfg.cutoff + h->skin;
+        a.rc2_build = (float)((double)a.rc_build * (double)a.rc_build);
+        a.cand_deg = h->cand_deg.as<int>();
+        a.cand_ptr = h->cand_ptr.as<int>();
+        a.cand_col = h->cand_col.as<int>();
+        a.cand_cap = h->cand_cap;
+    }
     return a;
 }
 
@@ -279,6 +309,12 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     if (el) {
         if ((r = launch_csr_from_edges(na, el->centre, el->neigh, el->n, h->tmp_eid.as<int>(), st)))
             return fail(-1, "edge-list CSR launch failed (%d)", r);
+        h->cand_valid = false;                                    // atom order changed under the candidate list
+    } else if (h->skin > 0.f) {
+        na.ref_pos = h->ref_pos.as<float4>();
+        na.force_rebuild = h->cand_valid ? 0 : 1;
+        if ((r = launch_neighbor_skin(na, st))) return fail(-1, "neighbor (skin) launch failed (%d)", r);
+        h->cand_valid = true;
     } else if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);
     mark("neighbor_build");
 
@@ -312,6 +348,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     auto hptr = [&](int l) { return h->hbuf.as<float>() + (h->cfg.keep_stages ? (size_t)l * nh : (size_t)(l & 1) * nh); };
 
     NodeArgs no{};
+    no.counters = h->counters.as<int>();
     no.n = h->n;
     no.pos_s = h->pos_s.as<float4>();
     no.node_emb = h->node_emb; no.enc_w = h->nenc_w; no.enc_b = h->nenc_b;
@@ -388,6 +425,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     if (cfg->n_layers <= 0 || cfg->n_layers > 16) return fail(-22, "n_layers out of range");
     if (!(cfg->cutoff > 0.f)) return fail(-22, "cutoff must be positive");
     if (cfg->edge_dtype != GAMD_EDGE_F32 && cfg->edge_dtype != GAMD_EDGE_BF16) return fail(-22, "unknown edge_dtype");
+    if (!(cfg->neighbor_skin >= 0.f)) return fail(-22, "neighbor_skin must be >= 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(-19, "no HIP device available: libgamd_hip has no CPU fallback");
@@ -406,6 +444,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     h->n = cfg->n_atoms;
     h->L = cfg->n_layers;
     h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
+    h->skin = cfg->neighbor_skin;
     const char* force_wide = getenv("GAMD_FORCE_WIDE");      // test hook: run the 128-wide config on wide.hip
     const bool forced = force_wide && force_wide[0] == '1' && cfg->edge_dtype != GAMD_EDGE_BF16;
     h->wide_enc = generic || forced;
@@ -437,6 +476,19 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         return fail(-12, "pinned allocation failed");
     }
     memset(h->counters_host, 0, sizeof(int) * CNT_COUNT);
+    if (hipHostMalloc((void**)&h->sticky_host, sizeof(int) * STICKY_COUNT, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->sticky_dev, h->sticky_host, 0) != hipSuccess) {
+        gamd_destroy(h);
+        return fail(-12, "mapped host allocation failed");
+    }
+    memset(h->sticky_host, 0, sizeof(int) * STICKY_COUNT);
+    if (h->skin > 0.f) {
+        int rr = 0;
+        rr |= h->ref_pos.ensure(sizeof(float4) * n, true);
+        rr |= h->cand_deg.ensure(sizeof(int) * n, true);
+        rr |= h->cand_ptr.ensure(sizeof(int) * (n + 1), true);
+        if (rr) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
+    }
     if ((r = set_box(h, cfg->box))) { gamd_destroy(h); return r; }
     long long ecap = cfg->edge_capacity;
     if (ecap <= 0) {
@@ -454,9 +506,11 @@ int32_t gamd_destroy(gamd_handle* h) {
     DevBuf* bufs[] = {&h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
-                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial};
+                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial,
+                      &h->ref_pos, &h->cand_deg, &h->cand_ptr, &h->cand_col};
     for (DevBuf* b : bufs) b->release();
     if (h->counters_host) (void)hipHostFree(h->counters_host);
+    if (h->sticky_host) (void)hipHostFree(h->sticky_host);
     for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
     delete h;
     return 0;
@@ -629,9 +683,11 @@ int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t
     for (int attempt = 0; attempt < 4; ++attempt) {
         if ((r = set_box(h, box))) return r;
         NbrArgs na = nbr_args(h, pos_dev, species_dev);
+        h->cand_valid = false;                                    // the exact build below reorders the atoms
         if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);
         HIP_TRY(hipMemcpyAsync(h->counters_host, h->counters.p, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
         if (!h->counters_host[CNT_OVERFLOW]) return attempt ? 1 : 0;
         const long long need = (long long)(1.25 * (double)h->counters_host[CNT_E]) + 1024;
         if ((r = alloc_edges(h, need))) return r;
@@ -653,10 +709,23 @@ int32_t gamd_forces_async(gamd_handle* h, const float* pos_dev, const uint8_t* s
 int32_t gamd_sync_status(gamd_handle* h, void* stream) {
     if (!h) return fail(-22, "null handle");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (h->counters_host[CNT_OVERFLOW]) {
-        const long long need = (long long)(1.25 * (double)h->counters_host[CNT_E]) + 1024;
+    // the sticky flags catch an overflow in ANY step enqueued since the last check (gamd_md_run), not only the last
+    if (h->sticky_host[STICKY_CAND_OVERFLOW]) {
+        h->sticky_host[STICKY_CAND_OVERFLOW] = 0;
+        h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
+        const long long seen = std::max<long long>(h->sticky_host[STICKY_NCAND], h->cand_cap);
+        const long long need = (long long)(1.25 * (double)seen) + 1024;
+        int r = alloc_candidates(h, need);
+        if (r) return r;
+        return fail(-34, "candidate neighbour buffers overflowed; regrown to %lld, re-issue the call", need);
+    }
+    if (h->counters_host[CNT_OVERFLOW] || h->sticky_host[STICKY_EDGE_OVERFLOW]) {
+        h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
+        const long long seen = std::max<long long>(h->counters_host[CNT_E], h->e_cap);
+        const long long need = (long long)(1.25 * (double)seen) + 1024;
         int r = alloc_edges(h, need);
         if (r) return r;
+        h->cand_valid = false;
         return fail(-34, "neighbour buffers overflowed (E=%d); regrown to %lld, re-issue the call",
                     h->counters_host[CNT_E], need);
     }
@@ -697,6 +766,7 @@ int32_t gamd_forces_edges(gamd_handle* h, const float* pos_dev, const uint8_t* s
                              nullptr, &el)))
         return r;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
     if (h->counters_host[CNT_OVERFLOW] == 2) return fail(-22, "edge list references an atom index outside [0, n_atoms)");
     if (h->counters_host[CNT_OVERFLOW]) return fail(-34, "edge buffers overflowed unexpectedly");
     return status;
@@ -707,6 +777,14 @@ int32_t gamd_get_counts(gamd_handle* h, int64_t* n_edges, int64_t* n_pieces, int
     if (n_edges) *n_edges = h->counters_host[CNT_E];
     if (n_pieces) *n_pieces = h->counters_host[CNT_PIECES];
     if (edge_capacity) *edge_capacity = h->e_cap;
+    return 0;
+}
+
+int32_t gamd_get_skin_stats(gamd_handle* h, int64_t* n_rebuilds, int64_t* n_candidates, int64_t* candidate_capacity) {
+    if (!h) return fail(-22, "null handle");
+    if (n_rebuilds) *n_rebuilds = h->sticky_host[STICKY_REBUILDS];
+    if (n_candidates) *n_candidates = h->sticky_host[STICKY_NCAND];
+    if (candidate_capacity) *candidate_capacity = h->cand_cap;
     return 0;
 }
 

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_COUNT = 8 };
+enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD = 4, CNT_NCAND = 5, CNT_COUNT = 8 };
+// host-mapped, never cleared by the per-call memset: overflow must survive later steps of an enqueued MD run
+enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, STICKY_NCAND = 3, STICKY_COUNT = 4 };
 
 // ---- neighbour build --------------------------------------------------------------------------
 struct NbrArgs {
@@ -33,8 +35,22 @@ struct NbrArgs {
     int* chunk_piece;      // [(e_cap+32)/16]
     unsigned* chunk_mask;  // [(e_cap+32)/16]
     int* counters;         // [CNT_COUNT]
+    int* sticky;           // [STICKY_COUNT] host-mapped
+    // Verlet-skin reuse (graph_utils.py:21-25,36-44: build with cutoff + dr_threshold, rebuild when an atom has moved
+    // dr_threshold / 2): candidate CSR built with rc + skin on the steps that need it, exact filter every step
+    const int* gate;       // non-null: the kernel returns unless *gate != 0 (rebuild kernels of the skin mode)
+    int cand_pass;         // 1: deg/row_ptr/col are the candidate arrays; nothing is published to counters but CNT_NCAND
+    float skin_half2;      // (skin / 2)^2
+    int force_rebuild;     // first call, box change, regrown buffers
+    float4* ref_pos;       // [n] wrapped positions at the last candidate build (original order)
+    int* cand_deg;         // [n]
+    int* cand_ptr;         // [n+1]
+    int* cand_col;         // [cand_cap] sorted index of the candidate neighbour
+    long long cand_cap;
+    float rc_build, rc2_build;   // rc + skin
 };
 int launch_neighbor_build(const NbrArgs& a, hipStream_t st);
+int launch_neighbor_skin(const NbrArgs& a, hipStream_t st);     // skin mode: check, gated candidate rebuild, exact filter
 // CSR from a caller-supplied directed edge list (centre[e], neigh[e]); atoms keep the caller's order.
 // tmp_eid: [n_edges] scratch.  Rows keep the caller's edge order (deterministic).
 int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh, long long n_edges, int* tmp_eid,
@@ -102,6 +118,8 @@ struct NodeLayerW {            // one conv layer's node-side parameters (device 
     const float* bphi;
 };
 struct NodeArgs {
+    const int* counters;       // CNT_OVERFLOW set: the CSR is truncated and piece indices are meaningless -> do nothing
+                               // (the host regrows the buffers and re-issues the call)
     int n;
     int mode;                  // 0: first (embed + pre(0)); 1: post(l-1) + pre(l); 2: post(L-1) + decoder
     // inputs

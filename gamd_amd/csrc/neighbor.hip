@@ -21,7 +21,10 @@ __device__ __forceinline__ int cell_coord(float p, float box, int nc) {
     return c < 0 ? 0 : (c >= nc ? nc - 1 : c);     // remainder() may round up to exactly `box`
 }
 
+#define GAMD_GATE() do { if (a.gate && *a.gate == 0) return; } while (0)
+
 __global__ void k_bin(NbrArgs a) {
+    GAMD_GATE();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     float4 p;
@@ -30,6 +33,7 @@ __global__ void k_bin(NbrArgs a) {
     p.z = gamd_remainder(a.pos[3 * i + 2], a.box[2]);
     p.w = 0.f;
     a.pos_w[i] = p;
+    if (a.ref_pos) a.ref_pos[i] = p;
     const int c = (cell_coord(p.x, a.box[0], a.nc[0]) * a.nc[1] + cell_coord(p.y, a.box[1], a.nc[1])) * a.nc[2] +
                   cell_coord(p.z, a.box[2], a.nc[2]);
     a.cell_of[i] = c;
@@ -76,10 +80,12 @@ __device__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
 }
 
 __global__ void __launch_bounds__(1024) k_scan_cells(NbrArgs a) {
+    GAMD_GATE();
     block_exclusive_scan(a.ncell, [&](int i) { return a.cell_cnt[i]; }, a.cell_start);
 }
 
 __global__ void k_fill_cells(NbrArgs a) {
+    GAMD_GATE();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const int c = a.cell_of[i];
@@ -91,6 +97,7 @@ __global__ void k_fill_cells(NbrArgs a) {
 // (and with it every floating-point summation order downstream) is bit-reproducible run to run.
 // One wave per cell: rank by counting (cells hold ~14 atoms), then gather the sorted positions.
 __global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
+    GAMD_GATE();
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (c >= a.ncell) return;
@@ -177,6 +184,7 @@ __device__ __forceinline__ unsigned half_ballot(bool p) {
 }
 
 __global__ void __launch_bounds__(256) k_count(NbrArgs a) {
+    GAMD_GATE();
     const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const int l = threadIdx.x & 31;
     const bool live = ctr < a.n;
@@ -189,8 +197,19 @@ __global__ void __launch_bounds__(256) k_count(NbrArgs a) {
 // row_ptr = exscan(deg); NA = inclusive count of non-empty segments that start off a chunk boundary;
 // publishes E, the piece count and the overflow flag.
 __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
+    GAMD_GATE();
     block_exclusive_scan(a.n, [&](int i) { return a.deg[i]; }, a.row_ptr);
     __syncthreads();
+    if (a.cand_pass) {                                     // candidate CSR: only its size and overflow matter
+        if (threadIdx.x == 0) {
+            const int nc = a.row_ptr[a.n];
+            a.counters[CNT_NCAND] = nc;
+            a.sticky[STICKY_NCAND] = nc;
+            if ((long long)nc > a.e_cap) a.sticky[STICKY_CAND_OVERFLOW] = 1;
+            a.sticky[STICKY_REBUILDS] += 1;
+        }
+        return;
+    }
     block_exclusive_scan(a.n, [&](int i) { return (a.deg[i] > 0 && (a.row_ptr[i] % GAMD_CHUNK) != 0) ? 1 : 0; },
                          a.na_excl);
     __syncthreads();
@@ -198,12 +217,13 @@ __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
         const int E = a.row_ptr[a.n];
         a.counters[CNT_E] = E;
         a.counters[CNT_PIECES] = (E + GAMD_CHUNK - 1) / GAMD_CHUNK + a.na_excl[a.n];
-        if ((long long)E > a.e_cap) a.counters[CNT_OVERFLOW] = 1;
+        if ((long long)E > a.e_cap) { a.counters[CNT_OVERFLOW] = 1; a.sticky[STICKY_EDGE_OVERFLOW] = 1; }
         a.counters[CNT_TILES] = (E + GAMD_TILE - 1) / GAMD_TILE;
     }
 }
 
 __global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
+    GAMD_GATE();
     const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const int l = threadIdx.x & 31;
     const bool live = ctr < a.n;
@@ -213,7 +233,7 @@ __global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
         const unsigned m = half_ballot(ok);
         if (ok && live) {
             const long long at = w + __popc(m & ((1u << l) - 1u));
-            if (at < a.e_cap) { a.col[at] = b; a.erow[at] = c; }
+            if (at < a.e_cap) { a.col[at] = b; if (a.erow) a.erow[at] = c; }
         }
         w += __popc(m);
     });
@@ -244,6 +264,80 @@ __global__ void k_chunk_meta(NbrArgs a) {
         prev = nxt;
     }
     a.chunk_mask[c] = mask;
+}
+
+// ---- Verlet-skin reuse ----------------------------------------------------------------------------
+// Every call: wrap the positions and raise the rebuild flag if any atom has moved more than skin/2 since the
+// candidate list was built (or the host forces it).  jax-md does the same test in update_neighbor_lst
+// (graph_utils.py:36-44) with dr_threshold = cutoff/6.
+__global__ void k_skin_check(NbrArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float4 p;
+    p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);
+    p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
+    p.z = gamd_remainder(a.pos[3 * i + 2], a.box[2]);
+    p.w = 0.f;
+    a.pos_w[i] = p;
+    bool moved = a.force_rebuild != 0;
+    if (!moved) {
+        const float4 r = a.ref_pos[i];
+        const float dx = gamd_min_image_wrapped(p.x - r.x, a.box[0], a.half[0]);
+        const float dy = gamd_min_image_wrapped(p.y - r.y, a.box[1], a.half[1]);
+        const float dz = gamd_min_image_wrapped(p.z - r.z, a.box[2], a.half[2]);
+        moved = !(((dx * dx + dy * dy) + dz * dz) <= a.skin_half2);      // NaN positions force a rebuild too
+    }
+    if (moved) a.counters[CNT_REBUILD] = 1;
+}
+
+// current positions in the (frozen) sorted order
+__global__ void k_regather(NbrArgs a) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n) return;
+    const int v = a.perm[s];
+    float4 p = a.pos_w[v];
+    p.w = a.species ? (float)a.species[v] : 0.f;
+    a.pos_s[s] = p;
+}
+
+// exact cutoff on the candidate rows: one half-wave per centre atom, candidates keep their order
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
+    const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    const bool live = ctr < a.n;
+    const int c = live ? ctr : a.n - 1;
+    const float4 pc = a.pos_s[c];
+    long long s = a.cand_ptr[c], e = a.cand_ptr[c + 1];
+    if (e > a.cand_cap) e = a.cand_cap;
+    if (s > e) s = e;
+    long long w = FILL ? (long long)a.row_ptr[c] : 0;
+    int cnt = 0;
+    for (long long b0 = s; b0 < e; b0 += 32) {
+        bool ok = false;
+        int b = 0;
+        if (b0 + l < e) {
+            b = a.cand_col[b0 + l];
+            const float4 pb = a.pos_s[b];
+            const float rx = gamd_min_image_wrapped(pb.x - pc.x, a.box[0], a.half[0]);
+            const float ry = gamd_min_image_wrapped(pb.y - pc.y, a.box[1], a.half[1]);
+            const float rz = gamd_min_image_wrapped(pb.z - pc.z, a.box[2], a.half[2]);
+            const float d2 = (rx * rx + ry * ry) + rz * rz;
+            if (a.flavour == 0) ok = d2 < a.rc2;
+            else ok = (sqrtf(d2) <= a.rc) && (b != c);
+        }
+        const unsigned m = half_ballot(ok);
+        if (FILL) {
+            if (ok && live) {
+                const long long at = w + __popc(m & ((1u << l) - 1u));
+                if (at < a.e_cap) { a.col[at] = b; a.erow[at] = c; }
+            }
+            w += __popc(m);
+        } else {
+            cnt += __popc(m);
+        }
+    }
+    if (!FILL && live && l == 0) a.deg[ctr] = cnt;
 }
 
 // ---- CSR from an explicit edge list (model-level forward([pos],[edge_idx]), nn_module.py:636-653) ----
@@ -329,6 +423,37 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
     }
     const long long nchunk_cap = (a.e_cap + GAMD_TILE) / GAMD_CHUNK;
     hipLaunchKernelGGL(k_chunk_meta, dim3((unsigned)((nchunk_cap + 255) / 256)), dim3(256), 0, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_neighbor_skin(const NbrArgs& a, hipStream_t st) {
+    hipError_t e;
+    e = hipMemsetAsync(a.counters, 0, sizeof(int) * (CNT_COUNT + 2 * (size_t)a.ncell_cap), st); if (e) return (int)e;
+    const int tb = 256, gb = (a.n + tb - 1) / tb, ga = (a.n + 7) / 8;
+    hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
+    // candidate rebuild with rc + skin, every kernel gated on the flag k_skin_check has just written
+    NbrArgs c = a;
+    c.gate = a.counters + CNT_REBUILD;
+    c.cand_pass = 1;
+    c.rc = a.rc_build; c.rc2 = a.rc2_build;
+    c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
+    hipLaunchKernelGGL(k_bin, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();          // also stores ref_pos
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_fill_cells, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sort_gather, dim3((a.ncell + 3) / 4), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_count, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_fill, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
+    // exact list of this step
+    NbrArgs x = a;
+    x.ref_pos = nullptr;
+    hipLaunchKernelGGL(k_regather, dim3(gb), dim3(tb), 0, st, x); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_filter<false>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, x); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_filter<true>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
+    const long long nchunk_cap = (a.e_cap + GAMD_TILE) / GAMD_CHUNK;
+    hipLaunchKernelGGL(k_chunk_meta, dim3((unsigned)((nchunk_cap + 255) / 256)), dim3(256), 0, st, x);
     GAMD_CHECK_LAUNCH();
     return 0;
 }

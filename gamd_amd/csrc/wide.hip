@@ -408,6 +408,8 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
     __shared__ float obuf[4][32][3];
     __shared__ float red[2][4][32];
 
+    if (a.counters[CNT_OVERFLOW]) return;
+
     const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
     const int quarter = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int atom_raw = blockIdx.x * GAMD_TILE + slot;

@@ -44,7 +44,8 @@ class GamdForce:
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_atoms: int, box, cutoff: float,
                  bond: Optional[np.ndarray] = None, scaler: Tuple[float, float] = (0.0, 1.0),
                  nbr_flavour: str = "jaxmd", device: int = 0, keep_stages: bool = False,
-                 edge_capacity: int = 0, cfg: Optional[ModelConfig] = None, edge_dtype: str = "f32"):
+                 edge_capacity: int = 0, cfg: Optional[ModelConfig] = None, edge_dtype: str = "f32",
+                 neighbor_skin: float = 0.0):
         self._h = C.c_void_p()
         self._lib = _lib.load()
         if not torch.cuda.is_available():
@@ -73,6 +74,7 @@ class GamdForce:
         c.edge_dtype = {"f32": 0, "bf16": 1}[edge_dtype]
         c.encoding_size, c.edge_embedding_dim, c.hidden_dim = cfg.encoding_size, cfg.edge_embedding_dim, cfg.hidden_dim
         c.no_expand_edge = int(cfg.n_rbf == 0)
+        c.neighbor_skin = float(neighbor_skin)      # > 0: Verlet-skin reuse (jax-md uses cutoff/6, graph_utils.py:24)
         self.edge_dtype = edge_dtype
         check(self._lib.gamd_create(C.byref(c), C.byref(self._h)), "gamd_create")
         self.keep_stages = keep_stages
@@ -184,6 +186,12 @@ class GamdForce:
         e, p, c = C.c_int64(), C.c_int64(), C.c_int64()
         check(self._lib.gamd_get_counts(self._h, C.byref(e), C.byref(p), C.byref(c)), "gamd_get_counts")
         return e.value, p.value, c.value
+
+    def skin_stats(self) -> Tuple[int, int, int]:
+        """(candidate-list rebuilds so far, candidates in the last rebuilt list, candidate capacity)."""
+        r, c, cap = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._lib.gamd_get_skin_stats(self._h, C.byref(r), C.byref(c), C.byref(cap)), "gamd_get_skin_stats")
+        return r.value, c.value, cap.value
 
     # -- stage getters for parity tests ----------------------------------------------------------
     def _dbg(self, what: int, shape, dtype) -> np.ndarray:

@@ -60,6 +60,11 @@ typedef struct gamd_config {
     int32_t no_expand_edge;  /* 1 = expand_edge=False: edge features are (unit vector, standardised length[, bond])
                                 without the 40 RBFs (nn_module.py:329-336; --disable_expand_edge,
                                 water/train_network_real_large.py:363) */
+    float neighbor_skin;     /* 0 = exact cell-list rebuild every call (default).  > 0: Verlet-skin reuse like the reference's
+                                jax-md list (graph_utils.py:21-25 dr_threshold = cutoff/6, :36-44 update): candidates
+                                within cutoff + skin are rebuilt only when an atom has moved more than skin/2, the exact
+                                cutoff is re-applied every call, so the edge SET is the same either way */
+    int32_t reserved;
 } gamd_config;
 
 const char* gamd_version(void);
@@ -117,15 +122,18 @@ int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t
 /* n_edges = directed edge count of the last build (incl. self edges in the jax-md flavour). */
 int32_t gamd_get_counts(gamd_handle* h, int64_t* n_edges, int64_t* n_pieces, int64_t* edge_capacity);
 
+/* Verlet-skin bookkeeping: candidate-list rebuilds so far, size of the candidate list in use, its capacity.  The analogue of watching nbrs.did_buffer_overflow / re-allocation in graph_utils.py:36-44. */
+int32_t gamd_get_skin_stats(gamd_handle* h, int64_t* n_rebuilds, int64_t* n_candidates, int64_t* candidate_capacity);
+
 /* Debug / parity getters: copy a stage tensor of the last call to HOST memory (synchronises).
  * Need keep_stages = 1 for H / FEAT. */
 enum {
     GAMD_DBG_PERM = 0,      /* int32 [n]      sorted -> original atom id */
     GAMD_DBG_ROWPTR = 1,    /* int32 [n+1]    CSR by destination, sorted ids */
     GAMD_DBG_COL = 2,       /* int32 [E]      source atom (sorted id) per CSR edge */
-    GAMD_DBG_EFRAG = 3,     /* fp32  [ceil(E/32)][4][4][64][4]  e in fragment order */
-    GAMD_DBG_FEAT = 4,      /* fp32  [E][48]  raw edge features (first 44|45 columns valid) */
-    GAMD_DBG_H0 = 16        /* fp32  [n][128] residual stream h_l, sorted order: GAMD_DBG_H0 + l */
+    GAMD_DBG_EFRAG = 3,     /* fp32  [ceil(E/32)][Eh/128][4][4][64][4]  e in fragment order */
+    GAMD_DBG_FEAT = 4,      /* fp32  [E][48]  raw edge features (first 44|45, or 4|5 unexpanded, columns valid) */
+    GAMD_DBG_H0 = 16        /* fp32  [n][H] residual stream h_l, sorted order: GAMD_DBG_H0 + l */
 };
 int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t bytes);
 

@@ -431,3 +431,66 @@ def test_error_conventions_for_widths_and_constraints():
     with pytest.raises(GamdError, match="r_hh"):
         eng.md_run(x, v, f, 1, mass_amu=16.0, mass_h_amu=1.0, species=sp, rigid_water=True, r_oh=0.96, r_hh=2.0)
     eng.close()
+
+
+def test_verlet_skin_reuse_gives_the_exact_edge_set_every_step():
+    """neighbor_skin > 0 (graph_utils.py:21-25,36-44 semantics: list built with cutoff + skin, rebuilt when an atom
+    has moved skin/2, exact cutoff re-applied every call): along a random walk the edge SET and the forces equal
+    those of the rebuild-every-call engine, while the candidate list is rebuilt only now and then."""
+    rng = np.random.default_rng(21)
+    n, rc, skin = 1500, 7.5, 1.2
+    pos, box = workloads.lj_box(n, seed=4)
+    sd = make_state_dict(ModelConfig(kind="lj"), 2, 5.0, 1.7)
+    exact = _engine(sd, n, box, rc)
+    reuse = _engine(sd, n, box, rc, neighbor_skin=skin)
+    x = pos.copy()
+    rebuilds = []
+    for step in range(40):
+        if step == 25:
+            x[7] += np.array([3.0, -2.0, 0.5])                       # one atom jumps: immediate rebuild
+        p = torch.from_numpy(x).float()
+        f0 = exact.forward(p).cpu().numpy()
+        f1 = reuse.forward(p).cpu().numpy()
+        assert np.array_equal(edge_set(exact.debug_edges()), edge_set(reuse.debug_edges())), step
+        assert rel_err(f1, f0) < TOL, step
+        rebuilds.append(reuse.skin_stats()[0])
+        x = x + rng.normal(0.0, 0.06, x.shape)
+    assert rebuilds[0] == 1 and rebuilds[-1] < 12                    # reused on most steps
+    assert rebuilds[25] == rebuilds[24] + 1                          # the jump forced one
+    assert rebuilds[-1] >= 3                                         # and the walk did too
+    n_cand = reuse.skin_stats()[1]
+    # another box on the next call: candidates are rebuilt for it
+    b2 = box * 1.02
+    p = torch.from_numpy(x * 1.02).float()
+    f0, f1 = exact.forward(p, box=b2).cpu().numpy(), reuse.forward(p, box=b2).cpu().numpy()
+    assert reuse.skin_stats()[0] == rebuilds[-1] + 1
+    assert np.array_equal(edge_set(exact.debug_edges()), edge_set(reuse.debug_edges())) and rel_err(f1, f0) < TOL
+    assert n_cand > exact.counts()[0]
+    exact.close(); reuse.close()
+
+
+def test_verlet_skin_in_the_md_loop_and_candidate_regrow():
+    from gamd_amd._lib import GamdError
+    n, rc = 2000, 7.5
+    pos, box = workloads.lj_box(n, seed=8)
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    eng = _engine(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=rc / 6)
+    x = torch.from_numpy(pos).float().cuda()
+    v = torch.from_numpy(workloads.maxwell_boltzmann(n, temperature_k=300.0, seed=1)).float().cuda()
+    f = eng.forward(x, denormalize=True).clone()
+    eng.md_run(x, v, f, 150, temperature_k=300.0)
+    r = eng.skin_stats()[0]
+    assert 1 <= r < 40                                               # 150 steps, a handful of rebuilds
+    exact = _engine(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"])
+    f0 = exact.forward(x, denormalize=True).cpu().numpy()
+    f1 = eng.forward(x, denormalize=True).cpu().numpy()
+    assert np.array_equal(edge_set(exact.debug_edges()), edge_set(eng.debug_edges()))
+    assert rel_err(f1, f0) < TOL
+    exact.close(); eng.close()
+    # too small a capacity: candidate / edge buffers are regrown and the call retried (status 1)
+    small = _engine(sd, n, box, rc, neighbor_skin=rc / 6, edge_capacity=1000)
+    out = small.forward(torch.from_numpy(pos).float()).cpu().numpy()
+    assert small.last_status == 1
+    ref = _engine(sd, n, box, rc)
+    assert rel_err(out, ref.forward(torch.from_numpy(pos).float()).cpu().numpy()) < TOL
+    small.close(); ref.close()
