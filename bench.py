@@ -81,6 +81,10 @@ def main():
                     help="Verlet-skin reuse of the neighbour candidates, in units of the cutoff (the reference's jax-md "
                          "list uses 1/6, graph_utils.py:24, and so does the default here); 0 = exact cell-list rebuild "
                          "every step.  The edge set is identical either way (c2 workload only)")
+    ap.add_argument("--edge-dtype", default="f32", choices=["f32", "f16x3"],
+                    help="c2 only. f32 (default, the headline): fp32 MFMA, bit-exact fp32 FMAs.  f16x3: the same GEMMs on the "
+                         "fp16 matrix pipe with every operand split into hi + lo fp16 (3 MFMAs per product term, fp32 "
+                         "accumulate): fp32-grade results (same 1e-5 parity bar), 3/16 of the fp32 matrix time")
     args = ap.parse_args()
 
     # RCCL ("nccl") over xGMI in production; GAMD_BENCH_BACKEND=gloo + GAMD_BENCH_SHARE_GPU=1 let the N>1 control
@@ -121,7 +125,9 @@ def main():
         pos, box = lj_box(N_ATOMS, seed=ens.box_seed(1234, ctx))
         sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
         eng = GamdForce(sd, N_ATOMS, box, CUTOFF, scaler=SHIPPED_SCALERS["lj"], device=dev,
-                        neighbor_skin=args.skin * CUTOFF)
+                        neighbor_skin=args.skin * CUTOFF, edge_dtype=args.edge_dtype)
+        if args.edge_dtype == "f16x3":
+            dtype_name, kernel_name = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)", "k_conv_edge_f16x3"
         n_atoms = N_ATOMS
         wl = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
               "random-init weights (seed 0), 1 box per GPU")

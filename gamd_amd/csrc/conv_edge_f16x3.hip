@@ -1,0 +1,268 @@
+// conv_edge_f16x3.hip — the conv-layer edge kernel (see conv_edge.hip for the data flow and the schedule) with its four
+// 128x128 GEMMs on the fp16 matrix pipe via operand splitting (gamd_f16x3.h): fp32-grade results at 3/16 of the fp32
+// matrix time.  Same persistent workgroups, 2-slot 64 KiB weight ring (the [hi | lo] fp16 image of a matrix is as
+// large as its fp32 image), one barrier per GEMM phase and partial-sum pieces as the fp32 kernel.  A GEMM's input is
+// an operand set (hi, lo fp16 images, 64 registers like the fp32 block it stands for); the post-op of a phase
+// (SiLU, split) writes the next phase's operand set directly.  e arrives pre-split from the encoder.
+// With the matrix time cut 5x the kernel is no longer MFMA-bound: probes/f16x3_chain_bench.hip puts the GEMM chain
+// itself at ~7 000 cycles per 4-tile round (LDS operand feed + SiLU/split VALU), memory-instruction issue comes next.
+#include "gamd_f16x3.h"
+#include "gamd_internal.h"
+
+#include <cstdlib>
+
+namespace {
+
+constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
+
+// L2 -> LDS copy of one packed 64 KiB weight matrix, 8 x 1 KiB per wave.  lane16 is made opaque so
+// the 64-bit addresses are rebuilt (1 VALU each) instead of being hoisted out of the tile loop and
+// spilled (a spilled pointer = scratch reload + s_waitcnt vmcnt(0) in front of every copy).
+template <int NW>
+__device__ __forceinline__ void stage_weight(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
+    asm volatile("" : "+v"(lane16));
+#pragma unroll
+    for (int k = 0; k < 64 / NW; ++k) {
+        const int chunk = k * NW + wave;      // 64 chunks of 1 KiB, lane-linear image == packed global image
+        const char* base = reinterpret_cast<const char*>(gw) + chunk * 1024;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(base + lane16),
+            (__attribute__((address_space(3))) void*)(ldsbuf + chunk * 256), 16, 0, 0);
+    }
+}
+
+// An operand set: the (hi, lo) fp16 images of a 32 x 128 activation block in MFMA operand order, 64 registers
+// (the size of the fp32 block it replaces): w[t][u][part] = 4 dwords = 8 halves of K step (t, u).
+struct OpSet { gamd_u32x4_t w[4][2][2]; };
+
+// fp32 pair -> dword d of (hi, lo)
+__device__ __forceinline__ void put_pair(OpSet& P, int t, int r0, float x0, float x1) {
+    const gamd_f32x2_t x = {x0, x1};
+    const gamd_f16x2 h = __builtin_convertvector(x, gamd_f16x2);
+    const gamd_f32x2_t rem = x - __builtin_convertvector(h, gamd_f32x2_t);
+    const gamd_f16x2 l = __builtin_convertvector(rem, gamd_f16x2);
+    const int u = r0 >> 3, d = (r0 & 7) >> 1;
+    P.w[t][u][0][d] = __builtin_bit_cast(unsigned, h);
+    P.w[t][u][1][d] = __builtin_bit_cast(unsigned, l);
+}
+
+// 128x128 split-fp16 GEMM, output tile by output tile (24 back-to-back MFMAs per accumulator).  PIPE: the
+// element-wise post-op of the PREVIOUS output tile is issued between the K steps of the current one (post(tp, r0)
+// handles elements r0, r0+1 of acc[tp]); otherwise all post-ops trail the GEMM.
+template <bool F2, bool PIPE, typename Post>
+__device__ __forceinline__ void gemm128_f16x3_post(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4], Post post) {
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f16x8 wh = W[((tp * 4 + t) * 2 + u) * 64 + lane];
+                const f16x8 wl = W[2048 + ((tp * 4 + t) * 2 + u) * 64 + lane];
+                const f16x8 xh = __builtin_bit_cast(f16x8, P.w[t][u][0]), xl = __builtin_bit_cast(f16x8, P.w[t][u][1]);
+                if (F2) {
+                    acc[tp] = mfma_f16(xl, wh, acc[tp]);
+                    acc[tp] = mfma_f16(xh, wl, acc[tp]);
+                    acc[tp] = mfma_f16(xh, wh, acc[tp]);
+                } else {
+                    acc[tp] = mfma_f16(wh, xl, acc[tp]);
+                    acc[tp] = mfma_f16(wl, xh, acc[tp]);
+                    acc[tp] = mfma_f16(wh, xh, acc[tp]);
+                }
+                if (PIPE && tp > 0) post(tp - 1, 2 * (t * 2 + u));
+            }
+    }
+#pragma unroll
+    for (int tp = PIPE ? 3 : 0; tp < 4; ++tp)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) post(tp, 2 * k);
+}
+
+// End of a phase: every wave has its own weight DMA (issued at the phase start, before the N most
+// recent VMEM loads) landed, then the workgroup meets.  The N prefetch loads stay in flight.
+// vmcnt retires in order, so "at most N outstanding" proves the older DMA is done only if at least
+// N loads really were issued after it: callers pass 0 on paths that skip the prefetch.
+template <int N>
+__device__ __forceinline__ void phase_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// pre-split e fragments written by edge_encode_f16x3.hip: [tile][t][u][hi|lo][lane][8 halves], 16 KiB per tile
+__device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, int tile, int lane, OpSet& P) {
+    const gamd_u32x4_t* ef = reinterpret_cast<const gamd_u32x4_t*>(e_frag) + (size_t)tile * 16 * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) P.w[t][u][p] = ef[((t * 2 + u) * 2 + p) * 64 + lane];
+}
+
+// One wave per SIMD (256-thread workgroups, the whole 512-entry register file per wave): the operand sets, the
+// accumulators and all gathered rows of a tile stay in registers without spilling, and every gather is issued a full
+// GEMM ahead of its use.  (Two waves per SIMD at 256 registers each spill ~100 registers and are slower.)
+__global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
+    constexpr int NW = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* buf0 = lds;
+    float* buf1 = lds + GAMD_WFRAG_FLOATS;
+    float* vb1 = buf1 + GAMD_WFRAG_FLOATS;
+    float* vb3 = vb1 + 128;
+    float* vb4 = vb3 + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, slot = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    int E = a.counters[CNT_E];
+    if ((long long)E > a.e_cap) E = (int)a.e_cap;
+    const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
+    // work unit = 4 tiles, one per wave / SIMD; units are dealt to the workgroups XCD by XCD (gamd_xcd_range)
+    const int n_units = (n_tiles + 3) / 4;
+    int first, end, step;
+    gamd_xcd_range(n_units, blockIdx.x, gridDim.x, first, end, step);
+    if (first >= end) return;
+    const int n_iter = (end - first + step - 1) / step;
+    auto tile_of = [&](int it) {              // this wave's tile in iteration `it`, or n_tiles (inactive)
+        const int u = first + it * step;
+        return (it < n_iter && u * 4 + wave < n_tiles) ? u * 4 + wave : n_tiles;
+    };
+
+    if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
+    stage_weight<NW>(a.w1p, buf0, wave, lane16);
+
+    // 64-register sets: two operand sets PA / PB alternate as GEMM input / output (the post-op of a phase writes its
+    // activation directly as the split operands of the next phase); RA = S[src], RC = D[dst] -> accumulators of
+    // phases 2 and 4 (piece sums), ACC = accumulators of phases 1 and 3, HN = hn[src] rows.
+    OpSet PA, PB;
+    f32x16 RA[4], RC[4], ACC[4];
+    f32x4 HN[16];                     // HN[r][tp] = hn[src of edge r][32 tp + slot]
+
+    int tile = tile_of(0);
+    bool active = tile < n_tiles;
+    int src = 0, dst = 0;
+    {
+        const int x = tile * GAMD_TILE + gamd_pi(slot);
+        if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
+        if (active) load_e_tile(a.e_frag, tile, lane, PA);
+    }
+    __syncthreads();
+    unsigned pend_ends = 0;           // piece stores of the tile just finished (issued after its last barrier)
+    int pend_p = 0;
+
+    for (int it = 0; it < n_iter; ++it) {
+        const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
+        int nvalid = E - x0;
+        nvalid = !active ? 0 : (nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid));
+        const int tile_n = tile_of(it + 1);
+        const bool active_n = tile_n < n_tiles;
+        int src_n = 0, dst_n = 0;
+
+        // ===== phase 1: T1 = SiLU(W1 e + b1) =====
+        stage_weight<NW>(a.w2p, buf1, wave, lane16);
+        unsigned mask = 0;
+        int p0 = 0;
+        if (active) {
+            // everything phase 2 and 4 gather for this tile is requested now, a GEMM or more ahead of its use
+            load_row_chain(a.S + (size_t)src * GAMD_H, half, RA);
+            load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
+            mask = a.chunk_mask[tile * 2 + half];
+            p0 = a.chunk_piece[tile * 2 + half];
+            load_bias_chain(vb1, half, ACC);
+            gemm128_f16x3_post<false, true>((const f16x8*)buf0, lane, PA, ACC, [&](int tp, int r0) {
+                put_pair(PB, tp, r0, gamd_silu_hw(ACC[tp][r0]), gamd_silu_hw(ACC[tp][r0 + 1]));
+            });
+        }
+        phase_barrier<0>();
+        // ===== phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]) =====
+        stage_weight<NW>(a.w3p, buf0, wave, lane16);
+        if (active) {
+            // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge); the source index of edge (half, r)
+            // lives in lane rho(r, half) of `src`.  hn rows are stored permuted (node.hip, hn_perm): features slot,
+            // 32 + slot, 64 + slot, 96 + slot are adjacent, so one 16-byte load per edge.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int s = __shfl(src, rho, 64);
+                HN[r] = *reinterpret_cast<const f32x4*>(a.hn + (size_t)s * GAMD_H + 4 * slot);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) RC[t] += RA[t];
+            gemm128_f16x3_post<false, true>((const f16x8*)buf1, lane, PB, RC, [&](int tp, int r0) {
+                put_pair(PA, tp, r0, gamd_silu_hw(RC[tp][r0]), gamd_silu_hw(RC[tp][r0 + 1]));
+            });
+        }
+        phase_barrier<0>();
+        // ===== phase 3: T4 = SiLU(W3 T3 + b3) =====
+        stage_weight<NW>(a.w4p, buf1, wave, lane16);
+        if (active_n) {
+            const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
+            if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
+        }
+        if (active) {
+            load_bias_chain(vb3, half, ACC);
+            gemm128_f16x3_post<false, true>((const f16x8*)buf0, lane, PA, ACC, [&](int tp, int r0) {
+                put_pair(PB, tp, r0, gamd_silu_hw(ACC[tp][r0]), gamd_silu_hw(ACC[tp][r0 + 1]));
+            });
+        }
+        phase_barrier<0>();
+        // ===== phase 4: e_emb = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
+        stage_weight<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
+        if (active_n) load_e_tile(a.e_frag, tile_n, lane, PA);       // PA is free since phase 3; lands during this GEMM
+        if (active) {
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const float b = vb4[32 * tp + slot];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) RC[tp][r] = b;
+            }
+            // message + segment sum (nn_module.py:142 u_mul_e -> sum), branch-free: RC[tp][r] becomes the running sum
+            // of the messages of the current piece (reset after every edge that closes a destination segment)
+            const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
+            gemm128_f16x3_post<true, true>((const f16x8*)buf1, lane, PB, RC, [&](int tp, int r0) {
+#pragma unroll
+                for (int r = r0; r < r0 + 2; ++r) {
+                    const float prod = (r < nvalid) ? HN[r][tp] * RC[tp][r] : 0.f;
+                    if (r == 0) RC[tp][0] = prod;
+                    else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
+                }
+            });
+            pend_ends = mask;
+            if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) pend_ends |= 1u << (nvalid - 1);
+            pend_p = p0;
+        }
+        phase_barrier<0>();
+        // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge does not close a
+        // segment, that edge too (the run continues in the next chunk as its own piece)
+        while (__any(pend_ends != 0)) {
+            if (pend_ends != 0) {
+                const int r = __builtin_ctz(pend_ends);
+                pend_ends &= pend_ends - 1;
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    float v = RC[tp][0];
+#pragma unroll
+                    for (int k = 1; k < 16; ++k) v = (r == k) ? RC[tp][k] : v;
+                    a.partial[(size_t)pend_p * GAMD_H + 32 * tp + slot] = v;
+                }
+                ++pend_p;
+            }
+        }
+        tile = tile_n; active = active_n; src = src_n; dst = dst_n;
+    }
+}
+
+}  // namespace
+
+int launch_conv_edge_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
+    const size_t lds = sizeof(float) * CONV_LDS_FLOATS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess) return (int)e1;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv_edge_f16x3, dim3(n_blocks), dim3(256), lds, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}

@@ -254,6 +254,35 @@ void pack_enc1_bf16(const float* W, int n_feat, uint16_t* out) {     // [tp][s][
                 }
 }
 
+// ---- split-fp16 packing (GAMD_EDGE_F16X3), layout of gamd_f16x3.h: [hi part | lo part] ------------------
+void split_f16(float w, uint16_t* hi, uint16_t* lo) {
+    const _Float16 h = (_Float16)w;                              // round to nearest even, subnormals kept
+    const _Float16 l = (_Float16)(w - (float)h);
+    memcpy(hi, &h, 2); memcpy(lo, &l, 2);
+}
+void pack128_f16x3(const float* W, uint16_t* out) {                // 2 x 16384 halves = 64 KiB
+    for (int tp = 0; tp < 4; ++tp)
+        for (int t = 0; t < 4; ++t)
+            for (int u = 0; u < 2; ++u)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 8 * u + j, half = lane >> 5;
+                        const int n = 32 * tp + (lane & 31), k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const size_t at = ((((tp * 4 + t) * 2 + u) * 64 + lane) * 8) + j;
+                        split_f16(W[n * 128 + k], out + at, out + 16384 + at);
+                    }
+}
+void pack_enc1_f16x3(const float* W, int n_feat, uint16_t* out) {   // 2 x [tp][s][lane][8], K padded to 48
+    for (int tp = 0; tp < 4; ++tp)
+        for (int s = 0; s < 3; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 32 * tp + (lane & 31), k = 16 * s + 8 * (lane >> 5) + j;
+                    const size_t at = (((tp * 3 + s) * 64 + lane) * 8) + j;
+                    split_f16(k < n_feat ? W[n * n_feat + k] : 0.f, out + at, out + 6144 + at);
+                }
+}
+
 struct BlobBuilder {
     std::vector<float> host;
     size_t add(size_t n_floats) {
@@ -339,7 +368,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.e_cap = h->e_cap;
     ea.feat_dbg = h->cfg.keep_stages ? h->feat_dbg.as<float>() : nullptr;
     r = h->wide_enc ? launch_edge_encode_wide(ea, h->EHT, h->n_cu, st)
-        : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_edge_encode_bf16(ea, h->n_cu, st) : launch_edge_encode(ea, h->n_cu, st);
+        : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_edge_encode_bf16(ea, h->n_cu, st)
+        : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_edge_encode_f16x3(ea, h->n_cu, st) : launch_edge_encode(ea, h->n_cu, st);
     if (r) return fail(-1, "edge encode launch failed (%d)", r);
     mark("edge_encode");
 
@@ -355,6 +385,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     no.row_ptr = h->row_ptr.as<int>(); no.na_excl = h->na_excl.as<int>(); no.deg = h->deg.as<int>();
     no.partial = h->partial.as<float>();
     no.P_in = h->P.as<float>();
+    no.hn_perm = (!h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F16X3) ? 1 : 0;
     no.hn_out = h->hn.as<float>(); no.S_out = h->S.as<float>(); no.D_out = h->D.as<float>(); no.P_out = h->P.as<float>();
     no.dec_w1p = h->dec_w1p; no.dec_b1 = h->dec_b1; no.dec_w2 = h->dec_w2; no.dec_b2 = h->dec_b2;
     no.scale = (float)std::sqrt(h->scaler_var);
@@ -389,7 +420,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
             HIP_TRY(hipEventRecord(h->tev[h->tev_used], st));
         }
         r = h->wide_conv ? launch_conv_edge_wide(ca, h->EHT, h->HT, h->n_cu, st)
-            : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st) : launch_conv_edge(ca, h->n_cu, st);
+            : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st)
+            : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3(ca, h->n_cu, st) : launch_conv_edge(ca, h->n_cu, st);
         if (r) return fail(-1, "conv edge launch failed (%d)", r);
         if (h->timing) { HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st)); h->tev_used += 2; }
         mark("conv_edge");
@@ -424,7 +456,8 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     if (cfg->n_atoms <= 0) return fail(-22, "n_atoms must be positive");
     if (cfg->n_layers <= 0 || cfg->n_layers > 16) return fail(-22, "n_layers out of range");
     if (!(cfg->cutoff > 0.f)) return fail(-22, "cutoff must be positive");
-    if (cfg->edge_dtype != GAMD_EDGE_F32 && cfg->edge_dtype != GAMD_EDGE_BF16) return fail(-22, "unknown edge_dtype");
+    if (cfg->edge_dtype != GAMD_EDGE_F32 && cfg->edge_dtype != GAMD_EDGE_BF16 && cfg->edge_dtype != GAMD_EDGE_F16X3)
+        return fail(-22, "unknown edge_dtype");
     if (!(cfg->neighbor_skin >= 0.f)) return fail(-22, "neighbor_skin must be >= 0");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -437,8 +470,8 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         return fail(-22, "encoding_size and edge_embedding_dim must be 128 or 256 (got %d, %d)", H, Eh);
     if (cfg->hidden_dim != 0 && cfg->hidden_dim != 128) return fail(-22, "hidden_dim must be 128 (got %d)", cfg->hidden_dim);
     const bool generic = H != 128 || Eh != 128 || cfg->no_expand_edge;
-    if (generic && cfg->edge_dtype == GAMD_EDGE_BF16)
-        return fail(-22, "the bf16 edge-MLP is built for the 128-wide RBF-expanded configuration only");
+    if (generic && cfg->edge_dtype != GAMD_EDGE_F32)
+        return fail(-22, "the bf16 and split-fp16 edge-MLPs are built for the 128-wide RBF-expanded configuration only");
     gamd_handle* h = new gamd_handle();
     h->cfg = *cfg;
     h->n = cfg->n_atoms;
@@ -446,7 +479,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
     h->skin = cfg->neighbor_skin;
     const char* force_wide = getenv("GAMD_FORCE_WIDE");      // test hook: run the 128-wide config on wide.hip
-    const bool forced = force_wide && force_wide[0] == '1' && cfg->edge_dtype != GAMD_EDGE_BF16;
+    const bool forced = force_wide && force_wide[0] == '1' && cfg->edge_dtype == GAMD_EDGE_F32;
     h->wide_enc = generic || forced;
     h->wide_conv = H != 128 || Eh != 128 || forced;
     h->n_feat = (cfg->no_expand_edge ? 4 : 44) + (cfg->use_bond ? 1 : 0);
@@ -547,6 +580,12 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         return o;
     };
     const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16;       // 128-wide only (gamd_create)
+    const bool f16x3_edges = h->cfg.edge_dtype == GAMD_EDGE_F16X3;     // 128-wide only (gamd_create)
+    auto put_edge_f16x3 = [&](const HostTensor* t) {
+        size_t o = bb.add(GAMD_WFRAG_FLOATS);
+        pack128_f16x3(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));
+        return o;
+    };
     auto put_edge_bf16 = [&](const HostTensor* t) {
         size_t o = bb.add(GAMD_WFRAG_FLOATS / 2);
         pack128_bf16(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));
@@ -573,6 +612,8 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         Off& o = lo[l];
         if (bf16_edges) {
             o.w1p = put_edge_bf16(ea0w); o.w2p = put_edge_bf16(ea2w); o.w3p = put_edge_bf16(t1w); o.w4p = put_edge_bf16(t3w);
+        } else if (f16x3_edges) {
+            o.w1p = put_edge_f16x3(ea0w); o.w2p = put_edge_f16x3(ea2w); o.w3p = put_edge_f16x3(t1w); o.w4p = put_edge_f16x3(t3w);
         } else {
             // one contiguous run of blocks: W1[:, kb] (EHT) | W2 | W3 | W4[ob, :] (HT) -- the order the kernels stream them
             o.w1p = put_blocks(ea0w, 1, (int)EHT);
@@ -602,9 +643,10 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         return -2;
     const size_t o_e1 = bb.add(4 * 6 * 64 * 4);
     if (bf16_edges) pack_enc1_bf16(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
+    else if (f16x3_edges) pack_enc1_f16x3(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
     else pack_enc1(e0w->data.data(), F, bb.host.data() + o_e1);
-    const size_t o_e2 = bf16_edges ? put_edge_bf16(e2w) : put_blocks(e2w, 1, 1);
-    const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : put_blocks(e4w, (int)EHT, 1);
+    const size_t o_e2 = bf16_edges ? put_edge_bf16(e2w) : f16x3_edges ? put_edge_f16x3(e2w) : put_blocks(e2w, 1, 1);
+    const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : f16x3_edges ? put_edge_f16x3(e4w) : put_blocks(e4w, (int)EHT, 1);
     const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(e4b), o_elg = put_vec(elg), o_elb = put_vec(elb);
     const size_t o_cen = expand ? put_vec(cen) : bb.add(64);
     const size_t o_d1 = put_blocks(d0w, 1, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);

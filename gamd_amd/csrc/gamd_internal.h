@@ -80,6 +80,7 @@ struct EncArgs {
 };
 int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st);
 int launch_edge_encode_bf16(const EncArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
+int launch_edge_encode_f16x3(const EncArgs& a, int n_blocks, hipStream_t st);  // w*p = [hi | lo] fp16 fragments, e_frag pre-split
 // generic widths (wide.hip): n_feat in {4, 5, 44, 45}; w3p = eht packed blocks W3[128 ob : 128 ob + 128, :],
 // b3 / ln_g / ln_b are [128 eht]; e_frag is [tiles][eht][4][4][64][4]
 int launch_edge_encode_wide(const EncArgs& a, int eht, int n_blocks, hipStream_t st);
@@ -103,6 +104,7 @@ struct ConvEdgeArgs {
 };
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
+int launch_conv_edge_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);  // w*p = [hi | lo] fp16 fragments (64 KiB)
 // generic widths (wide.hip): Eh = 128 eht, H = 128 ht.  w1p points at eht + 2 + ht contiguous packed blocks
 // W1[:, kb] | W2 | W3 | W4[ob, :]; b4 is [H]; hn and partial rows are H wide, S and D stay 128 wide
 int launch_conv_edge_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
@@ -139,6 +141,8 @@ struct NodeArgs {
     // outputs
     float* h_out;              // [n][128]
     float* hn_out; float* S_out; float* D_out; float* P_out;
+    int hn_perm;               // 1: hn rows are stored feature-permuted, position (f & 31) * 4 + (f >> 5), so that the
+                               // conv kernel's row-layout gather is one 16-byte load per edge (conv_edge_f16x3.hip)
     float* forces_norm;        // [n][3] normalised network output, ORIGINAL atom order (mode 2)
     float* forces;             // [n][3] denormalised fp32 (device MD loop), original order, or null
 };

@@ -167,7 +167,14 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mine[r] = (mine[r] - mean) * rstd * g[r] + b[r];
         }
-        if (valid) store_slice(a.hn_out + row, quarter, half, mine);
+        if (valid) {
+            if (a.hn_perm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a.hn_out[row + ((r & 3) + 8 * (r >> 2) + 4 * half) * 4 + quarter] = mine[r];
+            } else {
+                store_slice(a.hn_out + row, quarter, half, mine);
+            }
+        }
         exchange(xbuf, quarter, slot, half, mine, X);            // X = hn
         mine = load_slice(a.pre.bS, quarter, half);
         load_wquarter(a.pre.wdp, quarter, lane, wb);

@@ -71,7 +71,7 @@ class GamdForce:
         for d in range(3):
             c.box[d] = float(self.box[d])
         c.edge_capacity, c.keep_stages = int(edge_capacity), int(keep_stages)
-        c.edge_dtype = {"f32": 0, "bf16": 1}[edge_dtype]
+        c.edge_dtype = {"f32": 0, "bf16": 1, "f16x3": 2}[edge_dtype]
         c.encoding_size, c.edge_embedding_dim, c.hidden_dim = cfg.encoding_size, cfg.edge_embedding_dim, cfg.hidden_dim
         c.no_expand_edge = int(cfg.n_rbf == 0)
         c.neighbor_skin = float(neighbor_skin)      # > 0: Verlet-skin reuse (jax-md uses cutoff/6, graph_utils.py:24)
@@ -217,6 +217,21 @@ class GamdForce:
         """e [E, edge_embedding_dim] de-fragmented to CSR edge order."""
         e = self.counts()[0]
         nt = (e + 31) // 32
+        if self.edge_dtype == "f16x3":                   # pre-split fragments [tile][t][u][hi|lo][lane][8 halves]
+            raw = self._dbg(3, (nt, 4096), np.float32).view(np.float16).reshape(nt, 4, 2, 2, 64, 8).astype(np.float32)
+            val = raw[:, :, :, 0] + raw[:, :, :, 1]
+            lane = np.arange(64)
+            slot, half = lane & 31, lane >> 5
+            pi = 16 * ((slot >> 2) & 1) + (slot & 3) + 4 * (slot >> 3)
+            rows = (np.arange(nt)[:, None] * 32 + pi[None, :])
+            out = np.zeros((nt * 32, 128), dtype=np.float32)
+            for t in range(4):
+                for u in range(2):
+                    for j in range(8):
+                        r = 8 * u + j
+                        feat = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half
+                        out[rows, feat[None, :]] = val[:, t, u, :, j]
+            return out[:e]
         nb = self.cfg.edge_embedding_dim // 128
         frag = self._dbg(3, (nt, nb, 4, 4, 64, 4), np.float32)
         lane = np.arange(64)

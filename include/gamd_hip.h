@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct gamd_handle gamd_handle;
 
-enum { GAMD_EDGE_F32 = 0, GAMD_EDGE_BF16 = 1 };
+enum { GAMD_EDGE_F32 = 0, GAMD_EDGE_BF16 = 1, GAMD_EDGE_F16X3 = 2 };
 
 enum { GAMD_KIND_LJ = 0, GAMD_KIND_WATER = 1 };        /* SimpleMDNetNew | WaterMDNetNew / WaterMDDynamicBoxNet */
 enum { GAMD_NBR_JAXMD = 0, GAMD_NBR_TORCH = 1 };        /* dr^2 < rc^2 + self pair | |dr| <= rc, no self */
@@ -53,7 +53,9 @@ typedef struct gamd_config {
     int64_t edge_capacity;   /* 0 = estimate from density */
     int32_t keep_stages;     /* 1 = keep per-stage tensors for the debug getters */
     int32_t edge_dtype;      /* GAMD_EDGE_F32 (bit-exact fp32 MFMA, default) | GAMD_EDGE_BF16 (BASELINE config 5: edge-MLP
-                                operands rounded to bf16, fp32 accumulate; node side, S/D adds, SiLU, sums stay fp32) */
+                                operands rounded to bf16, fp32 accumulate; node side, S/D adds, SiLU, sums stay fp32)
+                                | GAMD_EDGE_F16X3 (fp32-grade edge-MLP on the fp16 matrix pipe: every operand split into
+                                hi + lo fp16, W x = Wh xh + (Wh xl + Wl xh), fp32 accumulate; same parity bar as F32) */
     int32_t encoding_size;   /* node width H: 0 (= 128), 128 or 256 (build_model 'encoding_size') */
     int32_t edge_embedding_dim; /* edge-embedding width Eh: 0 (= 128), 128 or 256 ('edge_embedding_dim') */
     int32_t hidden_dim;      /* 0 (= 128) or 128 ('hidden_dim') */

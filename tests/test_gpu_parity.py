@@ -23,12 +23,17 @@ def _engine(*a, **kw):
     return GamdForce(*a, **kw)
 
 
+@pytest.mark.parametrize("edge_dtype", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", ["lj258_seed0", "lj258_pert_seed1", "tip3p774_seed3"])
-def test_golden_stages_and_forces(name):
+def test_golden_stages_and_forces(name, edge_dtype):
+    """Every stage against the reference's own outputs, 1e-5 relative.  edge_dtype "f32": fp32 MFMA (bit-exact fp32
+    FMAs); "f16x3": the same GEMMs on the fp16 matrix pipe with every operand split into hi + lo fp16
+    (W x = Wh xh + Wh xl + Wl xh, fp32 accumulate) -- same goldens, same bar."""
     g, cfg, sd = load_golden(name)
     box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
     bond = g["bond"] if "bond" in g else None
-    eng = _engine(sd, n, box, rc, bond=bond, scaler=(g["scaler_mean"], g["scaler_var"]), keep_stages=True)
+    eng = _engine(sd, n, box, rc, bond=bond, scaler=(g["scaler_mean"], g["scaler_var"]), keep_stages=True,
+                  edge_dtype=edge_dtype)
     posw = np.mod(g["pos"], box).astype(np.float32)
     species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
     out = eng.forward(torch.from_numpy(posw), species=species).cpu().numpy()
@@ -494,3 +499,19 @@ def test_verlet_skin_in_the_md_loop_and_candidate_regrow():
     ref = _engine(sd, n, box, rc)
     assert rel_err(out, ref.forward(torch.from_numpy(pos).float()).cpu().numpy()) < TOL
     small.close(); ref.close()
+
+
+def test_split_fp16_at_c2_size_against_the_fp32_path():
+    n, rc = 10000, 10.2
+    pos, box = workloads.lj_box(n, seed=1234)
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    p = torch.from_numpy(pos).float()
+    a = _engine(sd, n, box, rc)
+    f32 = a.forward(p).cpu().numpy()
+    a.close()
+    b = _engine(sd, n, box, rc, edge_dtype="f16x3")
+    f16 = b.forward(p).cpu().numpy()
+    again = b.forward(p).cpu().numpy()
+    b.close()
+    assert np.array_equal(f16, again)                                  # bit-reproducible
+    assert rel_err(f16, f32) < TOL
