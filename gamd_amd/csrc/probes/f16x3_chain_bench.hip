@@ -22,6 +22,36 @@ __device__ __forceinline__ void put_pair(OpSet& P, int t, int r0, float x0, floa
     P.w[t][u][1][d] = __builtin_bit_cast(unsigned, l);
 }
 
+// the same with the instruction order pinned: every MFMA is followed by a slice of the previous tile's post-op VALU
+// work (a wave issues in order: VALU ops queued behind a stalled dependent MFMA cannot use the idle cycles)
+template <int NV, typename Post>
+__device__ __forceinline__ void gemm_post_sched(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4], Post post) {
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f16x8 wh = W[((tp * 4 + t) * 2 + u) * 64 + lane];
+                const f16x8 wl = W[2048 + ((tp * 4 + t) * 2 + u) * 64 + lane];
+                const f16x8 xh = __builtin_bit_cast(f16x8, P.w[t][u][0]), xl = __builtin_bit_cast(f16x8, P.w[t][u][1]);
+                acc[tp] = mfma_f16(wh, xl, acc[tp]);
+                acc[tp] = mfma_f16(wl, xh, acc[tp]);
+                acc[tp] = mfma_f16(wh, xh, acc[tp]);
+                if (tp > 0) {
+                    post(tp - 1, 2 * (t * 2 + u));
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) post(3, 2 * k);
+}
+
 template <typename Post>
 __device__ __forceinline__ void gemm_post(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4], Post post, bool pipelined) {
 #pragma unroll
@@ -96,6 +126,12 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ Wg, float*
                 }, true);
                 for (int t = 0; t < 4; ++t) for (int u = 0; u < 2; ++u) for (int p = 0; p < 2; ++p) PA.w[t][u][p] = PB.w[t][u][p];
                 if (MODE == 5) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+            } else if (MODE == 7 || MODE == 8 || MODE == 9) {
+                constexpr int NV = MODE == 7 ? 4 : (MODE == 8 ? 6 : 8);
+                gemm_post_sched<NV>((const f16x8*)cur, lane, PA, acc, [&](int tp, int r0) {
+                    put_pair(PB, tp, r0, gamd_silu_hw(acc[tp][r0]), gamd_silu_hw(acc[tp][r0 + 1]));
+                });
+                for (int t = 0; t < 4; ++t) for (int u = 0; u < 2; ++u) for (int p = 0; p < 2; ++p) PA.w[t][u][p] = PB.w[t][u][p];
             } else if (MODE == 4) {
                 gemm_post((const f16x8*)cur, lane, PA, acc, [&](int, int) {}, false);
 #pragma unroll
@@ -148,6 +184,9 @@ int main() {
         run<4>("mode4 GEMM + trailing SiLU/split", dW, dOut, iters, threads);
         run<5>("mode5 mode3 + barrier + 64 KiB restage per GEMM", dW, dOut, iters, threads);
         run<6>("mode6 t,u-outer GEMM, on-the-fly split, trailing SiLU", dW, dOut, iters, threads);
+        run<7>("mode7 mode3 with pinned order: MFMA + 4 VALU", dW, dOut, iters, threads);
+        run<8>("mode8 mode3 with pinned order: MFMA + 6 VALU", dW, dOut, iters, threads);
+        run<9>("mode9 mode3 with pinned order: MFMA + 8 VALU", dW, dOut, iters, threads);
     }
     return 0;
 }
