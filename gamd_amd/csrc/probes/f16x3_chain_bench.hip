@@ -52,6 +52,29 @@ __device__ __forceinline__ void gemm_post_sched(const f16x8* W, int lane, const 
     for (int k = 0; k < 8; ++k) post(3, 2 * k);
 }
 
+// explicit DEPTH-step-ahead register prefetch of the weight fragments (no post-op)
+template <int DEPTH>
+__device__ __forceinline__ void gemm_prefetch(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4]) {
+    f16x8 wh[DEPTH + 1], wl[DEPTH + 1];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { wh[d] = W[d * 64 + lane]; wl[d] = W[2048 + d * 64 + lane]; }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int tp = i >> 3, t = (i >> 1) & 3, u = i & 1;
+        if (i + DEPTH < 32) {
+            wh[(i + DEPTH) % (DEPTH + 1)] = W[(i + DEPTH) * 64 + lane];
+            wl[(i + DEPTH) % (DEPTH + 1)] = W[2048 + (i + DEPTH) * 64 + lane];
+        }
+        const f16x8 xh = __builtin_bit_cast(f16x8, P.w[t][u][0]), xl = __builtin_bit_cast(f16x8, P.w[t][u][1]);
+        const f16x8 a = wh[i % (DEPTH + 1)], b = wl[i % (DEPTH + 1)];
+        acc[tp] = mfma_f16(a, xl, acc[tp]);
+        acc[tp] = mfma_f16(b, xh, acc[tp]);
+        acc[tp] = mfma_f16(a, xh, acc[tp]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two ds_reads of step i + DEPTH
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // then this step's MFMAs
+    }
+}
+
 template <typename Post>
 __device__ __forceinline__ void gemm_post(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4], Post post, bool pipelined) {
 #pragma unroll
@@ -132,6 +155,10 @@ __global__ void __launch_bounds__(512, 2) k(const float* __restrict__ Wg, float*
                     put_pair(PB, tp, r0, gamd_silu_hw(acc[tp][r0]), gamd_silu_hw(acc[tp][r0 + 1]));
                 });
                 for (int t = 0; t < 4; ++t) for (int u = 0; u < 2; ++u) for (int p = 0; p < 2; ++p) PA.w[t][u][p] = PB.w[t][u][p];
+            } else if (MODE == 10 || MODE == 11 || MODE == 12) {
+                constexpr int DEPTH = MODE == 10 ? 1 : (MODE == 11 ? 2 : 4);
+                gemm_prefetch<DEPTH>((const f16x8*)cur, lane, Pin, acc);
+                PA.w[0][0][0][0] ^= __builtin_bit_cast(unsigned, acc[0][0]) & 1u;
             } else if (MODE == 4) {
                 gemm_post((const f16x8*)cur, lane, PA, acc, [&](int, int) {}, false);
 #pragma unroll
@@ -184,6 +211,9 @@ int main() {
         run<4>("mode4 GEMM + trailing SiLU/split", dW, dOut, iters, threads);
         run<5>("mode5 mode3 + barrier + 64 KiB restage per GEMM", dW, dOut, iters, threads);
         run<6>("mode6 t,u-outer GEMM, on-the-fly split, trailing SiLU", dW, dOut, iters, threads);
+        run<10>("mode10 mode1 with explicit 1-step weight prefetch", dW, dOut, iters, threads);
+        run<11>("mode11 mode1 with explicit 2-step weight prefetch", dW, dOut, iters, threads);
+        run<12>("mode12 mode1 with explicit 4-step weight prefetch", dW, dOut, iters, threads);
         run<7>("mode7 mode3 with pinned order: MFMA + 4 VALU", dW, dOut, iters, threads);
         run<8>("mode8 mode3 with pinned order: MFMA + 6 VALU", dW, dOut, iters, threads);
         run<9>("mode9 mode3 with pinned order: MFMA + 8 VALU", dW, dOut, iters, threads);
