@@ -82,7 +82,7 @@ def main():
                          "list uses 1/6, graph_utils.py:24, and so does the default here); 0 = exact cell-list rebuild "
                          "every step.  The edge set is identical either way (c2 workload only)")
     ap.add_argument("--edge-dtype", default="f32", choices=["f32", "f16x3"],
-                    help="c2 only. f32 (default, the headline): fp32 MFMA, bit-exact fp32 FMAs.  f16x3: the same GEMMs on the "
+                    help="c2 / c3. f32 (default, the headline): fp32 MFMA, bit-exact fp32 FMAs.  f16x3: the same GEMMs on the "
                          "fp16 matrix pipe with every operand split into hi + lo fp16 (3 MFMAs per product term, fp32 "
                          "accumulate): fp32-grade results (same 1e-5 parity bar), 3/16 of the fp32 matrix time")
     args = ap.parse_args()
@@ -137,7 +137,7 @@ def main():
         from gamd_amd import workloads as wk
         pos, box, species, bonds = water_box(nmol, mol_per_20A3=dens, seed=ens.box_seed(seed0, ctx), jitter=0.0, wrap=False)
         sd = make_state_dict(ModelConfig(kind="water", use_bond=True), 3, 2.9, 1.1)
-        dtype_name = "bf16" if args.workload == "c5" else "f32"
+        dtype_name = "bf16" if args.workload == "c5" else args.edge_dtype
         eng = GamdForce(sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS[scal], device=dev,
                         edge_dtype=dtype_name)
         n_atoms, mass = pos.shape[0], wk.MASS_O
@@ -203,7 +203,9 @@ def main():
                      "avg_launch_ms": avg_ms, "launches": conv_n,
                      "flop_per_launch": n_edges * flop_per_edge},
     }
-    if args.workload == "c2" and args.edge_dtype == "f16x3":
+    if args.workload in ("c2", "c3") and args.edge_dtype == "f16x3":
+        line["dtype"] = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)"
+        line["roofline"]["kernel"] = "k_conv_edge_f16x3"
         # every product term costs 3 fp16 MFMAs (Wh xh, Wh xl, Wl xh): the matrix pipe executes 3x the algorithmic FLOPs,
         # against the dense fp16 MFMA peak; the kernel is bound by LDS operand feed + VALU, not by that peak
         line["roofline"].update({"peak": 2500.0, "frac": achieved / 2500.0, "traffic": None,

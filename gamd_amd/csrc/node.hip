@@ -167,15 +167,20 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mine[r] = (mine[r] - mean) * rstd * g[r] + b[r];
         }
-        if (valid) {
-            if (a.hn_perm) {
+        if (valid && !a.hn_perm) store_slice(a.hn_out + row, quarter, half, mine);
+        exchange(xbuf, quarter, slot, half, mine, X);            // X = hn
+        if (a.hn_perm) {
+            // feature-permuted copy for the row-layout gather of conv_edge_f16x3.hip, written from the assembled rows
+            // in the exchange buffer: position 4 c + j holds feature 32 j + c, one coalesced 16-byte store per (atom, c)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a.hn_out[row + ((r & 3) + 8 * (r >> 2) + 4 * half) * 4 + quarter] = mine[r];
-            } else {
-                store_slice(a.hn_out + row, quarter, half, mine);
+            for (int k = 0; k < 4; ++k) {
+                const int idx = k * 256 + threadIdx.x, at = idx >> 5, c = idx & 31;
+                const float* xr = xbuf + at * XLD + c;
+                const f32x4 v = {xr[0], xr[32], xr[64], xr[96]};
+                const int atom_k = blockIdx.x * GAMD_TILE + at;
+                if (atom_k < a.n) *reinterpret_cast<f32x4*>(a.hn_out + (size_t)atom_k * GAMD_H + 4 * c) = v;
             }
         }
-        exchange(xbuf, quarter, slot, half, mine, X);            // X = hn
         mine = load_slice(a.pre.bS, quarter, half);
         load_wquarter(a.pre.wdp, quarter, lane, wb);
         gemm_quarter(wa, X, mine);
