@@ -1,0 +1,162 @@
+// conv_edge_small.hip — the conv-layer edge kernel for SMALL edge counts (the reference's own drivers run 258-atom LJ and
+// 774-atom water boxes: 200-800 tiles of 32 edges, a fraction of the 1024 SIMDs of the chip).
+//
+// conv_edge.hip gives every tile to one wave, which then runs the four 128x128 GEMMs of the layer back to back on one
+// SIMD: ~4 x 16 400 matrix cycles of pure latency when there is less than one tile per SIMD.  Here one 32-edge tile is
+// shared by the four waves of a 256-thread workgroup, each computing one 32-feature output block of every GEMM (64
+// MFMAs instead of 256, its 16 KiB weight quarter read straight from L2 one GEMM ahead), with the 128-wide activation
+// re-assembled through a 16.5 KiB LDS exchange buffer between the GEMMs — the scheme of node.hip applied to edges.
+// Same data, same order of floating-point operations per output element as conv_edge.hip (bias / D first, K in the same
+// order, then S, SiLU; same piece sums): the two kernels are bit-identical, so switching between them by size is
+// invisible in the results.
+#include "gamd_common.h"
+#include "gamd_internal.h"
+
+namespace {
+
+constexpr int XLD = 132;
+
+struct WQuarter { f32x4 w[16]; };
+
+__device__ __forceinline__ void load_wquarter(const float* __restrict__ Wp, int quarter, int lane, WQuarter& o) {
+    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 16 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o.w[i] = W[i * 64];
+}
+
+template <bool F2>
+__device__ __forceinline__ void gemm_quarter(const WQuarter& wq, const f32x16 (&X)[4], f32x16& acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = F2 ? mfma32(X[t][q * 4 + j], wq.w[t * 4 + q][j], acc) : mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
+}
+
+__device__ __forceinline__ f32x16 load_slice(const float* __restrict__ row, int quarter, int half) {
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 32 * quarter + 8 * q + 4 * half);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[q * 4 + j] = x[j];
+    }
+    return v;
+}
+
+__device__ __forceinline__ void exchange(float* xbuf, int quarter, int slot, int half, const f32x16& mine, f32x16 (&X)[4]) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = mine[q * 4 + j];
+        *reinterpret_cast<f32x4*>(xbuf + slot * XLD + 32 * quarter + 8 * q + 4 * half) = x;
+    }
+    __syncthreads();
+    load_row_chain(xbuf + slot * XLD, half, X);
+}
+
+__global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float xbuf[32 * XLD];
+    const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
+    const int quarter = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int E = a.counters[CNT_E];
+    if ((long long)E > a.e_cap) E = (int)a.e_cap;
+    const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int x = tile * GAMD_TILE + gamd_pi(slot);
+        const bool valid = x < E;
+        const int src = valid ? a.col[x] : 0;
+        const int dst = valid ? a.erow[x] : 0;
+        f32x16 X[4], acc;
+        WQuarter wa, wb;
+        load_wquarter(a.w1p, quarter, lane, wa);
+        {   // e tile in fragment order = chain layout registers
+            const f32x4* ef = (const f32x4*)a.e_frag + (size_t)tile * 16 * 64;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = ef[(t * 4 + q) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = v[j];
+                }
+        }
+        // rows this wave needs later: its quarter of S[src], D[dst]; hn[src] of its 16 edges x its 32 features
+        const f32x16 s_q = load_slice(a.S + (size_t)src * GAMD_H, quarter, half);
+        const f32x16 d_q = load_slice(a.D + (size_t)dst * GAMD_H, quarter, half);
+        f32x16 hn_q;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int s = __shfl(src, rho, 64);
+            hn_q[r] = a.hn[(size_t)s * GAMD_H + 32 * quarter + slot];
+        }
+        const unsigned mask = a.chunk_mask[tile * 2 + half];
+        int p = a.chunk_piece[tile * 2 + half];
+        const int x0 = tile * GAMD_TILE + 16 * half;
+        int nvalid = E - x0;
+        nvalid = nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid);
+
+        // phase 1: T1 = SiLU(W1 e + b1)
+        acc = load_slice(a.b1, quarter, half);
+        load_wquarter(a.w2p, quarter, lane, wb);
+        gemm_quarter<false>(wa, X, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = gamd_silu_hw(acc[r]);
+        exchange(xbuf, quarter, slot, half, acc, X);
+        // phase 2: T3 = SiLU((D[dst] + W2 T1) + S[src])
+        acc = d_q;
+        load_wquarter(a.w3p, quarter, lane, wa);
+        gemm_quarter<false>(wb, X, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = gamd_silu_hw(acc[r] + s_q[r]);
+        exchange(xbuf, quarter, slot, half, acc, X);
+        // phase 3: T4 = SiLU(W3 T3 + b3)
+        acc = load_slice(a.b3, quarter, half);
+        load_wquarter(a.w4p, quarter, lane, wb);
+        gemm_quarter<false>(wa, X, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = gamd_silu_hw(acc[r]);
+        exchange(xbuf, quarter, slot, half, acc, X);
+        // phase 4 (F2: lane = feature 32 quarter + slot, register = edge): e_emb, message, segment sum
+        {
+            const float b = a.b4[32 * quarter + slot];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = b;
+        }
+        gemm_quarter<true>(wb, X, acc);
+        const unsigned keep_bits = ~(mask << 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float prod = (r < nvalid) ? hn_q[r] * acc[r] : 0.f;
+            if (r == 0) acc[0] = prod;
+            else acc[r] = (((keep_bits >> r) & 1u) ? acc[r - 1] : 0.f) + prod;
+        }
+        unsigned ends = mask;
+        if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends |= 1u << (nvalid - 1);
+        while (__any(ends != 0)) {
+            if (ends != 0) {
+                const int r = __builtin_ctz(ends);
+                ends &= ends - 1;
+                float v = acc[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) v = (r == k) ? acc[k] : v;
+                a.partial[(size_t)p * GAMD_H + 32 * quarter + slot] = v;
+                ++p;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_conv_edge_small(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_conv_edge_small, dim3(n_blocks), dim3(256), 0, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}

@@ -65,6 +65,7 @@ struct gamd_handle {
     int n = 0, L = 0, n_feat = 44, n_cu = 256;
     int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width and their 128-blocks
     bool wide_enc = false, wide_conv = false;    // generic-width kernels of wide.hip
+    long long small_tile_limit = 512;            // fp32 path: at most this many 32-edge tiles -> conv_edge_small.hip
     std::map<std::string, HostTensor> host_w;
     bool finalized = false;
     double scaler_mean = 0.0, scaler_var = 1.0;
@@ -400,6 +401,15 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     if ((r = node(no))) return fail(-1, "node(0) launch failed (%d)", r);
     mark("node_first");
 
+    // fp32 path, few tiles (measured crossover ~500 tiles, half a tile per SIMD): the latency-oriented kernel, one tile per workgroup.  Both kernels are
+    // bit-identical, so the choice (from the last known edge count, or the density estimate before the first call) never
+    // shows in the results.
+    int small_tiles = 0;
+    if (!h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F32) {
+        const long long e_est = el ? el->n : (h->counters_host[CNT_E] > 0 ? (long long)h->counters_host[CNT_E] : (long long)((double)h->e_cap / 1.5));
+        const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
+        if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
+    }
     for (int l = 0; l < h->L; ++l) {
         ConvEdgeArgs ca{};
         ca.counters = h->counters.as<int>();
@@ -421,7 +431,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         }
         r = h->wide_conv ? launch_conv_edge_wide(ca, h->EHT, h->HT, h->n_cu, st)
             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st)
-            : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3(ca, h->n_cu, st) : launch_conv_edge(ca, h->n_cu, st);
+            : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3(ca, h->n_cu, st)
+            : small_tiles > 0 ? launch_conv_edge_small(ca, small_tiles, st) : launch_conv_edge(ca, h->n_cu, st);
         if (r) return fail(-1, "conv edge launch failed (%d)", r);
         if (h->timing) { HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st)); h->tev_used += 2; }
         mark("conv_edge");
@@ -478,6 +489,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     h->L = cfg->n_layers;
     h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
     h->skin = cfg->neighbor_skin;
+    if (const char* s = getenv("GAMD_CONV_SMALL_TILES")) h->small_tile_limit = atoll(s);     // tuning / test hook
     const char* force_wide = getenv("GAMD_FORCE_WIDE");      // test hook: run the 128-wide config on wide.hip
     const bool forced = force_wide && force_wide[0] == '1' && cfg->edge_dtype == GAMD_EDGE_F32;
     h->wide_enc = generic || forced;

@@ -515,3 +515,22 @@ def test_split_fp16_at_c2_size_against_the_fp32_path():
     b.close()
     assert np.array_equal(f16, again)                                  # bit-reproducible
     assert rel_err(f16, f32) < TOL
+
+
+def test_small_system_conv_kernel_is_bit_identical_to_the_throughput_kernel(monkeypatch):
+    """Below ~1 tile per SIMD the conv layer runs on conv_edge_small.hip (one tile shared by four waves).  Same
+    floating-point operation order per output element as conv_edge.hip: the outputs must be equal bit for bit."""
+    outs = {}
+    for name in ["lj258_seed0", "tip3p774_seed3"]:
+        g, cfg, sd = load_golden(name)
+        box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+        bond = g["bond"] if "bond" in g else None
+        posw = torch.from_numpy(np.mod(g["pos"], box).astype(np.float32))
+        species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
+        for limit in ("0", "1000000"):
+            monkeypatch.setenv("GAMD_CONV_SMALL_TILES", limit)
+            eng = _engine(sd, n, box, rc, bond=bond)
+            outs[limit] = eng.forward(posw, species=species).cpu().numpy().copy()
+            eng.close()
+        assert np.array_equal(outs["0"], outs["1000000"]), name
+        assert rel_err(outs["0"], g["out_norm"]) < TOL
