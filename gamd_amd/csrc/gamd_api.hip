@@ -405,7 +405,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     // bit-identical, so the choice (from the last known edge count, or the density estimate before the first call) never
     // shows in the results.
     int small_tiles = 0;
-    if (!h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F32) {
+    if (h->cfg.edge_dtype == GAMD_EDGE_F32) {
         const long long e_est = el ? el->n : (h->counters_host[CNT_E] > 0 ? (long long)h->counters_host[CNT_E] : (long long)((double)h->e_cap / 1.5));
         const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
         if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
@@ -429,7 +429,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
             }
             HIP_TRY(hipEventRecord(h->tev[h->tev_used], st));
         }
-        r = h->wide_conv ? launch_conv_edge_wide(ca, h->EHT, h->HT, h->n_cu, st)
+        r = h->wide_conv ? (small_tiles > 0 ? launch_conv_edge_small_wide(ca, h->EHT, h->HT, small_tiles, st)
+                                            : launch_conv_edge_wide(ca, h->EHT, h->HT, h->n_cu, st))
             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st)
             : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3(ca, h->n_cu, st)
             : small_tiles > 0 ? launch_conv_edge_small(ca, small_tiles, st) : launch_conv_edge(ca, h->n_cu, st);

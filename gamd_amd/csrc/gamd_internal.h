@@ -106,6 +106,7 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
 // small edge counts (conv_edge_small.hip): one tile per 4-wave workgroup, bit-identical to launch_conv_edge
 int launch_conv_edge_small(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
+int launch_conv_edge_small_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);   // = launch_conv_edge_wide
 int launch_conv_edge_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);  // w*p = [hi | lo] fp16 fragments (64 KiB)
 // generic widths (wide.hip): Eh = 128 eht, H = 128 ht.  w1p points at eht + 2 + ht contiguous packed blocks
 // W1[:, kb] | W2 | W3 | W4[ob, :]; b4 is [H]; hn and partial rows are H wide, S and D stay 128 wide

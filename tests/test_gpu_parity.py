@@ -534,3 +534,15 @@ def test_small_system_conv_kernel_is_bit_identical_to_the_throughput_kernel(monk
             eng.close()
         assert np.array_equal(outs["0"], outs["1000000"]), name
         assert rel_err(outs["0"], g["out_norm"]) < TOL
+    # the generic-width variant against wide.hip's conv kernel (DFT-water widths and a mixed one)
+    for name in ["dynbox384_dftcfg_seed5", "dynbox384_h128_e256_noexpand_seed8"]:
+        g, cfg, sd = load_golden(name)
+        n = g["pos"].shape[0]
+        species = g["node_feat"].reshape(-1) != 0
+        for limit in ("0", "1000000"):
+            monkeypatch.setenv("GAMD_CONV_SMALL_TILES", limit)
+            eng = _engine(sd, n, g["box"], float(g["cutoff"]), nbr_flavour="torch", cfg=cfg)
+            outs[limit] = eng.forward(torch.from_numpy(g["pos"]), box=g["box"], species=species).cpu().numpy().copy()
+            eng.close()
+        assert np.array_equal(outs["0"], outs["1000000"]), name
+        assert rel_err(outs["0"], g["out_norm"]) < TOL
