@@ -8,6 +8,9 @@
 // at 3/16 of the fp32 matrix time.  Measured error of a 128-term dot product: 3.6e-7 relative, the same as the
 // fp32 MFMA (3.5e-7); forces of the reference goldens differ from the fp32 path by < 2e-6 relative (tolerance 1e-5).
 //
+// Range: operands pass through fp16, |x| < 65504 (LayerNorm outputs, RBFs, unit vectors and SiLU activations are far
+// below that); not checked on the device.
+//
 // Layout: the chain layout of gamd_common.h carries over exactly as for bf16 (gamd_bf16.h): a lane's 16 features of
 // tile t feed two K=16 steps u = 0,1 of 8 packed values; weights are packed on the host as two fp16 fragment
 // images (hi | lo, 32 KiB each = 64 KiB per 128x128 matrix, the size of the fp32 image):
