@@ -87,3 +87,41 @@ def test_compat_water_bond_table():
     from gamd_amd.compat import create_water_bond
     b = create_water_bond(9)
     assert b.tolist() == [[0, 1], [0, 2], [3, 4], [3, 5], [6, 7], [6, 8]]
+
+
+def test_wide_and_unexpanded_specs_roundtrip():
+    """DFT-water widths (256/256/128 x 5) and expand_edge=False: spec, seeded weights and infer_config agree."""
+    from gamd_amd.weights import ModelConfig, make_state_dict, infer_config, state_dict_spec, validate_state_dict
+    for cfg in (ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5),
+                ModelConfig(kind="dynbox", n_rbf=0), ModelConfig(kind="water", use_bond=True, n_rbf=0)):
+        sd = make_state_dict(cfg, 4)
+        spec = state_dict_spec(cfg)
+        assert list(sd) == list(spec)
+        assert ("edge_expand.centers" in sd) == (cfg.n_rbf > 0)
+        assert sd["edge_encoder.mlp_layer.0.weight"].shape[1] == cfg.edge_in == 3 + 1 + cfg.n_rbf + int(cfg.use_bond)
+        got = infer_config(sd)
+        assert (got.encoding_size, got.hidden_dim, got.edge_embedding_dim, got.conv_layer, got.n_rbf, got.use_bond) == \
+               (cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim, cfg.conv_layer, cfg.n_rbf, cfg.use_bond)
+        validate_state_dict(sd, cfg)
+    # edge_affine's inner width is MLP's default 128 whatever hidden_dim is (nn_module.py:25,95)
+    wide = state_dict_spec(ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256))
+    assert wide["graph_conv.conv.0.edge_affine.mlp_layer.0.weight"] == (128, 256)
+    assert wide["graph_conv.conv.0.theta_edge.mlp_layer.3.weight"] == (256, 128)
+
+
+def test_compat_wrappers_are_lazy_and_mirror_the_reference_signatures():
+    """Constructing the Lightning-shaped wrappers needs no GPU; the engine is created on first use."""
+    import inspect
+    from types import SimpleNamespace
+    from gamd_amd.compat import ParticleNetLightningLJ, ParticleNetLightningWater, ParticleNetLightningDFT
+    lj = ParticleNetLightningLJ(SimpleNamespace())
+    assert list(inspect.signature(lj.predict_forces).parameters) == ["pos", "verbose"]          # train_network_lj.py:133
+    w = ParticleNetLightningWater(SimpleNamespace())
+    assert list(inspect.signature(w.predict_forces).parameters) == ["feat", "pos"]              # train_network_tip3p.py:142
+    d = ParticleNetLightningDFT(SimpleNamespace(cutoff=9.5))
+    assert list(inspect.signature(d.predict_forces).parameters) == ["feat", "pos", "box_size"]  # train_network_real_large.py:148
+    assert d.cutoff == 9.5 and d._nbr_flavour == "torch" and d._skin == 0.0
+    assert lj._skin == lj.cutoff / 6.0                                                          # graph_utils.py:24
+    assert lj.cuda() is lj and lj.eval() is lj
+    with pytest.raises(RuntimeError, match="no weights"):
+        lj._get_engine()
