@@ -49,14 +49,16 @@ __device__ __forceinline__ void put_pair(OpSet& P, int t, int r0, float x0, floa
 // 128x128 split-fp16 GEMM, output tile by output tile (24 back-to-back MFMAs per accumulator).  PIPE: the
 // element-wise post-op of the PREVIOUS output tile is issued between the K steps of the current one (post(tp, r0)
 // handles elements r0, r0+1 of acc[tp]); otherwise all post-ops trail the GEMM.
-template <bool F2, bool PIPE, typename Post>
-__device__ __forceinline__ void gemm128_f16x3_post(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4], Post post) {
+template <bool F2, bool PIPE, typename Post, typename Step>
+__device__ __forceinline__ void gemm128_f16x3_post(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4], Post post,
+                                                   Step step) {
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                step((tp * 4 + t) * 2 + u);              // K step 0..31: hook for work that rides in the MFMA shadow
                 const f16x8 wh = W[((tp * 4 + t) * 2 + u) * 64 + lane];
                 const f16x8 wl = W[2048 + ((tp * 4 + t) * 2 + u) * 64 + lane];
                 const f16x8 xh = __builtin_bit_cast(f16x8, P.w[t][u][0]), xl = __builtin_bit_cast(f16x8, P.w[t][u][1]);
@@ -78,6 +80,25 @@ __device__ __forceinline__ void gemm128_f16x3_post(const f16x8* W, int lane, con
         for (int k = 0; k < 8; ++k) post(tp, 2 * k);
 }
 
+// one 1 KiB piece (k = 0 .. 64/NW - 1 for this wave) of the same copy, to be issued between MFMAs: with one wave per
+// SIMD the ~100 cycles each LDS-DMA instruction takes to issue are otherwise dead time of the matrix pipe
+template <int NW>
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16, int k) {
+    asm volatile("" : "+v"(lane16));
+    const int chunk = k * NW + wave;
+    const char* base = reinterpret_cast<const char*>(gw) + chunk * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane16),
+                                     (__attribute__((address_space(3))) void*)(ldsbuf + chunk * 256), 16, 0, 0);
+}
+
+// piece i (0..15) of load_row_chain / load_e_tile, so that a gather can be spread over the K steps of a GEMM
+__device__ __forceinline__ void load_row_piece(const float* __restrict__ row, int half, f32x16 (&X)[4], int i) {
+    const int t = i >> 2, q = i & 3;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 32 * t + 8 * q + 4 * half);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = v[j];
+}
+
 // End of a phase: every wave has its own weight DMA (issued at the phase start, before the N most
 // recent VMEM loads) landed, then the workgroup meets.  The N prefetch loads stay in flight.
 // vmcnt retires in order, so "at most N outstanding" proves the older DMA is done only if at least
@@ -97,6 +118,10 @@ __device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, in
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int p = 0; p < 2; ++p) P.w[t][u][p] = ef[((t * 2 + u) * 2 + p) * 64 + lane];
+}
+__device__ __forceinline__ void load_e_piece(const float* __restrict__ e_frag, int tile, int lane, OpSet& P, int i) {
+    const gamd_u32x4_t* ef = reinterpret_cast<const gamd_u32x4_t*>(e_frag) + (size_t)tile * 16 * 64;
+    P.w[i >> 2][(i >> 1) & 1][i & 1] = ef[i * 64 + lane];
 }
 
 // One wave per SIMD (256-thread workgroups, the whole 512-entry register file per wave): the operand sets, the
@@ -159,42 +184,47 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         int src_n = 0, dst_n = 0;
 
         // ===== phase 1: T1 = SiLU(W1 e + b1) =====
-        stage_weight<NW>(a.w2p, buf1, wave, lane16);
         unsigned mask = 0;
         int p0 = 0;
         if (active) {
-            // everything phase 2 and 4 gather for this tile is requested now, a GEMM or more ahead of its use
-            load_row_chain(a.S + (size_t)src * GAMD_H, half, RA);
-            load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
+            // All memory instructions of the iteration ride between the MFMAs of the GEMMs (step hooks): with one wave
+            // per SIMD every VMEM issue stall is otherwise dead time of the matrix pipe.  S[src], D[dst] (phase 2) here.
+            const float* srow = a.S + (size_t)src * GAMD_H;
+            const float* drow = a.D + (size_t)dst * GAMD_H;
             mask = a.chunk_mask[tile * 2 + half];
             p0 = a.chunk_piece[tile * 2 + half];
             load_bias_chain(vb1, half, ACC);
             gemm128_f16x3_post<false, true>((const f16x8*)buf0, lane, PA, ACC, [&](int tp, int r0) {
                 put_pair(PB, tp, r0, gamd_silu_hw(ACC[tp][r0]), gamd_silu_hw(ACC[tp][r0 + 1]));
+            }, [&](int i) {
+                if (i < 16) stage_chunk<NW>(a.w2p, buf1, wave, lane16, i);
+                else { load_row_piece(srow, half, RA, i - 16); load_row_piece(drow, half, RC, i - 16); }
             });
+        } else {
+            stage_weight<NW>(a.w2p, buf1, wave, lane16);
         }
-        phase_barrier<0>();
+        if (active) phase_barrier<32>(); else phase_barrier<0>();     // S/D gathers (issued after the DMA) stay in flight
         // ===== phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]) =====
-        stage_weight<NW>(a.w3p, buf0, wave, lane16);
+        if (!active) stage_weight<NW>(a.w3p, buf0, wave, lane16);
         if (active) {
-            // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge); the source index of edge (half, r)
-            // lives in lane rho(r, half) of `src`.  hn rows are stored permuted (node.hip, hn_perm): features slot,
-            // 32 + slot, 64 + slot, 96 + slot are adjacent, so one 16-byte load per edge.
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int s = __shfl(src, rho, 64);
-                HN[r] = *reinterpret_cast<const f32x4*>(a.hn + (size_t)s * GAMD_H + 4 * slot);
-            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) RC[t] += RA[t];
             gemm128_f16x3_post<false, true>((const f16x8*)buf1, lane, PB, RC, [&](int tp, int r0) {
                 put_pair(PA, tp, r0, gamd_silu_hw(RC[tp][r0]), gamd_silu_hw(RC[tp][r0 + 1]));
+            }, [&](int i) {
+                if (i < 16) { stage_chunk<NW>(a.w3p, buf0, wave, lane16, i); return; }
+                // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge); the source index of edge (half, r)
+                // lives in lane rho(r, half) of `src`.  hn rows are stored permuted (node.hip, hn_perm): features slot,
+                // 32 + slot, 64 + slot, 96 + slot are adjacent, so one 16-byte load per edge.
+                const int r = i - 16;
+                const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int sr = __shfl(src, rho, 64);
+                HN[r] = *reinterpret_cast<const f32x4*>(a.hn + (size_t)sr * GAMD_H + 4 * slot);
             });
         }
-        phase_barrier<0>();
+        if (active) phase_barrier<16>(); else phase_barrier<0>();     // hn gathers stay in flight
         // ===== phase 3: T4 = SiLU(W3 T3 + b3) =====
-        stage_weight<NW>(a.w4p, buf1, wave, lane16);
+        if (!active) stage_weight<NW>(a.w4p, buf1, wave, lane16);
         if (active_n) {
             const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
             if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
@@ -203,12 +233,12 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
             load_bias_chain(vb3, half, ACC);
             gemm128_f16x3_post<false, true>((const f16x8*)buf0, lane, PA, ACC, [&](int tp, int r0) {
                 put_pair(PB, tp, r0, gamd_silu_hw(ACC[tp][r0]), gamd_silu_hw(ACC[tp][r0 + 1]));
-            });
+            }, [&](int i) { if (i < 16) stage_chunk<NW>(a.w4p, buf1, wave, lane16, i); });
         }
         phase_barrier<0>();
         // ===== phase 4: e_emb = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
-        stage_weight<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
-        if (active_n) load_e_tile(a.e_frag, tile_n, lane, PA);       // PA is free since phase 3; lands during this GEMM
+        if (!active) stage_weight<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
+        if (active_n && !active) load_e_tile(a.e_frag, tile_n, lane, PA);
         if (active) {
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {
@@ -226,12 +256,15 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
                     if (r == 0) RC[tp][0] = prod;
                     else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
                 }
+            }, [&](int i) {
+                if (i < 16) stage_chunk<NW>(a.w1p, buf0, wave, lane16, i);
+                else if (active_n) load_e_piece(a.e_frag, tile_n, lane, PA, i - 16);    // PA is free since phase 3
             });
             pend_ends = mask;
             if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) pend_ends |= 1u << (nvalid - 1);
             pend_p = p0;
         }
-        phase_barrier<0>();
+        if (active && active_n) phase_barrier<16>(); else phase_barrier<0>();   // next e tile stays in flight
         // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge does not close a
         // segment, that edge too (the run continues in the next chunk as its own piece)
         while (__any(pend_ends != 0)) {
