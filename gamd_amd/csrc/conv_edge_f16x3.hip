@@ -9,13 +9,11 @@
 #include "gamd_f16x3.h"
 #include "gamd_internal.h"
 
-#include <cstdlib>
-
 namespace {
 
 constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
 
-// L2 -> LDS copy of one packed 64 KiB weight matrix, 8 x 1 KiB per wave.  lane16 is made opaque so
+// L2 -> LDS copy of one packed 64 KiB weight matrix, 64 / NW x 1 KiB per wave.  lane16 is made opaque so
 // the 64-bit addresses are rebuilt (1 VALU each) instead of being hoisted out of the tile loop and
 // spilled (a spilled pointer = scratch reload + s_waitcnt vmcnt(0) in front of every copy).
 template <int NW>
@@ -46,10 +44,10 @@ __device__ __forceinline__ void put_pair(OpSet& P, int t, int r0, float x0, floa
     P.w[t][u][1][d] = __builtin_bit_cast(unsigned, l);
 }
 
-// 128x128 split-fp16 GEMM, output tile by output tile (24 back-to-back MFMAs per accumulator).  PIPE: the
-// element-wise post-op of the PREVIOUS output tile is issued between the K steps of the current one (post(tp, r0)
-// handles elements r0, r0+1 of acc[tp]); otherwise all post-ops trail the GEMM.
-template <bool F2, bool PIPE, typename Post, typename Step>
+// 128x128 split-fp16 GEMM, output tile by output tile (24 back-to-back MFMAs per accumulator).  The element-wise
+// post-op of the PREVIOUS output tile is issued between the K steps of the current one (post(tp, r0) handles elements
+// r0, r0+1 of acc[tp]); step(i) is called in front of K step i = 0..31 for work that should ride in the MFMA shadow.
+template <bool F2, typename Post, typename Step>
 __device__ __forceinline__ void gemm128_f16x3_post(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4], Post post,
                                                    Step step) {
 #pragma unroll
@@ -71,13 +69,11 @@ __device__ __forceinline__ void gemm128_f16x3_post(const f16x8* W, int lane, con
                     acc[tp] = mfma_f16(wl, xh, acc[tp]);
                     acc[tp] = mfma_f16(wh, xh, acc[tp]);
                 }
-                if (PIPE && tp > 0) post(tp - 1, 2 * (t * 2 + u));
+                if (tp > 0) post(tp - 1, 2 * (t * 2 + u));
             }
     }
 #pragma unroll
-    for (int tp = PIPE ? 3 : 0; tp < 4; ++tp)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) post(tp, 2 * k);
+    for (int k = 0; k < 8; ++k) post(3, 2 * k);
 }
 
 // one 1 KiB piece (k = 0 .. 64/NW - 1 for this wave) of the same copy, to be issued between MFMAs: with one wave per
@@ -194,7 +190,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
             mask = a.chunk_mask[tile * 2 + half];
             p0 = a.chunk_piece[tile * 2 + half];
             load_bias_chain(vb1, half, ACC);
-            gemm128_f16x3_post<false, true>((const f16x8*)buf0, lane, PA, ACC, [&](int tp, int r0) {
+            gemm128_f16x3_post<false>((const f16x8*)buf0, lane, PA, ACC, [&](int tp, int r0) {
                 put_pair(PB, tp, r0, gamd_silu_hw(ACC[tp][r0]), gamd_silu_hw(ACC[tp][r0 + 1]));
             }, [&](int i) {
                 if (i < 16) stage_chunk<NW>(a.w2p, buf1, wave, lane16, i);
@@ -209,7 +205,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         if (active) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) RC[t] += RA[t];
-            gemm128_f16x3_post<false, true>((const f16x8*)buf1, lane, PB, RC, [&](int tp, int r0) {
+            gemm128_f16x3_post<false>((const f16x8*)buf1, lane, PB, RC, [&](int tp, int r0) {
                 put_pair(PA, tp, r0, gamd_silu_hw(RC[tp][r0]), gamd_silu_hw(RC[tp][r0 + 1]));
             }, [&](int i) {
                 if (i < 16) { stage_chunk<NW>(a.w3p, buf0, wave, lane16, i); return; }
@@ -231,14 +227,13 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         }
         if (active) {
             load_bias_chain(vb3, half, ACC);
-            gemm128_f16x3_post<false, true>((const f16x8*)buf0, lane, PA, ACC, [&](int tp, int r0) {
+            gemm128_f16x3_post<false>((const f16x8*)buf0, lane, PA, ACC, [&](int tp, int r0) {
                 put_pair(PB, tp, r0, gamd_silu_hw(ACC[tp][r0]), gamd_silu_hw(ACC[tp][r0 + 1]));
             }, [&](int i) { if (i < 16) stage_chunk<NW>(a.w4p, buf1, wave, lane16, i); });
         }
         phase_barrier<0>();
         // ===== phase 4: e_emb = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
         if (!active) stage_weight<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
-        if (active_n && !active) load_e_tile(a.e_frag, tile_n, lane, PA);
         if (active) {
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {
@@ -249,7 +244,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
             // message + segment sum (nn_module.py:142 u_mul_e -> sum), branch-free: RC[tp][r] becomes the running sum
             // of the messages of the current piece (reset after every edge that closes a destination segment)
             const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
-            gemm128_f16x3_post<true, true>((const f16x8*)buf1, lane, PB, RC, [&](int tp, int r0) {
+            gemm128_f16x3_post<true>((const f16x8*)buf1, lane, PB, RC, [&](int tp, int r0) {
 #pragma unroll
                 for (int r = r0; r < r0 + 2; ++r) {
                     const float prod = (r < nvalid) ? HN[r][tp] * RC[tp][r] : 0.f;

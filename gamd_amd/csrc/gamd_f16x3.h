@@ -23,8 +23,6 @@ typedef _Float16 gamd_f16x2 __attribute__((ext_vector_type(2)));
 typedef float gamd_f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned gamd_u32x4_t __attribute__((ext_vector_type(4)));
 
-#define GAMD_WFRAG_F16_HALVES (GAMD_H * GAMD_H)          // one part (hi or lo) of a packed matrix: 16384 halves = 32 KiB
-
 // 8 consecutive registers of a chain-layout block -> (hi, lo) operand pair of one K step
 __device__ __forceinline__ void gamd_split8(const f32x16& v, int u, f16x8& hi, f16x8& lo) {
 #pragma unroll
@@ -75,14 +73,4 @@ __device__ __forceinline__ void gemm128_f16x3(const f16x8* W, int lane, const f3
             gamd_split8(X[t], u, xh, xl);
             gamd_f16x3_step<F2>(W, lane, t, u, xh, xl, acc);
         }
-}
-
-// the same with operands that were split by the producer (e fragments written by the edge encoder):
-// P[t][u][0] = hi, P[t][u][1] = lo
-template <bool F2>
-__device__ __forceinline__ void gemm128_f16x3_presplit(const f16x8* W, int lane, const f16x8 (&P)[4][2][2], f32x16 (&acc)[4]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) gamd_f16x3_step<F2>(W, lane, t, u, P[t][u][0], P[t][u][1], acc);
 }
