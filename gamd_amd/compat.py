@@ -63,10 +63,11 @@ class _ModelLevel:
 
 class _ForceFieldBase:
     def __init__(self, args=None, state_dict=None, *, num_atoms: int, box_size, cutoff: float,
-                 bond=None, scaler_ckpt: Optional[str] = None, device: int = 0):
+                 bond=None, scaler_ckpt: Optional[str] = None, device: int = 0, edge_dtype: str = "f32"):
         self.args = args or SimpleNamespace()
         self.num_atoms, self.box_size, self.cutoff = int(num_atoms), box_size, float(cutoff)
         self.bond, self.device_index = bond, device
+        self.edge_dtype = edge_dtype                 # "f32" (default) | "f16x3" (fp32-grade split-fp16 GEMMs) | "bf16"
         self._nbr_flavour = "jaxmd"                  # graph_utils.NeighborSearcher semantics ('<' on r^2, self edge kept)
         self._skin = self.cutoff / 6.0               # its dr_threshold (graph_utils.py:24): candidate list reused
                                                      # between calls, exact cutoff re-applied every call
@@ -108,7 +109,8 @@ class _ForceFieldBase:
                 raise RuntimeError("no weights loaded: call load_from_checkpoint / load_state_dict first")
             self._engine = GamdForce(self._sd, self.num_atoms, self.box_size, self.cutoff, bond=self.bond,
                                      scaler=(self.training_mean, self.training_var), device=self.device_index,
-                                     nbr_flavour=self._nbr_flavour, neighbor_skin=self._skin)
+                                     nbr_flavour=self._nbr_flavour, neighbor_skin=self._skin,
+                                     edge_dtype=self.edge_dtype)
         return self._engine
 
     def denormalize(self, normalized_force, var, mean):

@@ -75,6 +75,10 @@ def test_compat_predict_forces_matches_reference_api():
     w.training_mean, w.training_var = g["scaler_mean"], g["scaler_var"]
     fw = w.predict_forces(torch.from_numpy(g["node_feat"]).cuda(), g["pos"])
     assert fw.dtype == np.float64 and rel_err(fw, g["forces"]) < TOL
+    # the opt-in split-fp16 GEMMs through the same wrapper: same golden, same bar
+    w16 = ParticleNetLightningWater(state_dict=sd, edge_dtype="f16x3")
+    w16.training_mean, w16.training_var = g["scaler_mean"], g["scaler_var"]
+    assert rel_err(w16.predict_forces(torch.from_numpy(g["node_feat"]).cuda(), g["pos"]), g["forces"]) < TOL
 
 
 def test_compat_dft_predict_forces_takes_the_box_per_call():
