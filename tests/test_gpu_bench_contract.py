@@ -41,3 +41,9 @@ def test_split_fp16_line_is_labelled_as_such():
     d = _run("--no-cpu-baseline", "--edge-dtype", "f16x3")
     assert d["dtype"].startswith("f16x3") and d["roofline"]["kernel"] == "k_conv_edge_f16x3"
     assert d["roofline"]["peak"] == 2500.0 and d["roofline"]["frac"] < 1.0
+
+
+def test_graft_entry_smoke_runs():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.smoke()
