@@ -3,173 +3,346 @@
 
 One "step" = one MD step of one 10 000-atom LJ box (config C2): BAOAB first half ->
 neighbour build + full GNN force evaluation -> BAOAB second half, all on device, inputs
-resident in HBM.  N GPUs = N independent boxes (ensemble, weak scaling), launched as
-`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+resident in HBM.  N GPUs = N independent boxes (ensemble, weak scaling, no collective on
+the step path).
+
+`python bench.py --gpus N ...` launches the N ranks itself (one child process per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before this process touches any GPU) and
+relays rank 0's line; under `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` it joins the ranks torchrun started.  Either way it fails loudly when the
+world size and --gpus disagree or when fewer than N devices are visible.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      live HIP-event timing of the dominant kernel (conv-layer edge kernel) in the timed region
-  cpu_baseline  the CPU oracle (port of the reference's PyTorch path) timed on this host (N=1 only)
+  roofline      live HIP-event timing of the dominant kernel (conv-layer edge kernel) over the timed
+                region, plus a `kernels` list (edge encoder, node kernel, neighbour stage) from
+                event-timed replays after it
+  cpu_baseline  the CPU oracle (port of the reference's PyTorch path) timed on this host on the
+                SAME 10 000-atom inputs and weights (N=1 only)
+  secondary     short runs of the other single-GPU BASELINE configs (C1, C3, C5) (N=1 only)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
-from gamd_amd import ensemble as ens
-from gamd_amd.engine import GamdForce
-from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS
-from gamd_amd.workloads import lj_box, maxwell_boltzmann, LJ_SIGMA
-
 N_ATOMS = 10000
-CUTOFF = 3.0 * LJ_SIGMA
 FLOP_PER_EDGE_CONV = 8 * 128 * 128          # 4 GEMMs 128x128 per edge per conv-edge launch
 PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-
-
+PEAK_HBM_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E spec peak
 CPU_SAMPLE_ATOMS = 2000
+# the files whose contents decide k_conv_edge's memory traffic: profiles/pmc_conv_edge.json is stamped with their hash
+PMC_SOURCES = ("gamd_amd/csrc/conv_edge.hip", "gamd_amd/csrc/gamd_common.h", "gamd_amd/csrc/gamd_internal.h",
+               "gamd_amd/csrc/neighbor.hip")
 
 
-def cpu_baseline(sd, dev):
-    """Time the oracle's forward (op-for-op port of nn_module.py, unfused nn.Linear on E gathered rows,
-    index_add_ aggregation) on the host cores, on a BOUNDED sample of the workload: a 2 000-atom LJ box of
-    the same density / cutoff / weights (cost is linear in atoms: ~64 edges per atom either way).
-    torch's CPU kernels stop scaling long before this host's core count, so a few thread counts are
-    tried and the best is reported with the threads it used.  Checker code, used as a *reported
-    baseline only*; the same sample is also evaluated on the GPU as a parity check."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import gamd_oracle as orc
-    pos, box = lj_box(CPU_SAMPLE_ATOMS, seed=4321)
-    p = torch.from_numpy(pos).float()
-    edges = orc.neighbor_edges(p, box, CUTOFF, "jaxmd")
-    best, best_thr, out = None, None, None
-    ncpu = os.cpu_count() or 1
-    for thr in sorted({min(ncpu, t) for t in (8, 16, 32)}):
-        torch.set_num_threads(thr)
-        orc.forward(sd, p, edges, box)                  # warm-up
-        for _ in range(2):
-            t0 = time.perf_counter()
-            out = orc.forward(sd, p, edges, box)
-            dt = time.perf_counter() - t0
-            if best is None or dt < best:
-                best, best_thr = dt, thr
-    eng = GamdForce(sd, CPU_SAMPLE_ATOMS, box, CUTOFF, device=dev)
-    gpu = eng.forward(p).cpu().numpy()
-    same_edges = eng.counts()[0] == edges.shape[1]
-    eng.close()
-    err = float(np.abs(gpu - out.numpy()).max() / np.abs(out.numpy()).max())
-    return best, best_thr, int(edges.shape[1]), err, same_edges
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for rel in PMC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "dft"],
-                    help="c2 (default, the headline metric): 10k-atom LJ fp32; c3: 4 170-atom TIP3P fp32; "
-                         "c5: 6 000-network-atom TIP4P-Ew-sized box, bf16 edge-MLP; dft: the 774-atom DFT-water "
-                         "configuration (256/256/128 x 5 layers, bohr, cutoff 9.5)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short C1/C3/C5 runs and the per-kernel replays")
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "c5b", "dft"],
+                    help="c2 (default, the headline metric): 10k-atom LJ fp32; c1: 258-atom LJ box (the reference's own "
+                         "driver size); c3: 4 170-atom TIP3P fp32; c5: TIP4P-Ew-sized box of 2 000 molecules = 6 000 network "
+                         "atoms, bf16 edge-MLP; c5b: the other reading of BASELINE config 5, 2 667 molecules = 8 001 network "
+                         "atoms; dft: the 774-atom DFT-water configuration (256/256/128 x 5 layers, bohr, cutoff 9.5)")
     ap.add_argument("--skin", type=float, default=1.0 / 6.0,
                     help="Verlet-skin reuse of the neighbour candidates, in units of the cutoff (the reference's jax-md "
                          "list uses 1/6, graph_utils.py:24, and so does the default here); 0 = exact cell-list rebuild "
-                         "every step.  The edge set is identical either way (c2 workload only)")
+                         "every step.  The edge set is identical either way (LJ workloads only)")
     ap.add_argument("--edge-dtype", default="f32", choices=["f32", "f16x3"],
                     help="c2 / c3. f32 (default, the headline): fp32 MFMA, bit-exact fp32 FMAs.  f16x3: the same GEMMs on the "
                          "fp16 matrix pipe with every operand split into hi + lo fp16 (3 MFMAs per product term, fp32 "
                          "accumulate): fp32-grade results (same 1e-5 parity bar), 3/16 of the fp32 matrix time")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 without torchrun: this process only spawns and relays; it never initialises a GPU
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    import torch                                   # device_count() does not initialise the GPU on this stack
+    share = os.environ.get("GAMD_BENCH_SHARE_GPU", "0") == "1"
+    ndev = torch.cuda.device_count()
+    if not share and ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) are visible "
+              "(set GAMD_BENCH_SHARE_GPU=1 GAMD_BENCH_BACKEND=gloo for a control-flow dry run on one GPU)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = ""
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:                            # exact PIDs of our own children only
+            if p.poll() is None:
+                p.kill()
+    if rc != 0:
+        print(f"bench.py: a rank exited with status {rc}", file=sys.stderr)
+        return rc or 1
+    lines = [l for l in out0.splitlines() if l.strip()]
+    if len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} lines, expected one JSON line", file=sys.stderr)
+        return 1
+    print(lines[0])
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads (SURVEY.md §8d synthetic inputs)
+# ---------------------------------------------------------------------------------------------------------------
+class Workload:
+    pass
+
+
+def build_workload(name, ctx, dev, skin, edge_dtype):
+    import numpy as np
+    import torch
+    from gamd_amd import ensemble as ens
+    from gamd_amd import workloads as wk
+    from gamd_amd.engine import GamdForce
+    from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS
+
+    w = Workload()
+    w.name, w.species, w.mass, w.dtype_name = name, None, 39.9, "f32"
+    w.md_extra, w.flop_per_edge, w.kernel_name = {}, FLOP_PER_EDGE_CONV, "k_conv_edge"
+    w.dt_ps, w.uses_skin = 0.0005, False
+    if name == "dft":
+        # water/test_script/test_nosehoover_hb.py:64-113: 258 molecules, (20 A)^3 box and positions in bohr, cutoff 9.5
+        from gamd_amd.compat import HARTREE_PER_BOHR_TO_KJ_PER_MOL_NM as CONV
+        bohr = wk.BOHR_PER_NM / 10.0
+        pos, box, w.species, bonds = wk.water_box(258, seed=ens.box_seed(4567, ctx), jitter=0.0, wrap=False)
+        pos, box = pos * bohr, box * bohr
+        cfg = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
+        w.sd = make_state_dict(cfg, 5, 3.1 * bohr, 1.2 * bohr)
+        mean, var = SHIPPED_SCALERS["dft"]
+        w.eng = GamdForce(w.sd, pos.shape[0], box, 9.5, nbr_flavour="torch", cfg=cfg, device=dev,
+                          scaler=(mean * CONV, var * CONV ** 2))        # hartree/bohr -> kJ/mol/nm folded into the scaler
+        w.cutoff = 9.5
+        w.mass = wk.MASS_O
+        w.md_extra = dict(mass_h_amu=wk.MASS_H, length_per_nm=wk.BOHR_PER_NM, rigid_water=True,
+                          r_oh=wk.TIP3P_R_OH * bohr, r_hh=wk.TIP3P_R_HH * bohr)
+        w.flop_per_edge, w.kernel_name = 2 * 128 * 128 * (2 + 2 + 2), "k_conv_edge_wide<2,2>"
+        w.label = ("DFT-water configuration: 258 rigid molecules = 774 atoms, positions/box in bohr (L = 37.8), cutoff 9.5, "
+                   "WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, fp32, random-init weights (seed 5), SETTLE on "
+                   "device, 1 box per GPU")
+    elif name in ("c2", "c1"):
+        n = N_ATOMS if name == "c2" else 258
+        w.cutoff = 3.0 * wk.LJ_SIGMA if name == "c2" else 7.5       # C1: CUTOFF_RADIUS of LJ/train_network_lj.py:26-29
+        pos, box = wk.lj_box(n, seed=ens.box_seed(1234, ctx))
+        w.sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+        w.eng = GamdForce(w.sd, n, box, w.cutoff, scaler=SHIPPED_SCALERS["lj"], device=dev,
+                          neighbor_skin=skin * w.cutoff, edge_dtype=edge_dtype)
+        w.uses_skin = skin > 0
+        if edge_dtype == "f16x3":
+            w.dtype_name, w.kernel_name = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)", "k_conv_edge_f16x3"
+        w.dt_ps = 0.002
+        w.label = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
+                   "random-init weights (seed 0), 1 box per GPU") if name == "c2" else \
+                  ("C1-sized: 258-atom LJ box, rho*=0.5, L=27.27 A, cutoff 7.5 A (the reference's LJ driver system, "
+                   "lattice + jitter positions), fp32, random-init weights (seed 0)")
+    else:
+        nmol, dens, scal, seed0 = {"c3": (1390, 258.0, "tip3p", 2345), "c5": (2000, 251.0, "tip4p", 3456),
+                                   "c5b": (2667, 251.0, "tip4p", 3456)}[name]
+        pos, box, w.species, bonds = wk.water_box(nmol, mol_per_20A3=dens, seed=ens.box_seed(seed0, ctx), jitter=0.0, wrap=False)
+        w.sd = make_state_dict(ModelConfig(kind="water", use_bond=True), 3, 2.9, 1.1)
+        w.dtype_name = "bf16" if name in ("c5", "c5b") else edge_dtype
+        if w.dtype_name == "f16x3":
+            w.kernel_name = "k_conv_edge_f16x3"
+        w.cutoff = 4.2
+        w.eng = GamdForce(w.sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS[scal], device=dev,
+                          edge_dtype=w.dtype_name)
+        w.mass = wk.MASS_O
+        w.md_extra = dict(mass_h_amu=wk.MASS_H, rigid_water=True, r_oh=wk.TIP3P_R_OH, r_hh=wk.TIP3P_R_HH)
+        w.label = (f"{name.upper()}: {nmol} rigid water molecules (SETTLE on device) = {pos.shape[0]} network atoms, cutoff 4.2 A, "
+                   f"bond feature, {'bf16 edge-MLP operands / fp32 accumulate' if w.dtype_name == 'bf16' else 'fp32'}, "
+                   "random-init weights (seed 3), 1 box per GPU")
+    w.n_atoms, w.box, w.pos = pos.shape[0], box, pos
+    w.x = torch.from_numpy(pos).float().cuda(dev)
+    w.v = torch.from_numpy(wk.maxwell_boltzmann(w.n_atoms, mass_amu=w.mass, seed=99 + ctx.rank)).float().cuda(dev)
+    if name == "dft":
+        w.v *= float(wk.BOHR_PER_NM / 10.0)
+    w.f = w.eng.forward(w.x, species=w.species, denormalize=True)
+    w.md = dict(dt_ps=w.dt_ps, mass_amu=w.mass, temperature_k=100.0, gamma_per_ps=25.0,
+                seed=ens.box_seed(7, ctx), species=w.species, **w.md_extra)
+    return w
+
+
+def timed_run(w, steps, warmup, ctx, dev, ddev):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides;
+    the conv-edge kernel is timed live with HIP events on the launch stream.  Returns (seconds, max over ranks,
+    conv ms, conv launches)."""
+    import torch
+    from gamd_amd import ensemble as ens
+    w.eng.md_run(w.x, w.v, w.f, warmup, first_step=0, **w.md)
+    torch.cuda.synchronize(dev)
+    ens.barrier(ctx)
+    torch.cuda.synchronize(dev)
+    w.eng.timing_enable(True)
+    t0 = time.perf_counter()
+    w.eng.md_run(w.x, w.v, w.f, steps, first_step=warmup, sync=True, **w.md)
+    torch.cuda.synchronize(dev)
+    ens.barrier(ctx)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    conv_ms, conv_n = w.eng.timing_read()
+    w.eng.timing_enable(False)
+    return dt, ens.max_over_ranks(dt, ctx, device=ddev), conv_ms, conv_n
+
+
+def stage_replays(w, reps=8):
+    """Event-timed replays of one force evaluation (gamd_profile): average ms per stage label."""
+    acc, cnt = {}, {}
+    for _ in range(reps):
+        for label, ms in w.eng.profile(w.x, species=w.species):
+            acc[label] = acc.get(label, 0.0) + ms
+            cnt[label] = cnt.get(label, 0) + 1
+    return {k: acc[k] / cnt[k] for k in acc}, {k: cnt[k] // reps for k in cnt}
+
+
+def cpu_baseline(w, dev):
+    """The oracle's forward (op-for-op port of nn_module.py: unfused nn.Linear on E gathered rows, index_add_
+    aggregation) on the host cores.  torch's CPU kernels stop scaling long before this host's core count, so the
+    thread count is chosen on a 2 000-atom sample (best of 8/16/32) and the reported figure is then measured on the
+    timed run's own 10 000-atom inputs and weights: 1 warm-up + 2 evaluations.  Checker code, used
+    as a *reported baseline only*; the GPU result on the same inputs is compared with it."""
+    import numpy as np
+    import torch
+    from gamd_amd.engine import GamdForce
+    from gamd_amd.workloads import lj_box
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gamd_oracle as orc
+    ncpu = os.cpu_count() or 1
+    # --- thread count: bounded sample -------------------------------------------------------------------------
+    pos_s, box_s = lj_box(CPU_SAMPLE_ATOMS, seed=4321)
+    p_s = torch.from_numpy(pos_s).float()
+    edges_s = orc.neighbor_edges(p_s, box_s, w.cutoff, "jaxmd")
+    best_s, best_thr, out_s = None, None, None
+    for thr in sorted({min(ncpu, t) for t in (8, 16, 32)}):
+        torch.set_num_threads(thr)
+        orc.forward(w.sd, p_s, edges_s, box_s)                  # warm-up
+        t0 = time.perf_counter()
+        out_s = orc.forward(w.sd, p_s, edges_s, box_s)
+        dt = time.perf_counter() - t0
+        if best_s is None or dt < best_s:
+            best_s, best_thr = dt, thr
+    eng_s = GamdForce(w.sd, CPU_SAMPLE_ATOMS, box_s, w.cutoff, device=dev)
+    gpu_s = eng_s.forward(p_s).cpu().numpy()
+    same_edges_s = eng_s.counts()[0] == edges_s.shape[1]
+    eng_s.close()
+    err_s = float(np.abs(gpu_s - out_s.numpy()).max() / np.abs(out_s.numpy()).max())
+    # --- the headline inputs: current positions of the timed box, its weights, the GPU's own edge list ---------------
+    torch.set_num_threads(best_thr)
+    x_host = w.x.detach().cpu()
+    gpu = w.eng.forward(w.x).cpu().numpy()
+    edges = torch.from_numpy(w.eng.debug_edges()).long()
+    xw = torch.remainder(x_host, float(w.box))
+    orc.forward(w.sd, xw, edges, w.box)                         # warm-up
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        out = orc.forward(w.sd, xw, edges, w.box)
+        times.append(time.perf_counter() - t0)
+    err = float(np.abs(gpu - out.numpy()).max() / np.abs(out.numpy()).max())
+    sec = min(times)
+    return {"value": w.n_atoms / sec, "unit": "atom-steps/s", "cores": best_thr, "kind": "port",
+            "sample": f"force evaluation of the timed run's own {w.n_atoms}-atom LJ box (positions after the timed steps, "
+                      f"same weights, {edges.shape[1]} edges from the GPU's neighbour list), 1 warm-up + 2 evaluations "
+                      f"(best) with {best_thr} torch threads on a {ncpu}-thread host (os.cpu_count()); neighbour search "
+                      "and integrator excluded",
+            "seconds_per_eval": sec, "seconds_all": times, "host_threads": ncpu, "gpu_vs_cpu_rel_err": err,
+            "sample_2000": {"value": CPU_SAMPLE_ATOMS / best_s, "seconds_per_eval": best_s, "edges": int(edges_s.shape[1]),
+                            "gpu_vs_cpu_rel_err": err_s, "same_edge_count": bool(same_edges_s),
+                            "note": "2 000-atom box of the same density, cutoff and weights: thread-count scan "
+                                    "(best of 8/16/32) and linearity cross-check"}}
+
+
+def roofline_block(w, n_edges, conv_ms, conv_n):
+    avg_ms = conv_ms / max(conv_n, 1)
+    achieved = n_edges * w.flop_per_edge / (avg_ms * 1e-3) / 1e12
+    r = {"kernel": w.kernel_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+         "avg_launch_ms": avg_ms, "launches": conv_n, "flop_per_launch": n_edges * w.flop_per_edge}
+    if w.dtype_name.startswith("f16x3"):
+        # every product term costs 3 fp16 MFMAs (Wh xh, Wh xl, Wl xh): the matrix pipe executes 3x the algorithmic FLOPs,
+        # against the dense fp16 MFMA peak; the kernel is bound by LDS operand feed + VALU (DESIGN.md), not by that peak
+        r.update({"peak": 2500.0, "frac": achieved / 2500.0, "executed_mfma_tflops": 3.0 * achieved,
+                  "note": "achieved = algorithmic fp32-equivalent FLOP/s; peak = dense fp16 MFMA"})
+    if w.dtype_name == "bf16":
+        # SURVEY.md §8d "neighbour gather" figure (per edge: 4 B index + 512 B h[src] row + 512 B S[src] row) against HBM
+        # peak.  These are ALGORITHMIC gather bytes: the rows are served from L2 (node tables are 3 MB), the HBM traffic
+        # of the kernel is far lower; the kernel itself is VALU/MFMA-issue bound (DESIGN.md §5)
+        gbytes = n_edges * 1028.0
+        r = {"kernel": "k_conv_edge_bf16", "bound": "hbm", "achieved": gbytes / (avg_ms * 1e-3) / 1e9,
+             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbytes / (avg_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), "traffic": None,
+             "avg_launch_ms": avg_ms, "launches": conv_n, "bytes_per_launch": gbytes,
+             "note": "algorithmic neighbour-gather bytes (L2-served), not HBM traffic"}
+    return r
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
+    import torch
+    from gamd_amd import ensemble as ens
 
     # RCCL ("nccl") over xGMI in production; GAMD_BENCH_BACKEND=gloo + GAMD_BENCH_SHARE_GPU=1 let the N>1 control
     # flow be dry-run with several ranks on a single-GPU box (the timing of such a run means nothing)
     backend = os.environ.get("GAMD_BENCH_BACKEND", "nccl")
     share = os.environ.get("GAMD_BENCH_SHARE_GPU", "0") == "1"
-    if share:
-        os.environ["LOCAL_RANK_FOR_DEVICE"] = "0"
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with matching values "
+                         "(or without torchrun: bench.py --gpus N starts its own ranks)")
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if not share and torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank with LOCAL_RANK={local} has no device ({torch.cuda.device_count()} visible)")
     ctx = ens.init_ensemble(backend, device_index=0 if share else None)
-    if ctx.world != args.gpus and ctx.world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}")
     dev = 0 if share else (ctx.local_rank if ctx.distributed else 0)
     torch.cuda.set_device(dev)
     ddev = f"cuda:{dev}" if (ctx.distributed and backend == "nccl") else "cpu"
 
-    species, mass, dtype_name = None, 39.9, "f32"
-    md_extra, flop_per_edge, kernel_name = {}, FLOP_PER_EDGE_CONV, "k_conv_edge"
-    if args.workload == "dft":
-        # water/test_script/test_nosehoover_hb.py:64-113: 258 molecules, (20 A)^3 box and positions in bohr, cutoff 9.5
-        from gamd_amd import workloads as wk
-        from gamd_amd.compat import HARTREE_PER_BOHR_TO_KJ_PER_MOL_NM as CONV
-        bohr = wk.BOHR_PER_NM / 10.0
-        pos, box, species, bonds = wk.water_box(258, seed=ens.box_seed(4567, ctx), jitter=0.0, wrap=False)
-        pos, box = pos * bohr, box * bohr
-        cfg = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
-        sd = make_state_dict(cfg, 5, 3.1 * bohr, 1.2 * bohr)
-        mean, var = SHIPPED_SCALERS["dft"]
-        eng = GamdForce(sd, pos.shape[0], box, 9.5, nbr_flavour="torch", cfg=cfg, device=dev,
-                        scaler=(mean * CONV, var * CONV ** 2))        # hartree/bohr -> kJ/mol/nm folded into the scaler
-        n_atoms, mass = pos.shape[0], wk.MASS_O
-        md_extra = dict(mass_h_amu=wk.MASS_H, length_per_nm=wk.BOHR_PER_NM, rigid_water=True,
-                        r_oh=wk.TIP3P_R_OH * bohr, r_hh=wk.TIP3P_R_HH * bohr)
-        flop_per_edge, kernel_name = 2 * 128 * 128 * (2 + 2 + 2), "k_conv_edge_wide<2,2>"
-        wl = ("DFT-water configuration: 258 rigid molecules = 774 atoms, positions/box in bohr (L = 37.8), cutoff 9.5, "
-              "WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, fp32, random-init weights (seed 5), SETTLE on "
-              "device, 1 box per GPU")
-    elif args.workload == "c2":
-        pos, box = lj_box(N_ATOMS, seed=ens.box_seed(1234, ctx))
-        sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
-        eng = GamdForce(sd, N_ATOMS, box, CUTOFF, scaler=SHIPPED_SCALERS["lj"], device=dev,
-                        neighbor_skin=args.skin * CUTOFF, edge_dtype=args.edge_dtype)
-        if args.edge_dtype == "f16x3":
-            dtype_name, kernel_name = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)", "k_conv_edge_f16x3"
-        n_atoms = N_ATOMS
-        wl = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
-              "random-init weights (seed 0), 1 box per GPU")
-    else:
-        from gamd_amd.workloads import water_box
-        nmol, dens, scal, seed0 = (1390, 258.0, "tip3p", 2345) if args.workload == "c3" else (2000, 251.0, "tip4p", 3456)
-        from gamd_amd import workloads as wk
-        pos, box, species, bonds = water_box(nmol, mol_per_20A3=dens, seed=ens.box_seed(seed0, ctx), jitter=0.0, wrap=False)
-        sd = make_state_dict(ModelConfig(kind="water", use_bond=True), 3, 2.9, 1.1)
-        dtype_name = "bf16" if args.workload == "c5" else args.edge_dtype
-        eng = GamdForce(sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS[scal], device=dev,
-                        edge_dtype=dtype_name)
-        n_atoms, mass = pos.shape[0], wk.MASS_O
-        md_extra = dict(mass_h_amu=wk.MASS_H, rigid_water=True, r_oh=wk.TIP3P_R_OH, r_hh=wk.TIP3P_R_HH)
-        wl = (f"{args.workload.upper()}: {nmol} rigid water molecules (SETTLE on device) = {n_atoms} network atoms, cutoff 4.2 A, "
-              f"bond feature, {'bf16 edge-MLP operands / fp32 accumulate' if dtype_name == 'bf16' else 'fp32'}, "
-              "random-init weights (seed 3), 1 box per GPU")
-    x = torch.from_numpy(pos).float().cuda(dev)
-    v = torch.from_numpy(maxwell_boltzmann(n_atoms, mass_amu=mass, seed=99 + ctx.rank)).float().cuda(dev)
-    if args.workload == "dft":
-        v *= float(wk.BOHR_PER_NM / 10.0)
-    f = eng.forward(x, species=species, denormalize=True).clone()
-
-    md = dict(dt_ps=0.002 if args.workload == "c2" else 0.0005, mass_amu=mass, temperature_k=100.0, gamma_per_ps=25.0,
-              seed=ens.box_seed(7, ctx), species=species, **md_extra)
-    eng.md_run(x, v, f, args.warmup, first_step=0, **md)
-    torch.cuda.synchronize(dev)
-    ens.barrier(ctx)
-    torch.cuda.synchronize(dev)
-    eng.timing_enable(True)
-    t0 = time.perf_counter()
-    eng.md_run(x, v, f, args.steps, first_step=args.warmup, sync=True, **md)
-    torch.cuda.synchronize(dev)
-    ens.barrier(ctx)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    conv_ms, conv_n = eng.timing_read()
-    eng.timing_enable(False)
-    n_edges = eng.counts()[0]
-    dt_max = ens.max_over_ranks(dt, ctx, device=ddev)
-    summary = ens.gather_summary({"seconds": dt, "edges": float(n_edges), "fsum": float(f.abs().sum().item()),
-                                  "finite": float(torch.isfinite(x).all().item() and torch.isfinite(f).all().item())},
+    skin = args.skin if args.workload in ("c1", "c2") else 0.0
+    w = build_workload(args.workload, ctx, dev, skin, args.edge_dtype)
+    dt, dt_max, conv_ms, conv_n = timed_run(w, args.steps, args.warmup, ctx, dev, ddev)
+    n_edges = w.eng.counts()[0]
+    summary = ens.gather_summary({"seconds": dt, "edges": float(n_edges), "fsum": float(w.f.abs().sum().item()),
+                                  "box_seed": float(ens.box_seed(1234, ctx)),
+                                  "finite": float(torch.isfinite(w.x).all().item() and torch.isfinite(w.f).all().item())},
                                  ctx, device=ddev)
     if ctx.rank != 0:
         ens.shutdown(ctx)
@@ -177,56 +350,92 @@ def main():
     if not all(s["finite"] == 1.0 for s in summary):
         raise SystemExit("non-finite state after the timed run")
 
-    value = ens.aggregate_throughput(n_atoms * args.steps, dt_max, ctx)
-    avg_ms = conv_ms / max(conv_n, 1)
-    achieved = n_edges * flop_per_edge / (avg_ms * 1e-3) / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_conv_edge.json")
-    if os.path.exists(pmc) and args.workload == "c2":        # the PMC passes were taken on the C2 workload
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    value = ens.aggregate_throughput(w.n_atoms * args.steps, dt_max, ctx)
     line = {
         "metric": "atom-steps/sec (force eval + integrate), 10k-atom LJ box" if args.workload == "c2"
-                  else f"atom-steps/sec (force eval + constrained integrate), {args.workload} water box",
+                  else f"atom-steps/sec (force eval + integrate), {args.workload} box",
         "value": value, "unit": "atom-steps/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
-        "config": {"workload": wl, "n_atoms": n_atoms, "edges_per_step": n_edges, "boxes": ctx.world,
-                   "neighbour_list": ("exact cell-list rebuild every step" if args.skin == 0 or args.workload != "c2" else
-                                      f"Verlet skin {args.skin:.3f} x cutoff, exact re-filter every step, "
-                                      f"{eng.skin_stats()[0]} candidate rebuilds in warm-up + timed steps"),
-                   "step": "BAOAB half + neighbour build + GNN forces + BAOAB half, on device"},
-        "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                     "avg_launch_ms": avg_ms, "launches": conv_n,
-                     "flop_per_launch": n_edges * flop_per_edge},
+        "vs_baseline": None, "dtype": w.dtype_name, "data": "synthetic",
+        "config": {"workload": w.label, "n_atoms": w.n_atoms, "edges_per_step": n_edges, "boxes": ctx.world,
+                   "neighbour_list": (f"Verlet skin {skin:.3f} x cutoff, exact re-filter every step, "
+                                      f"{w.eng.skin_stats()[0]} candidate rebuilds in warm-up + timed steps"
+                                      if w.uses_skin else "exact cell-list rebuild every step"),
+                   "step": "BAOAB half + neighbour build + GNN forces + BAOAB half, on device",
+                   "launch": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else
+                             ("self-spawned ranks" if ctx.world > 1 else "single process")},
+        "ensemble": {"boxes": ctx.world, "collective_on_step_path": False,
+                     "per_rank": [{"rank": r, "box_seed": int(s["box_seed"]), "seconds": s["seconds"], "edges": int(s["edges"]),
+                                   "force_abs_sum": s["fsum"]} for r, s in enumerate(summary)]},
+        "roofline": roofline_block(w, n_edges, conv_ms, conv_n),
     }
-    if args.workload in ("c2", "c3") and args.edge_dtype == "f16x3":
-        line["dtype"] = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)"
-        line["roofline"]["kernel"] = "k_conv_edge_f16x3"
-        # every product term costs 3 fp16 MFMAs (Wh xh, Wh xl, Wl xh): the matrix pipe executes 3x the algorithmic FLOPs,
-        # against the dense fp16 MFMA peak; the kernel is bound by LDS operand feed + VALU, not by that peak
-        line["roofline"].update({"peak": 2500.0, "frac": achieved / 2500.0, "traffic": None,
-                                 "executed_mfma_tflops": 3.0 * achieved,
-                                 "note": "achieved = algorithmic fp32-equivalent FLOP/s; peak = dense fp16 MFMA"})
-    if dtype_name == "bf16":
-        # the bf16 kernel is gather-bound, not matrix-bound: report the neighbour-gather bytes of SURVEY.md §8d
-        # (per edge: 4 B index + 512 B h[src] row + 512 B S[src] row) against HBM peak
-        gbytes = n_edges * 1028.0
-        line["roofline"] = {"kernel": "k_conv_edge_bf16", "bound": "hbm", "achieved": gbytes / (avg_ms * 1e-3) / 1e9,
-                            "peak": 8000.0, "unit": "GB/s", "frac": gbytes / (avg_ms * 1e-3) / 8e12, "traffic": None,
-                            "avg_launch_ms": avg_ms, "launches": conv_n, "bytes_per_launch": gbytes}
-    if ctx.world == 1 and not args.no_cpu_baseline and args.workload == "c2":
-        cpu_s, thr, cpu_edges, err, same_edges = cpu_baseline(sd, dev)
-        line["cpu_baseline"] = {"value": CPU_SAMPLE_ATOMS / cpu_s, "unit": "atom-steps/s", "cores": thr,
-                                "kind": "port",
-                                "sample": f"force evaluation of a {CPU_SAMPLE_ATOMS}-atom LJ box (same density, cutoff "
-                                          f"and weights; {cpu_edges} edges), best of 2 after warm-up at the best of "
-                                          f"8/16/32 torch threads on a {os.cpu_count()}-thread host; neighbour search "
-                                          "and integrator excluded",
-                                "seconds_per_eval": cpu_s, "gpu_vs_cpu_rel_err": err, "same_edge_count": same_edges}
+    rl = line["roofline"]
+    if args.workload == "c2" and w.dtype_name == "f32":
+        # HBM bytes per launch from the PMC passes (profiles/), valid only for the kernel sources they were taken on
+        pmc = os.path.join(ROOT, "profiles", "pmc_conv_edge.json")
+        try:
+            rec = json.load(open(pmc))
+            if rec.get("kernel_source_sha256_16") == kernel_source_hash():
+                rl["traffic"] = rec.get("hbm_bytes_per_launch")
+                rl["traffic_source"] = "profiles/pmc_conv_edge.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same kernel sources)"
+            else:
+                rl["traffic_note"] = ("profiles/pmc_conv_edge.json was taken on other kernel sources "
+                                      f"({rec.get('kernel_source_sha256_16')} != {kernel_source_hash()}): not reported")
+        except Exception as exc:                                        # missing / unreadable file: say so, report null
+            rl["traffic_note"] = f"no PMC record: {exc}"
+        # SURVEY.md §8d "neighbour gather" figure: L2-served rows, so this is not HBM traffic; stated with its bound
+        n_layers = 4
+        gather_bytes = n_layers * (n_edges * 1028.0 + w.n_atoms * 1024.0)
+        gather_s = rl["avg_launch_ms"] * 1e-3 * n_layers
+        rl["neighbour_gather"] = {"bytes_per_step": gather_bytes, "GB_per_s": gather_bytes / gather_s / 1e9,
+                                  "frac_of_hbm_peak": gather_bytes / gather_s / (PEAK_HBM_GBS * 1e9),
+                                  "bound": "mfma-bound in fp32: the gather rides inside k_conv_edge, whose time is set by "
+                                           "the fp32 matrix pipe; the north star's >= 50 % of the memory roofline on the "
+                                           "gather is reachable only by the bf16 kernel (see secondary c5)"}
+    single = ctx.world == 1
+    if single and not args.no_secondary:
+        # per-kernel figures of the other MFMA kernels from event-timed replays of one force evaluation
+        ms, per_eval = stage_replays(w)
+        F = 45 if w.species is not None else 44
+        kern = []
+        if "edge_encode" in ms and w.dtype_name == "f32" and args.workload in ("c1", "c2", "c3"):
+            fl = n_edges * 2.0 * (F * 128 + 2 * 128 * 128)
+            kern.append({"kernel": "k_edge_encode", "bound": "mfma", "flop_per_launch": fl, "avg_launch_ms": ms["edge_encode"],
+                         "achieved": fl / (ms["edge_encode"] * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / (ms["edge_encode"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": 1})
+        if "node_mid" in ms and args.workload in ("c1", "c2", "c3", "c5", "c5b"):
+            fl = w.n_atoms * 10.0 * 128 * 128
+            kern.append({"kernel": "k_node (post + pre of a middle layer)", "bound": "latency (one round of 32-atom tiles)",
+                         "flop_per_launch": fl, "avg_launch_ms": ms["node_mid"],
+                         "achieved": fl / (ms["node_mid"] * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / (ms["node_mid"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "launches_per_step": per_eval.get("node_mid", 0) + 2,
+                         "node_ms_per_step": ms.get("node_first", 0.0) + ms["node_mid"] * per_eval.get("node_mid", 0)
+                                             + ms.get("node_last_decode", 0.0)})
+        if "neighbor_build" in ms:
+            kern.append({"kernel": "neighbour stage (skin check + exact filter | cell-list build, CSR, chunk metadata)",
+                         "bound": "latency / hbm (tiny)", "avg_stage_ms": ms["neighbor_build"],
+                         "bytes_algorithmic": 12.0 * w.n_atoms + 8.0 * n_edges})
+        rl["kernels"] = kern
+        rl["kernels_note"] = ("event-bracketed stages of gamd_profile replays after the timed region (8 evaluations); each "
+                              "figure includes the launch gap in front of the kernel")
+    if single and not args.no_cpu_baseline and args.workload == "c2":
+        line["cpu_baseline"] = cpu_baseline(w, dev)
+    if single and not args.no_secondary and args.workload == "c2":
+        sec = {}
+        w.eng.close()
+        for name in ("c1", "c3", "c5", "c5b"):
+            s = build_workload(name, ctx, dev, args.skin if name == "c1" else 0.0, "f32")
+            sdt, _, sconv_ms, sconv_n = timed_run(s, 20, 5, ctx, dev, ddev)
+            se = s.eng.counts()[0]
+            ok = bool(torch.isfinite(s.x).all().item() and torch.isfinite(s.f).all().item())
+            rb = roofline_block(s, se, sconv_ms, sconv_n)
+            sec[name] = {"workload": s.label, "n_atoms": s.n_atoms, "edges_per_step": se, "dtype": s.dtype_name,
+                         "steps": 20, "warmup": 5, "ms_per_step": sdt / 20 * 1e3, "value": s.n_atoms * 20 / sdt,
+                         "unit": "atom-steps/s", "finite": ok,
+                         "conv_kernel": {k: rb[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
+            s.eng.close()
+        line["secondary"] = sec
     print(json.dumps(line))
     ens.shutdown(ctx)
 

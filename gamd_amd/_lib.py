@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgamd_hip.so")
+# GAMD_LIB: load another build of the SAME C ABI instead (tools/ point it at libgamd_hip_prof.so, the -DGAMD_PROFILING
+# build with instrumented kernel variants).  It must exist: there is no fallback either way.
+LIB_PATH = os.environ.get("GAMD_LIB") or os.path.join(_HERE, "libgamd_hip.so")
 
 
 class GamdConfig(C.Structure):
@@ -18,7 +20,8 @@ class GamdConfig(C.Structure):
                 ("cutoff", C.c_float), ("box", C.c_float * 3), ("edge_capacity", C.c_int64),
                 ("keep_stages", C.c_int32), ("edge_dtype", C.c_int32),
                 ("encoding_size", C.c_int32), ("edge_embedding_dim", C.c_int32), ("hidden_dim", C.c_int32),
-                ("no_expand_edge", C.c_int32), ("neighbor_skin", C.c_float), ("reserved", C.c_int32)]
+                ("no_expand_edge", C.c_int32), ("neighbor_skin", C.c_float), ("self_loop_mode", C.c_int32),
+                ("kernel_select", C.c_int32), ("small_tile_limit", C.c_int32)]
 
 
 # common tail of both integrator parameter blocks (masses per species, length unit, rigid water)
@@ -49,6 +52,8 @@ SYMBOLS = {
     "gamd_set_scaler": (_i32, [_vp, C.c_double, C.c_double]),
     "gamd_set_bonds": (_i32, [_vp, _vp, _i64]),
     "gamd_forces_async": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp]),
+    "gamd_set_node_features": (_i32, [_vp, _vp]),
+    "gamd_get_device_flags": (_i32, [_vp, C.POINTER(_i32)]),
     "gamd_sync_status": (_i32, [_vp, _vp]),
     "gamd_forces": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp]),
     "gamd_forces_edges": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -14,7 +14,6 @@ constructor arguments here.
 """
 from __future__ import annotations
 
-import time
 from types import SimpleNamespace
 from typing import Optional
 
@@ -29,6 +28,16 @@ def create_water_bond(total_atom_num: int) -> np.ndarray:
     """O-H1, O-H2 per molecule, atoms ordered O,H,H (water/train_network_tip3p.py:38-42)."""
     o = np.arange(0, total_atom_num, 3)
     return np.stack([np.repeat(o, 2), (o[:, None] + np.array([1, 2])).reshape(-1)], axis=1)
+
+
+def _node_feature(feat):
+    """The `x` / `feat` argument of the water models: a float [N,1] tensor that the reference feeds to node_encoder
+    as is (nn_module.py:554, :403).  The drivers build it as O = 1 / H = 0 (water/test_script/test_nosehoover.py:82-89)
+    but any float value is carried through (GamdForce hands floating-point input to the library as float features)."""
+    if isinstance(feat, np.ndarray):
+        feat = torch.from_numpy(feat)
+    f = feat.reshape(-1)
+    return f if f.dtype.is_floating_point else f.to(torch.float32)
 
 
 class _ModelLevel:
@@ -52,10 +61,10 @@ class _ModelLevel:
             eng = self._owner._get_engine()
             if abs(float(cutoff) - eng.cutoff) > 1e-6 * eng.cutoff:
                 raise ValueError(f"cutoff {cutoff} differs from the one the engine was built with ({eng.cutoff})")
-            return eng.forward(pos_lst[0], box=np.asarray(box_lst[0], dtype=np.float32), species=feat.reshape(-1) != 0)
+            return eng.forward(pos_lst[0], box=np.asarray(box_lst[0], dtype=np.float32), species=_node_feature(feat))
         else:
             raise TypeError("expected ([pos], [edge_idx]), ([pos], feat, [edge_idx]) or ([pos], feat, [box], cutoff)")
-        species = None if feat is None else (feat.reshape(-1) != 0)
+        species = None if feat is None else _node_feature(feat)
         return self._owner._get_engine().forward_edges(pos_lst[0], edge_lst[0], species=species)
 
     forward = __call__
@@ -63,11 +72,13 @@ class _ModelLevel:
 
 class _ForceFieldBase:
     def __init__(self, args=None, state_dict=None, *, num_atoms: int, box_size, cutoff: float,
-                 bond=None, scaler_ckpt: Optional[str] = None, device: int = 0, edge_dtype: str = "f32"):
+                 bond=None, scaler_ckpt: Optional[str] = None, device: int = 0, edge_dtype: str = "f32",
+                 self_loop_mode: str = "dgl07_noop"):
         self.args = args or SimpleNamespace()
         self.num_atoms, self.box_size, self.cutoff = int(num_atoms), box_size, float(cutoff)
         self.bond, self.device_index = bond, device
         self.edge_dtype = edge_dtype                 # "f32" (default) | "f16x3" (fp32-grade split-fp16 GEMMs) | "bf16"
+        self.self_loop_mode = self_loop_mode         # what add_self_loop()'s discarded result means
         self._nbr_flavour = "jaxmd"                  # graph_utils.NeighborSearcher semantics ('<' on r^2, self edge kept)
         self._skin = self.cutoff / 6.0               # its dr_threshold (graph_utils.py:24): candidate list reused
                                                      # between calls, exact cutoff re-applied every call
@@ -110,7 +121,7 @@ class _ForceFieldBase:
             self._engine = GamdForce(self._sd, self.num_atoms, self.box_size, self.cutoff, bond=self.bond,
                                      scaler=(self.training_mean, self.training_var), device=self.device_index,
                                      nbr_flavour=self._nbr_flavour, neighbor_skin=self._skin,
-                                     edge_dtype=self.edge_dtype)
+                                     edge_dtype=self.edge_dtype, self_loop_mode=self.self_loop_mode)
         return self._engine
 
     def denormalize(self, normalized_force, var, mean):
@@ -118,18 +129,22 @@ class _ForceFieldBase:
 
     def _predict(self, pos: np.ndarray, feat=None, verbose=False) -> np.ndarray:
         eng = self._get_engine()
-        t0 = time.time()
         # enforce periodic boundary in f64 on the host, then f32 (train_network_lj.py:141-142)
         posw = np.mod(np.asarray(pos, dtype=np.float64), np.asarray(self.box_size, dtype=np.float64))
-        species = None
-        if feat is not None:
-            species = (feat.reshape(-1) != 0)
-        pred = eng.forward(torch.from_numpy(posw).float(), species=species)
-        pred = pred.detach().cpu().numpy()                    # device -> host sync (:153)
-        t1 = time.time()
+        species = None if feat is None else _node_feature(feat)
+        x = torch.from_numpy(posw).float()
         if verbose:
+            # the reference's two time.time() buckets (train_network_lj.py:134-151): neighbour search vs network forward.
+            # Here both are stages of one enqueued call, so they are measured with HIP events on the stream
+            stages = eng.profile(x, species=species)
+            pred = eng._out.detach().cpu().numpy()
+            nbr = sum(ms for label, ms in stages if label == "neighbor_build") * 1e-3
+            force = sum(ms for label, ms in stages if label != "neighbor_build") * 1e-3
             print('=============================================')
-            print(f'Nbr search + force eval used time: {t1 - t0}')
+            print(f'Nbr search used time: {nbr}')
+            print(f'Force eval used time: {force}')
+        else:
+            pred = eng.forward(x, species=species, inplace=True).detach().cpu().numpy()   # device -> host sync (:153)
         return self.denormalize(pred, self.training_var, self.training_mean)   # f64 result (:155)
 
 
@@ -177,6 +192,7 @@ class ParticleNetLightningDFT(_ForceFieldBase):
         eng = self._get_engine()
         box = np.asarray(box_size, dtype=np.float64).reshape(-1)
         posw = np.mod(np.asarray(pos, dtype=np.float64), box)                 # train_network_real_large.py:150
-        pred = eng.forward(torch.from_numpy(posw).float(), box=box.astype(np.float32), species=(feat.reshape(-1) != 0))
+        pred = eng.forward(torch.from_numpy(posw).float(), box=box.astype(np.float32), species=_node_feature(feat),
+                           inplace=True)
         pred = pred.detach().cpu().numpy()
         return self.denormalize(pred, self.training_var, self.training_mean)  # :160

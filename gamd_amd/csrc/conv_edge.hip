@@ -38,21 +38,6 @@ namespace {
 
 constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
 
-// L2 -> LDS copy of one packed 64 KiB weight matrix, 8 x 1 KiB per wave.  lane16 is made opaque so
-// the 64-bit addresses are rebuilt (1 VALU each) instead of being hoisted out of the tile loop and
-// spilled (a spilled pointer = scratch reload + s_waitcnt vmcnt(0) in front of every copy).
-__device__ __forceinline__ void stage_weight(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
-    asm volatile("" : "+v"(lane16));
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int chunk = k * 8 + wave;      // 64 chunks of 1 KiB, lane-linear image == packed global image
-        const char* base = reinterpret_cast<const char*>(gw) + chunk * 1024;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(base + lane16),
-            (__attribute__((address_space(3))) void*)(ldsbuf + chunk * 256), 16, 0, 0);
-    }
-}
-
 // 128x128 GEMM of the chain with a software-pipelined element-wise post-op: while output tile tp is
 // being accumulated (64 MFMAs in 16 groups of 4), post(tp-1, g) finishes element g of the previous,
 // already complete, output tile.  Only tile 3's post-op trails the last MFMA.
@@ -100,9 +85,25 @@ __device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, in
         }
 }
 
-// TIME: s_memtime instrumentation (profiling builds only, GAMD_CONV_VARIANT=1)
-template <bool TIME>
+// Kernel variants (template bit mask).  CV_TIME is the s_memtime instrumentation; the others are scheduling choices
+// that do not change any result bit.  The release library instantiates CONV_PRODUCTION only; libgamd_hip_prof.so
+// (-DGAMD_PROFILING) also builds the other combinations and selects one with GAMD_CONV_VARIANT for A/B timing.
+enum {
+    CV_TIME = 1,        // per-segment cycle counters -> a.tdbg
+    CV_ASYM_DMA = 2,    // the weight DMA of a phase is issued by waves 4-7 only (16 x 1 KiB each): waves 0-3, which the
+                        // SIMD arbiter serves first after a barrier, go straight to their first MFMA
+    CV_EARLY_INIT = 4,  // waves 0-3 initialise the next phase's accumulators (bias rows) BEFORE the barrier, in the time
+                        // they spend waiting for waves 4-7 anyway; waves 4-7 do it after the barrier, behind waves 0-3's MFMAs
+    CV_PRIO_YOUNG = 8,  // static s_setprio 1 for waves 4-7
+    CV_PRIO_GEMM = 16,  // s_setprio 1 around every wave's own MFMA stream
+};
+#ifndef CONV_PRODUCTION
+#define CONV_PRODUCTION 0
+#endif
+
+template <int V>
 __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
+    constexpr bool TIME = (V & CV_TIME) != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* buf0 = lds;
     float* buf1 = lds + GAMD_WFRAG_FLOATS;
@@ -119,7 +120,10 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     // Work unit = 4 tiles, one per SIMD.  Waves 0-3 and 4-7 of the workgroup take successive units of its list, so
     // the work is balanced to half an iteration (an iteration with only waves 0-3 active takes about half the
     // time: the two waves of a SIMD serialise their MFMA streams anyway).
-    const int n_units = (n_tiles + 3) / 4;
+    int n_units = (n_tiles + 3) / 4;
+    // hybrid launch: whole rounds only (the same number of units for every workgroup); the remaining
+    // < 4 * gridDim.x tiles are k_conv_edge_small's, which splits each tile over four SIMDs
+    if (a.split_wgs > 0) n_units = (n_units / (int)gridDim.x) * (int)gridDim.x;
     int first, end, step;
     gamd_xcd_range(n_units, blockIdx.x, gridDim.x, first, end, step);
     if (first >= end) return;
@@ -129,18 +133,35 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         const int u = first + (2 * it + whalf) * step;
         return (it < n_iter && u < end) ? u * 4 + wsub : n_tiles;
     };
+    // L2 -> LDS copy of the next phase's weight matrix
+    auto stage = [&](const float* gw, float* buf) {
+        if (V & CV_ASYM_DMA) { if (whalf == 1) gamd_stage_weight<4>(gw, buf, wsub, lane16); }
+        else gamd_stage_weight<8>(gw, buf, wave, lane16);
+    };
+    // accumulator initialisation of a phase: before the preceding barrier for waves 0-3, after it for waves 4-7
+    const bool early = (V & CV_EARLY_INIT) && whalf == 0;
+    if (V & CV_PRIO_YOUNG) { if (whalf == 1) __builtin_amdgcn_s_setprio(1); }
 
     long long tacc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) tacc[i] = 0;
     long long tprev = 0;
 #define TMARK(i) do { if (TIME) { const long long tn__ = (long long)__builtin_readcyclecounter(); tacc[i] += tn__ - tprev; tprev = tn__; } } while (0)
+#define GEMM_PRIO(p) do { if (V & CV_PRIO_GEMM) __builtin_amdgcn_s_setprio(p); } while (0)
 
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
-    stage_weight(a.w1p, buf0, wave, lane16);
+    stage(a.w1p, buf0);
 
     // three 64-register sets rotate through the roles {GEMM input, GEMM output, prefetched gather}
     f32x16 RA[4], RB[4], RC[4];
+    auto init_b4 = [&]() {
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const float b = vb4[32 * tp + slot];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) RC[tp][r] = b;
+        }
+    };
 
     // per-lane edge of the current tile (slot order) and prefetch for the first tile
     int tile = tile_of(0);
@@ -155,6 +176,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         }
     }
     __syncthreads();
+    if (early && active) load_bias_chain(vb1, half, RB);
     if (TIME) tprev = (long long)__builtin_readcyclecounter();
     unsigned pend_ends = 0;           // piece stores of the tile just finished (issued after its last barrier)
     int pend_p = 0;
@@ -169,23 +191,27 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         int src_n = 0, dst_n = 0;
 
         // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====
-        stage_weight(a.w2p, buf1, wave, lane16);
+        stage(a.w2p, buf1);
         if (active) {
-            load_bias_chain(vb1, half, RB);
+            if (!early) load_bias_chain(vb1, half, RB);
             TMARK(0);
+            GEMM_PRIO(1);
             gemm128_post<false>((const f32x4*)buf0, lane, RA, RB,
                                 [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
+            GEMM_PRIO(0);
             load_row_chain(a.S + (size_t)src * GAMD_H, half, RA);        // for phase 2's post-op
             TMARK(1);
         }
         if (active) phase_barrier<16>(); else phase_barrier<0>();
         TMARK(2);
         // ===== phase 2: RC = SiLU(W2 T1 + D[dst] + S[src])        in RB, S in RA =====
-        stage_weight(a.w3p, buf0, wave, lane16);
+        stage(a.w3p, buf0);
         if (active) {
             TMARK(3);
+            GEMM_PRIO(1);
             gemm128_post<false>((const f32x4*)buf1, lane, RB, RC,
                                 [&](int tp, int g) { RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]); });
+            GEMM_PRIO(0);
             // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge); the source index of
             // edge (half, r) lives in lane rho(r, half) of `src`
 #pragma unroll
@@ -196,12 +222,13 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
 #pragma unroll
                 for (int tp = 0; tp < 4; ++tp) RA[tp][r] = hrow[32 * tp];
             }
+            if (early) load_bias_chain(vb3, half, RB);                    // RB (T1) is free: phase 3's accumulators
             TMARK(4);
         }
         if (active) phase_barrier<63>(); else phase_barrier<0>();
         TMARK(5);
         // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
-        stage_weight(a.w4p, buf1, wave, lane16);
+        stage(a.w4p, buf1);
         unsigned mask = 0;
         int p0 = 0;
         // small index loads for phase 4 / the next tile go first: done long before the barrier needs vmcnt(0)
@@ -214,33 +241,33 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
         }
         if (active) {
-            load_bias_chain(vb3, half, RB);
+            if (!early) load_bias_chain(vb3, half, RB);
             TMARK(6);
+            GEMM_PRIO(1);
             gemm128_post<false>((const f32x4*)buf0, lane, RC, RB,
                                 [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
+            GEMM_PRIO(0);
+            if (early) init_b4();                                         // RC (T3) is free: phase 4's accumulators
             TMARK(7);
         }
         phase_barrier<0>();
         TMARK(8);
         // ===== phase 4: RC = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
-        stage_weight(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
+        stage(a.w1p, buf0);       // next tile's W1 (harmless on the last iteration)
         if (active) {
-#pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                const float b = vb4[32 * tp + slot];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) RC[tp][r] = b;
-            }
+            if (!early) init_b4();
             TMARK(9);
             // e_emb for this lane's 16 edges x 4 features, then message + segment sum (nn_module.py:142
             // u_mul_e -> sum).  In-stream part is branch-free: RC[tp][r] becomes the running sum of the
             // messages of the current piece (reset after every edge that closes a destination segment).
             const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
+            GEMM_PRIO(1);
             gemm128_post<true>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
                 const float prod = (r < nvalid) ? RA[tp][r] * RC[tp][r] : 0.f;
                 if (r == 0) RC[tp][0] = prod;
                 else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
             });
+            GEMM_PRIO(0);
             // piece stores are deferred past the barrier (vmcnt counts stores too: issued here they would sit
             // in front of the prefetch loads and the counted wait below would wait for their write latency)
             pend_ends = mask;
@@ -250,6 +277,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         }
         // prefetch the next tile's e (-> RA): in flight across the barrier
         if (active_n) load_e_tile(a.e_frag, tile_n, lane, RA);
+        if (early && active_n) load_bias_chain(vb1, half, RB);            // RB (T4) is free: next tile's phase 1
         if (active_n) phase_barrier<16>(); else phase_barrier<0>();
         TMARK(11);
         // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge does
@@ -277,28 +305,19 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         for (int i = 0; i < 12; ++i) a.tdbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = tacc[i];
     }
 #undef TMARK
+#undef GEMM_PRIO
 }
 
-int conv_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* s = getenv("GAMD_CONV_VARIANT");
-        v = s ? atoi(s) : 0;
-        if (v < 0 || v > 1) v = 0;
-    }
-    return v;
-}
-
-template <bool TIME>
+template <int V>
 int launch_variant(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * CONV_LDS_FLOATS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge<TIME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return (int)e1;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_conv_edge<TIME>, dim3(n_blocks), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(k_conv_edge<V>, dim3(n_blocks), dim3(512), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
 }
@@ -306,6 +325,15 @@ int launch_variant(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
 }  // namespace
 
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
-    // GAMD_CONV_VARIANT=1 selects the s_memtime-instrumented build (profiling only)
-    return conv_variant() == 1 ? launch_variant<true>(a, n_blocks, st) : launch_variant<false>(a, n_blocks, st);
+#ifdef GAMD_PROFILING
+    static int v = -1;
+    if (v < 0) { const char* s = getenv("GAMD_CONV_VARIANT"); v = s ? atoi(s) : CONV_PRODUCTION; }
+    switch (v) {
+#define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
+        CASE(0); CASE(1); CASE(2); CASE(3); CASE(4); CASE(6); CASE(7); CASE(8); CASE(14); CASE(16); CASE(22);
+#undef CASE
+        default: break;
+    }
+#endif
+    return launch_variant<CONV_PRODUCTION>(a, n_blocks, st);
 }

@@ -13,22 +13,6 @@ namespace {
 
 constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
 
-// L2 -> LDS copy of one packed 64 KiB weight matrix, 64 / NW x 1 KiB per wave.  lane16 is made opaque so
-// the 64-bit addresses are rebuilt (1 VALU each) instead of being hoisted out of the tile loop and
-// spilled (a spilled pointer = scratch reload + s_waitcnt vmcnt(0) in front of every copy).
-template <int NW>
-__device__ __forceinline__ void stage_weight(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
-    asm volatile("" : "+v"(lane16));
-#pragma unroll
-    for (int k = 0; k < 64 / NW; ++k) {
-        const int chunk = k * NW + wave;      // 64 chunks of 1 KiB, lane-linear image == packed global image
-        const char* base = reinterpret_cast<const char*>(gw) + chunk * 1024;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(base + lane16),
-            (__attribute__((address_space(3))) void*)(ldsbuf + chunk * 256), 16, 0, 0);
-    }
-}
-
 // An operand set: the (hi, lo) fp16 images of a 32 x 128 activation block in MFMA operand order, 64 registers
 // (the size of the fp32 block it replaces): w[t][u][part] = 4 dwords = 8 halves of K step (t, u).
 struct OpSet { gamd_u32x4_t w[4][2][2]; };
@@ -150,7 +134,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
     };
 
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
-    stage_weight<NW>(a.w1p, buf0, wave, lane16);
+    gamd_stage_weight<NW>(a.w1p, buf0, wave, lane16);
 
     // 64-register sets: two operand sets PA / PB alternate as GEMM input / output (the post-op of a phase writes its
     // activation directly as the split operands of the next phase); RA = S[src], RC = D[dst] -> accumulators of
@@ -197,11 +181,11 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
                 else { load_row_piece(srow, half, RA, i - 16); load_row_piece(drow, half, RC, i - 16); }
             });
         } else {
-            stage_weight<NW>(a.w2p, buf1, wave, lane16);
+            gamd_stage_weight<NW>(a.w2p, buf1, wave, lane16);
         }
         if (active) phase_barrier<32>(); else phase_barrier<0>();     // S/D gathers (issued after the DMA) stay in flight
         // ===== phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]) =====
-        if (!active) stage_weight<NW>(a.w3p, buf0, wave, lane16);
+        if (!active) gamd_stage_weight<NW>(a.w3p, buf0, wave, lane16);
         if (active) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) RC[t] += RA[t];
@@ -220,7 +204,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         }
         if (active) phase_barrier<16>(); else phase_barrier<0>();     // hn gathers stay in flight
         // ===== phase 3: T4 = SiLU(W3 T3 + b3) =====
-        if (!active) stage_weight<NW>(a.w4p, buf1, wave, lane16);
+        if (!active) gamd_stage_weight<NW>(a.w4p, buf1, wave, lane16);
         if (active_n) {
             const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
             if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
@@ -233,7 +217,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         }
         phase_barrier<0>();
         // ===== phase 4: e_emb = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
-        if (!active) stage_weight<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
+        if (!active) gamd_stage_weight<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
         if (active) {
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {

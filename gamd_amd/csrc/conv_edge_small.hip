@@ -14,50 +14,7 @@
 
 namespace {
 
-constexpr int XLD = 132;
-
-struct WQuarter { f32x4 w[16]; };
-
-__device__ __forceinline__ void load_wquarter(const float* __restrict__ Wp, int quarter, int lane, WQuarter& o) {
-    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 16 * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o.w[i] = W[i * 64];
-}
-
-template <bool F2>
-__device__ __forceinline__ void gemm_quarter(const WQuarter& wq, const f32x16 (&X)[4], f32x16& acc) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc = F2 ? mfma32(X[t][q * 4 + j], wq.w[t * 4 + q][j], acc) : mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
-}
-
-__device__ __forceinline__ f32x16 load_slice(const float* __restrict__ row, int quarter, int half) {
-    f32x16 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 32 * quarter + 8 * q + 4 * half);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[q * 4 + j] = x[j];
-    }
-    return v;
-}
-
-__device__ __forceinline__ void exchange(float* xbuf, int quarter, int slot, int half, const f32x16& mine, f32x16 (&X)[4]) {
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = mine[q * 4 + j];
-        *reinterpret_cast<f32x4*>(xbuf + slot * XLD + 32 * quarter + 8 * q + 4 * half) = x;
-    }
-    __syncthreads();
-    load_row_chain(xbuf + slot * XLD, half, X);
-}
+constexpr int XLD = GAMD_XLD;
 
 // EHT, HT: edge-embedding / node width in 128-blocks (wide.hip); the weight blocks W1[:, kb] | W2 | W3 | W4[ob, :] are
 // contiguous from a.w1p (gamd_finalize_weights lays them out that way for every width).  WIDE selects the operation
@@ -71,8 +28,12 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
     int E = a.counters[CNT_E];
     if ((long long)E > a.e_cap) E = (int)a.e_cap;
     const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
+    // hybrid launch (ConvEdgeArgs::split_wgs): k_conv_edge has taken the whole rounds of 4-tile units; this kernel
+    // finishes the launch tail, one tile per workgroup = a quarter tile per SIMD instead of a whole one
+    int tile_begin = 0;
+    if (a.split_wgs > 0) tile_begin = 4 * ((((n_tiles + 3) / 4) / a.split_wgs) * a.split_wgs);
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = tile_begin + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
         const int src = valid ? a.col[x] : 0;

@@ -141,6 +141,16 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         load_bias_chain(vb3, half, acc);
         gemm128<false>((const f32x4*)w3, lane, X, acc);
         if (!(ABL & 2)) layernorm_chain(acc, vg, vbeta, half, 1e-5f);
+        if (a.self_loop) {
+            // self_loop_mode 1: the last edge of every row is the loop an in-place add_self_loop would have appended AFTER
+            // edata['e'] was set (nn_module.py:649-652): its embedding is DGL's zero fill, not an encoded feature row
+            if (valid && x == (long long)a.row_ptr[dst + 1] - 1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            }
+        }
         // ---- store e fragment: 16 x 1 KiB coalesced ----
         // next tile's positions (indices arrived long ago); consumed at the top of the next iteration
         src_c = src_n; dst_c = dst_n;
@@ -179,14 +189,18 @@ static int launch_abl(const EncArgs& a, int n_blocks, hipStream_t st) {
 }
 
 int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st) {
+#ifdef GAMD_PROFILING
+    // timing ablations (wrong results by construction): compiled into libgamd_hip_prof.so only
     static int v = -1;
     if (v < 0) { const char* s = getenv("GAMD_ENC_VARIANT"); v = s ? atoi(s) : 0; }
-    switch (v) {                                   // non-zero: timing ablations for profiling only
+    switch (v) {
         case 1: return launch_abl<1>(a, n_blocks, st);
         case 2: return launch_abl<2>(a, n_blocks, st);
         case 4: return launch_abl<4>(a, n_blocks, st);
         case 8: return launch_abl<8>(a, n_blocks, st);
         case 15: return launch_abl<15>(a, n_blocks, st);
-        default: return launch_abl<0>(a, n_blocks, st);
+        default: break;
     }
+#endif
+    return launch_abl<0>(a, n_blocks, st);
 }

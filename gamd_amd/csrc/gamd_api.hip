@@ -58,10 +58,38 @@ struct LayerDev {
     NodeLayerW node;
 };
 
+// every entry point runs on the handle's device and leaves the caller's current device as it found it
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// the gamd_md_run / gamd_md_run_nhc call whose steps are still in the stream: what gamd_sync_status needs to finish the
+// run after a neighbour-buffer overflow froze it
+struct MdPending {
+    bool active = false;
+    int kind = 0;                      // 0: split BAOAB, 1: split Nose-Hoover chain
+    MdArgs m{};
+    NhcArgs a{};
+    unsigned long long first_step = 0;
+    long long n_steps = 0;
+    float* x = nullptr;
+    float* f = nullptr;
+    const uint8_t* species = nullptr;
+    hipStream_t st = nullptr;
+};
+
 }  // namespace
 
 struct gamd_handle {
     gamd_config cfg{};
+    int dev = 0;
     int n = 0, L = 0, n_feat = 44, n_cu = 256;
     int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width and their 128-blocks
     bool wide_enc = false, wide_conv = false;    // generic-width kernels of wide.hip
@@ -92,7 +120,12 @@ struct gamd_handle {
     int* counters_host = nullptr;   // pinned
     int* sticky_host = nullptr;     // pinned + mapped: overflow flags and rebuild count, written by kernels directly
     int* sticky_dev = nullptr;
+    DevBuf devflags;                // [DEVFLAG_COUNT] device-resident freeze flag + where an MD run stopped
+    const float* feat_dev = nullptr;   // gamd_set_node_features
+    const uint8_t* rigid_checked = nullptr;   // species pointer whose O,H,H layout has been validated
+    MdPending pending;
     bool has_bonds = false;
+    bool hybrid_tail = true;
     // Verlet-skin reuse (cfg.neighbor_skin > 0)
     float skin = 0.f;
     DevBuf ref_pos, cand_deg, cand_ptr, cand_col;
@@ -174,6 +207,9 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
     a.e_cap = h->e_cap;
     a.pos = pos_dev;
     a.species = species_dev;
+    a.feat = h->feat_dev;
+    a.self_loop = h->cfg.self_loop_mode == GAMD_SELF_LOOP_APPEND_ZERO_FEATURE ? 1 : 0;
+    a.devflags = h->devflags.as<int>();
     a.pos_w = h->pos_w.as<float4>();
     a.pos_s = h->pos_s.as<float4>();
     a.cell_of = h->cell_of.as<int>();
@@ -311,14 +347,13 @@ const HostTensor* find_w(gamd_handle* h, const std::string& name, std::initializ
 struct EdgeList { const int* centre; const int* neigh; long long n; };
 
 // rigid-water block shared by both integrators; returns 0 or an error code (message set)
-int fill_rigid(const gamd_handle* h, int rigid_water, float mass_o, float mass_h, float r_oh, float r_hh, const uint8_t* species,
+int fill_rigid(const gamd_handle* h, int rigid_water, float mass_o, float mass_h, float r_oh, float r_hh,
                int* use_rigid, RigidWater* g) {
     *use_rigid = 0;
     if (!rigid_water) return 0;
     if (h->n % 3 != 0) return fail(-22, "rigid_water needs O,H,H triples: n_atoms = %d is not a multiple of 3", h->n);
     if (!(mass_h > 0.f) || !(mass_o > 0.f)) return fail(-22, "rigid_water needs mass_amu (O) and mass_h_amu (H)");
     if (!(r_oh > 0.f) || !(r_hh > 0.f) || !(r_hh < 2.f * r_oh)) return fail(-22, "rigid_water needs 0 < r_hh < 2 r_oh");
-    (void)species;
     const double rc = 0.5 * (double)r_hh, t = std::sqrt((double)r_oh * r_oh - rc * rc);
     const double ra = t * 2.0 * mass_h / ((double)mass_o + 2.0 * mass_h);
     g->m_o = mass_o; g->m_h = mass_h;
@@ -355,6 +390,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.erow = h->erow.as<int>();
     ea.bond_nbr = h->has_bonds ? h->bond_nbr.as<int>() : nullptr;
     ea.perm = h->perm.as<int>();
+    ea.row_ptr = h->row_ptr.as<int>();
+    ea.self_loop = na.self_loop;
     for (int d = 0; d < 3; ++d) { ea.box[d] = h->box[d]; ea.half[d] = 0.5f * h->box[d]; }
     ea.length_mean = h->length_mean;
     ea.length_std = h->length_std;
@@ -380,6 +417,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
 
     NodeArgs no{};
     no.counters = h->counters.as<int>();
+    no.devflags = h->devflags.as<int>();
+    no.sticky = h->sticky_dev;
     no.n = h->n;
     no.pos_s = h->pos_s.as<float4>();
     no.node_emb = h->node_emb; no.enc_w = h->nenc_w; no.enc_b = h->nenc_b;
@@ -406,10 +445,15 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     // shows in the results.
     int small_tiles = 0;
     if (h->cfg.edge_dtype == GAMD_EDGE_F32) {
-        const long long e_est = el ? el->n : (h->counters_host[CNT_E] > 0 ? (long long)h->counters_host[CNT_E] : (long long)((double)h->e_cap / 1.5));
+        const long long e_est = el ? el->n + (na.self_loop ? h->n : 0)
+                                   : (h->counters_host[CNT_E] > 0 ? (long long)h->counters_host[CNT_E] : (long long)((double)h->e_cap / 1.5));
         const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
         if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
     }
+    // Large fp32 launches: the throughput kernel takes the whole rounds of work (every workgroup the same number of
+    // 4-tile units) and the latency kernel the < 4 * n_cu tiles that are left, a quarter tile per SIMD instead of a
+    // whole one: the launch tail shrinks from half a round to a fraction of it.  Bit-identical per tile either way.
+    const bool hybrid = h->hybrid_tail && !h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F32 && small_tiles == 0;
     for (int l = 0; l < h->L; ++l) {
         ConvEdgeArgs ca{};
         ca.counters = h->counters.as<int>();
@@ -422,6 +466,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
         ca.partial = h->partial.as<float>();
         ca.e_cap = h->e_cap;
+        ca.split_wgs = hybrid ? h->n_cu : 0;
         ca.tdbg = h->tdbg.as<long long>();
         if (h->timing) {
             if (h->tev_used + 2 > h->tev.size()) {
@@ -434,6 +479,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st)
             : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3(ca, h->n_cu, st)
             : small_tiles > 0 ? launch_conv_edge_small(ca, small_tiles, st) : launch_conv_edge(ca, h->n_cu, st);
+        if (r == 0 && hybrid) r = launch_conv_edge_small(ca, 4 * h->n_cu, st);
         if (r) return fail(-1, "conv edge launch failed (%d)", r);
         if (h->timing) { HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st)); h->tev_used += 2; }
         mark("conv_edge");
@@ -456,6 +502,56 @@ int check_ready(gamd_handle* h) {
     return 0;
 }
 
+// what every force evaluation needs besides positions and box (shared by the forces, md_run and profile entry points)
+int check_model_inputs(gamd_handle* h, const uint8_t* species_dev) {
+    if (h->cfg.kind == GAMD_KIND_WATER && !species_dev && !h->feat_dev)
+        return fail(-22, "water model needs species (or gamd_set_node_features)");
+    if (h->cfg.use_bond && !h->has_bonds) return fail(-22, "use_bond set but no bonds given (gamd_set_bonds)");
+    return 0;
+}
+
+// rigid_water integrates O,H,H triples: check once per species buffer that the layout really is 1,0,0 per molecule
+int check_rigid_layout(gamd_handle* h, const uint8_t* species_dev, hipStream_t st) {
+    if (!species_dev) return fail(-22, "rigid_water needs species (O = 1, H = 0, atoms ordered O,H,H)");
+    if (h->rigid_checked == species_dev) return 0;
+    std::vector<uint8_t> sp((size_t)h->n);
+    HIP_TRY(hipMemcpyAsync(sp.data(), species_dev, sp.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < h->n; ++i)
+        if ((sp[(size_t)i] != 0) != (i % 3 == 0))
+            return fail(-22, "rigid_water needs atoms ordered O,H,H per molecule: species[%d] = %d", i, (int)sp[(size_t)i]);
+    h->rigid_checked = species_dev;
+    return 0;
+}
+
+int clear_devflags(gamd_handle* h) {
+    const int init[DEVFLAG_COUNT] = {0, -1, 0, 0};
+    HIP_TRY(hipMemcpy(h->devflags.p, init, sizeof(init), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// steps [s_begin, n_steps) of the pending MD run; skip_first: the first half of step s_begin has already been done
+int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
+    MdPending& p = h->pending;
+    int r;
+    for (long long s = s_begin; s < p.n_steps; ++s) {
+        const bool first = !(skip_first && s == s_begin);
+        if (p.kind == 0) {
+            p.m.step = p.first_step + (unsigned long long)s;
+            p.m.step_index = (int)s;
+            if (first && (r = launch_baoab_first(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
+            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr))) return r;
+            if ((r = launch_baoab_second(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
+        } else {
+            p.a.step_index = (int)s;
+            if (first && (r = launch_nhc_first(p.a, p.st))) return fail(-1, "integrator launch failed (%d)", r);
+            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr))) return r;
+            if ((r = launch_nhc_second(p.a, p.st))) return fail(-1, "integrator launch failed (%d)", r);
+        }
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -471,10 +567,17 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     if (cfg->edge_dtype != GAMD_EDGE_F32 && cfg->edge_dtype != GAMD_EDGE_BF16 && cfg->edge_dtype != GAMD_EDGE_F16X3)
         return fail(-22, "unknown edge_dtype");
     if (!(cfg->neighbor_skin >= 0.f)) return fail(-22, "neighbor_skin must be >= 0");
+    if (cfg->self_loop_mode != GAMD_SELF_LOOP_DGL07_NOOP && cfg->self_loop_mode != GAMD_SELF_LOOP_APPEND_ZERO_FEATURE)
+        return fail(-22, "unknown self_loop_mode %d", cfg->self_loop_mode);
+    if (cfg->self_loop_mode != GAMD_SELF_LOOP_DGL07_NOOP && cfg->edge_dtype != GAMD_EDGE_F32)
+        return fail(-22, "self_loop_mode 1 is built for the fp32 edge dtype only");
+    if (cfg->kernel_select & ~(GAMD_KSEL_FORCE_GENERIC_WIDTH | GAMD_KSEL_NO_HYBRID_TAIL))
+        return fail(-22, "unknown kernel_select bits 0x%x", cfg->kernel_select);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(-19, "no HIP device available: libgamd_hip has no CPU fallback");
-    HIP_TRY(hipSetDevice(cfg->device));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(-22, "device %d out of range (%d visible)", cfg->device, ndev);
+    DeviceGuard guard(cfg->device);            // the caller's current device is restored on every return path
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
     const int H = cfg->encoding_size ? cfg->encoding_size : 128, Eh = cfg->edge_embedding_dim ? cfg->edge_embedding_dim : 128;
@@ -486,13 +589,14 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         return fail(-22, "the bf16 and split-fp16 edge-MLPs are built for the 128-wide RBF-expanded configuration only");
     gamd_handle* h = new gamd_handle();
     h->cfg = *cfg;
+    h->dev = cfg->device;
     h->n = cfg->n_atoms;
     h->L = cfg->n_layers;
     h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
     h->skin = cfg->neighbor_skin;
-    if (const char* s = getenv("GAMD_CONV_SMALL_TILES")) h->small_tile_limit = atoll(s);     // tuning / test hook
-    const char* force_wide = getenv("GAMD_FORCE_WIDE");      // test hook: run the 128-wide config on wide.hip
-    const bool forced = force_wide && force_wide[0] == '1' && cfg->edge_dtype == GAMD_EDGE_F32;
+    if (cfg->small_tile_limit != 0) h->small_tile_limit = cfg->small_tile_limit < 0 ? -1 : cfg->small_tile_limit;
+    h->hybrid_tail = !(cfg->kernel_select & GAMD_KSEL_NO_HYBRID_TAIL);
+    const bool forced = (cfg->kernel_select & GAMD_KSEL_FORCE_GENERIC_WIDTH) && cfg->edge_dtype == GAMD_EDGE_F32;
     h->wide_enc = generic || forced;
     h->wide_conv = H != 128 || Eh != 128 || forced;
     h->n_feat = (cfg->no_expand_edge ? 4 : 44) + (cfg->use_bond ? 1 : 0);
@@ -516,7 +620,9 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->f_norm.ensure(sizeof(float) * 3 * n, true);
     r |= h->f_den.ensure(sizeof(float) * 3 * n, true);
     r |= h->tdbg.ensure(sizeof(long long) * 16 * 8 * 1024, true);
+    r |= h->devflags.ensure(sizeof(int) * DEVFLAG_COUNT, true);
     if (r) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
+    if ((r = clear_devflags(h))) { gamd_destroy(h); return r; }
     if (hipHostMalloc((void**)&h->counters_host, sizeof(int) * CNT_COUNT) != hipSuccess) {
         gamd_destroy(h);
         return fail(-12, "pinned allocation failed");
@@ -542,6 +648,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         const double per_atom = 4.18879 * std::pow((double)cfg->cutoff, 3) * (double)h->n / vol + 1.0;
         ecap = (long long)(1.5 * per_atom * (double)h->n) + 1024;
     }
+    if (cfg->self_loop_mode) ecap += h->n;
     if ((r = alloc_edges(h, ecap))) { gamd_destroy(h); return r; }
     *out = h;
     return 0;
@@ -549,6 +656,8 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
 
 int32_t gamd_destroy(gamd_handle* h) {
     if (!h) return 0;
+    DeviceGuard guard(h->dev);
+    h->devflags.release();
     DevBuf* bufs[] = {&h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
@@ -575,6 +684,7 @@ int32_t gamd_load_weight(gamd_handle* h, const char* name, const float* data, co
 
 int32_t gamd_finalize_weights(gamd_handle* h) {
     if (!h) return fail(-22, "null handle");
+    DeviceGuard guard(h->dev);
     const int F = h->n_feat, L = h->L;
     const int64_t H = h->H, Eh = h->Eh, HT = h->HT, EHT = h->EHT;
     const bool expand = !h->cfg.no_expand_edge;
@@ -711,6 +821,7 @@ int32_t gamd_set_scaler(gamd_handle* h, double mean, double var) {
 
 int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds) {
     if (!h || (!bonds && n_bonds > 0)) return fail(-22, "bad argument to gamd_set_bonds");
+    DeviceGuard guard(h->dev);
     std::vector<int> tab((size_t)h->n * 4, -1);
     auto add = [&](int i, int j) -> int {
         for (int k = 0; k < 4; ++k) {
@@ -730,10 +841,26 @@ int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds) {
     return 0;
 }
 
+int32_t gamd_set_node_features(gamd_handle* h, const float* feat_dev) {
+    if (!h) return fail(-22, "null handle");
+    if (feat_dev && h->cfg.kind != GAMD_KIND_WATER) return fail(-22, "node features belong to the water models (the LJ model has node_emb)");
+    h->feat_dev = feat_dev;
+    return 0;
+}
+
+int32_t gamd_get_device_flags(gamd_handle* h, int32_t flags[4]) {
+    if (!h || !flags) return fail(-22, "null argument");
+    flags[0] = h->sticky_host[STICKY_NONFINITE] ? 1 : 0;
+    flags[1] = flags[2] = flags[3] = 0;
+    h->sticky_host[STICKY_NONFINITE] = 0;
+    return 0;
+}
+
 int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box, void* stream) {
     int r;
     if ((r = check_ready(h))) return r;
     if (!pos_dev || !box) return fail(-22, "null argument");
+    DeviceGuard guard(h->dev);
     hipStream_t st = (hipStream_t)stream;
     for (int attempt = 0; attempt < 4; ++attempt) {
         if ((r = set_box(h, box))) return r;
@@ -746,6 +873,7 @@ int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t
         if (!h->counters_host[CNT_OVERFLOW]) return attempt ? 1 : 0;
         const long long need = (long long)(1.25 * (double)h->counters_host[CNT_E]) + 1024;
         if ((r = alloc_edges(h, need))) return r;
+        if ((r = clear_devflags(h))) return r;
     }
     return fail(-34, "neighbor buffers still overflow after regrowing");
 }
@@ -755,36 +883,61 @@ int32_t gamd_forces_async(gamd_handle* h, const float* pos_dev, const uint8_t* s
     int r;
     if ((r = check_ready(h))) return r;
     if (!pos_dev || !box) return fail(-22, "null argument");
-    if (h->cfg.kind == GAMD_KIND_WATER && !species_dev) return fail(-22, "water model needs species");
-    if (h->cfg.use_bond && !h->has_bonds) return fail(-22, "use_bond set but no bonds given (gamd_set_bonds)");
+    if ((r = check_model_inputs(h, species_dev))) return r;
+    DeviceGuard guard(h->dev);
     if ((r = set_box(h, box))) return r;
+    h->pending.active = false;
     return enqueue_forward(h, pos_dev, species_dev, out_norm_dev, out_denorm_dev, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 int32_t gamd_sync_status(gamd_handle* h, void* stream) {
     if (!h) return fail(-22, "null handle");
-    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    // the sticky flags catch an overflow in ANY step enqueued since the last check (gamd_md_run), not only the last
-    if (h->sticky_host[STICKY_CAND_OVERFLOW]) {
+    DeviceGuard guard(h->dev);
+    bool resumed = false;
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        // the sticky flags catch an overflow in ANY step enqueued since the last check (gamd_md_run), not only the last
+        const bool cand_ovf = h->sticky_host[STICKY_CAND_OVERFLOW] != 0;
+        const bool edge_ovf = h->counters_host[CNT_OVERFLOW] || h->sticky_host[STICKY_EDGE_OVERFLOW];
+        if (!cand_ovf && !edge_ovf) {
+            h->pending.active = false;
+            if (h->cfg.edge_dtype != GAMD_EDGE_F32 && h->sticky_host[STICKY_NONFINITE])
+                return fail(-33, "non-finite forces with a reduced-precision edge dtype: an MFMA operand left the fp16 range "
+                                 "(|x| > 65504) or the input positions are not finite");
+            return resumed ? 1 : 0;
+        }
+        int r;
+        long long need = 0;
+        if (cand_ovf) {
+            const long long seen = std::max<long long>(h->sticky_host[STICKY_NCAND], h->cand_cap);
+            need = (long long)(1.25 * (double)seen) + 1024;
+            if ((r = alloc_candidates(h, need))) return r;
+        }
+        if (edge_ovf) {
+            const long long seen = std::max<long long>(h->counters_host[CNT_E], h->e_cap);
+            need = (long long)(1.25 * (double)seen) + 1024;
+            if ((r = alloc_edges(h, need))) return r;
+            h->cand_valid = false;
+        }
         h->sticky_host[STICKY_CAND_OVERFLOW] = 0;
         h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
-        const long long seen = std::max<long long>(h->sticky_host[STICKY_NCAND], h->cand_cap);
-        const long long need = (long long)(1.25 * (double)seen) + 1024;
-        int r = alloc_candidates(h, need);
-        if (r) return r;
-        return fail(-34, "candidate neighbour buffers overflowed; regrown to %lld, re-issue the call", need);
+        h->counters_host[CNT_OVERFLOW] = 0;
+        int flags[DEVFLAG_COUNT] = {0, -1, 0, 0};
+        HIP_TRY(hipMemcpy(flags, h->devflags.p, sizeof(flags), hipMemcpyDeviceToHost));
+        if ((r = clear_devflags(h))) return r;
+        if (!h->pending.active)
+            return fail(-34, "%s neighbour buffers overflowed; regrown to %lld, re-issue the call", cand_ovf ? "candidate" : "edge", need);
+        // an enqueued MD run froze at (step, half): forces at the frozen positions, the rest of that step, the remaining steps
+        const int at = flags[DEVFLAG_FROZEN_AT];
+        if (at < 0) {
+            h->pending.active = false;
+            return fail(-34, "neighbour buffers overflowed inside an MD run but no integrator kernel recorded where it stopped");
+        }
+        if ((r = enqueue_md_steps(h, at / 2, (at & 1) != 0))) return r;
+        resumed = true;
     }
-    if (h->counters_host[CNT_OVERFLOW] || h->sticky_host[STICKY_EDGE_OVERFLOW]) {
-        h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
-        const long long seen = std::max<long long>(h->counters_host[CNT_E], h->e_cap);
-        const long long need = (long long)(1.25 * (double)seen) + 1024;
-        int r = alloc_edges(h, need);
-        if (r) return r;
-        h->cand_valid = false;
-        return fail(-34, "neighbour buffers overflowed (E=%d); regrown to %lld, re-issue the call",
-                    h->counters_host[CNT_E], need);
-    }
-    return 0;
+    h->pending.active = false;
+    return fail(-34, "neighbour buffers still overflow after regrowing four times");
 }
 
 int32_t gamd_forces(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
@@ -805,16 +958,18 @@ int32_t gamd_forces_edges(gamd_handle* h, const float* pos_dev, const uint8_t* s
     int r;
     if ((r = check_ready(h))) return r;
     if (!pos_dev || !box || n_edges < 0 || (n_edges > 0 && (!centre_dev || !neigh_dev))) return fail(-22, "bad argument");
-    if (h->cfg.kind == GAMD_KIND_WATER && !species_dev) return fail(-22, "water model needs species");
-    if (h->cfg.use_bond && !h->has_bonds) return fail(-22, "use_bond set but no bonds given (gamd_set_bonds)");
+    if ((r = check_model_inputs(h, species_dev))) return r;
     if (n_edges > 0x7fff0000ll) return fail(-22, "edge list too long");
+    DeviceGuard guard(h->dev);
     if ((r = set_box(h, box))) return r;
+    h->pending.active = false;
     int status = 0;
-    if (n_edges > h->e_cap) {                       // the count is known up front: grow before launching
-        if ((r = alloc_edges(h, n_edges + n_edges / 8 + 1024))) return r;
+    const long long total = n_edges + (h->cfg.self_loop_mode ? h->n : 0);     // + one appended loop per atom
+    if (total > h->e_cap) {                         // the count is known up front: grow before launching
+        if ((r = alloc_edges(h, total + total / 8 + 1024))) return r;
         status = 1;
     }
-    if (h->tmp_eid.ensure(sizeof(int) * ((size_t)std::max<long long>(n_edges, 1) + 64), false))
+    if (h->tmp_eid.ensure(sizeof(int) * ((size_t)std::max<long long>(total, 1) + 64), false))
         return fail(-12, "edge scratch allocation failed");
     EdgeList el{centre_dev, neigh_dev, (long long)n_edges};
     if ((r = enqueue_forward(h, pos_dev, species_dev, out_norm_dev, out_denorm_dev, (hipStream_t)stream, nullptr, nullptr,
@@ -822,8 +977,13 @@ int32_t gamd_forces_edges(gamd_handle* h, const float* pos_dev, const uint8_t* s
         return r;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
-    if (h->counters_host[CNT_OVERFLOW] == 2) return fail(-22, "edge list references an atom index outside [0, n_atoms)");
-    if (h->counters_host[CNT_OVERFLOW]) return fail(-34, "edge buffers overflowed unexpectedly");
+    if (h->counters_host[CNT_OVERFLOW]) {
+        const int why = h->counters_host[CNT_OVERFLOW];
+        h->counters_host[CNT_OVERFLOW] = 0;
+        if ((r = clear_devflags(h))) return r;
+        if (why == 2) return fail(-22, "edge list references an atom index outside [0, n_atoms)");
+        return fail(-34, "edge buffers overflowed unexpectedly");
+    }
     return status;
 }
 
@@ -845,6 +1005,7 @@ int32_t gamd_get_skin_stats(gamd_handle* h, int64_t* n_rebuilds, int64_t* n_cand
 
 int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t bytes) {
     if (!h || !host_out) return fail(-22, "null argument");
+    DeviceGuard guard(h->dev);
     HIP_TRY(hipDeviceSynchronize());
     const size_t n = (size_t)h->n;
     const size_t E = (size_t)std::min<long long>(h->counters_host[CNT_E], h->e_cap);
@@ -860,7 +1021,7 @@ int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t byte
     } else if (what >= GAMD_DBG_H0 && what <= GAMD_DBG_H0 + h->L) {
         if (!h->cfg.keep_stages) return fail(-22, "H_l needs keep_stages=1");
         src = h->hbuf.as<float>() + (size_t)(what - GAMD_DBG_H0) * n * (size_t)h->H; avail = sizeof(float) * n * (size_t)h->H;
-    } else if (what == 5) { src = h->tdbg.p; avail = sizeof(long long) * 16 * 8 * (size_t)h->n_cu;
+    } else if (what == GAMD_DBG_CYCLES) { src = h->tdbg.p; avail = sizeof(long long) * 16 * 8 * (size_t)h->n_cu;
     } else return fail(-22, "unknown debug tensor %d", what);
     if (bytes < avail) return fail(-22, "host buffer too small: %zu < %zu", bytes, avail);
     HIP_TRY(hipMemcpy(host_out, src, avail, hipMemcpyDeviceToHost));
@@ -872,6 +1033,9 @@ int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, co
     int r;
     if ((r = check_ready(h))) return r;
     if (!x_dev || !v_dev || !f_dev || !box || !p) return fail(-22, "null argument");
+    if (n_steps < 0 || n_steps > 0x3fffffff) return fail(-22, "n_steps out of range");
+    if ((r = check_model_inputs(h, species_dev))) return r;
+    DeviceGuard guard(h->dev);
     if ((r = set_box(h, box))) return r;
     hipStream_t st = (hipStream_t)stream;
     MdArgs m{};
@@ -886,17 +1050,16 @@ int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, co
     const double a = std::exp(-(double)p->gamma_per_ps * p->dt_ps);
     m.a = (float)a;
     m.b_len_kT = (float)(std::sqrt(1.0 - a * a) * (double)m.len * std::sqrt(kB * p->temperature_k));
-    if ((r = fill_rigid(h, p->rigid_water, p->mass_amu, p->mass_h_amu, p->r_oh, p->r_hh, species_dev, &m.use_rigid, &m.rigid)))
+    if ((r = fill_rigid(h, p->rigid_water, p->mass_amu, p->mass_h_amu, p->r_oh, p->r_hh, &m.use_rigid, &m.rigid)))
         return r;
+    if (m.use_rigid && (r = check_rigid_layout(h, species_dev, st))) return r;
     for (int d = 0; d < 3; ++d) m.box[d] = box[d];
     m.seed = p->seed;
-    for (int64_t s = 0; s < n_steps; ++s) {
-        m.step = p->first_step + (uint64_t)s;
-        if ((r = launch_baoab_first(m, st))) return fail(-1, "integrator launch failed (%d)", r);
-        if ((r = enqueue_forward(h, x_dev, species_dev, nullptr, f_dev, st, nullptr, nullptr, nullptr))) return r;
-        if ((r = launch_baoab_second(m, st))) return fail(-1, "integrator launch failed (%d)", r);
-    }
-    return 0;
+    m.devflags = h->devflags.as<int>();
+    MdPending& pd = h->pending;
+    pd.active = true; pd.kind = 0; pd.m = m; pd.first_step = p->first_step; pd.n_steps = n_steps;
+    pd.x = x_dev; pd.f = f_dev; pd.species = species_dev; pd.st = st;
+    return enqueue_md_steps(h, 0, false);
 }
 
 int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
@@ -904,13 +1067,16 @@ int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev
     int r;
     if ((r = check_ready(h))) return r;
     if (!x_dev || !v_dev || !f_dev || !box || !p || !chain_state_dev) return fail(-22, "null argument");
+    if (n_steps < 0 || n_steps > 0x3fffffff) return fail(-22, "n_steps out of range");
     if (p->chain_length < 1 || p->chain_length > 16) return fail(-22, "chain_length must be in [1, 16]");
+    if ((r = check_model_inputs(h, species_dev))) return r;
     static const double YS1[] = {1.0};
     static const double YS3[] = {0.8289815435887510, -0.6579630871775020, 0.8289815435887510};
     static const double YS5[] = {0.2967324292201065, 0.2967324292201065, -0.1869297168804260, 0.2967324292201065,
                                  0.2967324292201065};                       // hack_integrator.py:183-187
     const double* ys = p->num_yoshidasuzuki == 1 ? YS1 : p->num_yoshidasuzuki == 3 ? YS3 : p->num_yoshidasuzuki == 5 ? YS5 : nullptr;
     if (!ys) return fail(-22, "Invalid Yoshida-Suzuki value. Allowed values are: 1,3,5");
+    DeviceGuard guard(h->dev);
     if ((r = set_box(h, box))) return r;
     hipStream_t st = (hipStream_t)stream;
     NhcArgs a{};
@@ -920,8 +1086,9 @@ int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev
     a.mass = p->mass_amu; a.mass_h = p->mass_h_amu > 0.f ? p->mass_h_amu : 0.f;
     a.len = p->length_per_nm > 0.f ? p->length_per_nm : 10.0f;
     a.dt = p->dt_ps;
-    if ((r = fill_rigid(h, p->rigid_water, p->mass_amu, p->mass_h_amu, p->r_oh, p->r_hh, species_dev, &a.use_rigid, &a.rigid)))
+    if ((r = fill_rigid(h, p->rigid_water, p->mass_amu, p->mass_h_amu, p->r_oh, p->r_hh, &a.use_rigid, &a.rigid)))
         return r;
+    if (a.use_rigid && (r = check_rigid_layout(h, species_dev, st))) return r;
     for (int d = 0; d < 3; ++d) a.box[d] = box[d];
     a.kT = 0.00831446261815324 * (double)p->temperature_k;
     a.freq = p->frequency_per_ps;
@@ -932,18 +1099,17 @@ int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev
     a.n_blocks = std::min(256, (3 * h->n + 255) / 256);
     if (h->ke_partial.ensure(sizeof(double) * 256, true)) return fail(-12, "allocation failed");
     a.partial = h->ke_partial.as<double>();
+    a.devflags = h->devflags.as<int>();
     if (p->reset) {
         std::vector<double> init(3 * a.M + 2, 0.0);
         for (int i = 0; i < a.M; ++i) init[2 * a.M + i] = -a.freq * a.freq;      // G_i = -frequency^2 (:255)
         HIP_TRY(hipMemcpyAsync(chain_state_dev, init.data(), sizeof(double) * init.size(), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    for (int64_t s = 0; s < n_steps; ++s) {
-        if ((r = launch_nhc_first(a, st))) return fail(-1, "integrator launch failed (%d)", r);
-        if ((r = enqueue_forward(h, x_dev, species_dev, nullptr, f_dev, st, nullptr, nullptr, nullptr))) return r;
-        if ((r = launch_nhc_second(a, st))) return fail(-1, "integrator launch failed (%d)", r);
-    }
-    return 0;
+    MdPending& pd = h->pending;
+    pd.active = true; pd.kind = 1; pd.a = a; pd.first_step = 0; pd.n_steps = n_steps;
+    pd.x = x_dev; pd.f = f_dev; pd.species = species_dev; pd.st = st;
+    return enqueue_md_steps(h, 0, false);
 }
 
 int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
@@ -952,7 +1118,10 @@ int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* specie
     int r;
     if ((r = check_ready(h))) return r;
     if (!pos_dev || !box || !names || !ms || !n_out) return fail(-22, "null argument");
+    if ((r = check_model_inputs(h, species_dev))) return r;
+    DeviceGuard guard(h->dev);
     if ((r = set_box(h, box))) return r;
+    h->pending.active = false;
     hipStream_t st = (hipStream_t)stream;
     const int max_ev = 64;
     hipEvent_t evs[max_ev];
@@ -987,6 +1156,7 @@ int32_t gamd_timing_enable(gamd_handle* h, int32_t enable) {
 
 int32_t gamd_timing_read(gamd_handle* h, void* stream, double* total_ms, int64_t* n_launches) {
     if (!h || !total_ms || !n_launches) return fail(-22, "null argument");
+    DeviceGuard guard(h->dev);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     double tot = 0.0;
     for (size_t i = 0; i + 1 < h->tev_used; i += 2) {

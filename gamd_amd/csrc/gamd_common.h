@@ -179,6 +179,92 @@ __device__ __forceinline__ void layernorm_chain(f32x16 (&X)[4], GPtr gamma, GPtr
         }
 }
 
+// ---- shared building blocks of several kernels -------------------------------------------------------------------
+// L2 -> LDS copy of one packed 64 KiB weight matrix by the NW waves of a workgroup (64 / NW x 1 KiB per wave) with
+// global_load_lds.  lane16 = lane * 16 is made opaque so the 64-bit addresses are rebuilt (1 VALU each) instead of
+// being hoisted out of the tile loop and spilled (a spilled pointer = scratch reload + s_waitcnt vmcnt(0) in front of
+// every copy).
+template <int NW = 8>
+__device__ __forceinline__ void gamd_stage_weight(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
+    asm volatile("" : "+v"(lane16));
+#pragma unroll
+    for (int k = 0; k < 64 / NW; ++k) {
+        const int chunk = k * NW + wave;      // 64 chunks of 1 KiB, lane-linear image == packed global image
+        const char* base = reinterpret_cast<const char*>(gw) + chunk * 1024;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(base + lane16),
+            (__attribute__((address_space(3))) void*)(ldsbuf + chunk * 256), 16, 0, 0);
+    }
+}
+
+// Latency-oriented split of a 32-row tile over the 4 waves of a 256-thread workgroup (node.hip, conv_edge_small.hip,
+// wide.hip's node kernel): wave `quarter` computes output features [32 quarter, 32 quarter + 32) of every GEMM from its
+// 16 KiB weight quarter, fetched from L2 in ONE batch of 16 float4 per lane (a GEMM then costs one L2 round trip, not
+// sixteen), and the 128-wide activation rows are re-assembled through a padded LDS exchange buffer between GEMMs.
+struct WQuarter { f32x4 w[16]; };
+
+__device__ __forceinline__ void load_wquarter(const float* __restrict__ Wp, int quarter, int lane, WQuarter& o) {
+    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 16 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o.w[i] = W[i * 64];
+}
+
+// acc (this wave's 32 output features x 32 rows, one C tile) += W[quarter] * X^T   (F2: X * W[quarter]^T, row layout)
+template <bool F2 = false>
+__device__ __forceinline__ void gemm_quarter(const WQuarter& wq, const f32x16 (&X)[4], f32x16& acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc = F2 ? mfma32(X[t][q * 4 + j], wq.w[t * 4 + q][j], acc) : mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
+}
+
+// 16 floats of a plain row-major [128] row that belong to (quarter, half) in chain order
+__device__ __forceinline__ f32x16 load_slice(const float* __restrict__ row, int quarter, int half) {
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 32 * quarter + 8 * q + 4 * half);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[q * 4 + j] = x[j];
+    }
+    return v;
+}
+
+__device__ __forceinline__ void store_slice(float* __restrict__ row, int quarter, int half, const f32x16& v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = v[q * 4 + j];
+        *reinterpret_cast<f32x4*>(row + 32 * quarter + 8 * q + 4 * half) = x;
+    }
+}
+
+// every wave contributes its quarter of each of NB 128-blocks of the rows; afterwards every wave holds the full rows
+// in chain layout.  XLDW: padded row stride of the exchange buffer in floats (128 NB + 4).
+template <int NB, int XLDW>
+__device__ __forceinline__ void exchange_blocks(float* xbuf, int quarter, int slot, int half, const f32x16 (&mine)[NB],
+                                                f32x16 (&X)[NB][4]) {
+    __syncthreads();                                        // previous readers are done
+#pragma unroll
+    for (int b = 0; b < NB; ++b) store_slice(xbuf + slot * XLDW + 128 * b, quarter, half, mine[b]);
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) load_row_chain(xbuf + slot * XLDW + 128 * b, half, X[b]);
+}
+
+constexpr int GAMD_XLD = 132;                  // exchange-buffer row stride of the 128-wide kernels
+
+__device__ __forceinline__ void exchange(float* xbuf, int quarter, int slot, int half, const f32x16& mine, f32x16 (&X)[4]) {
+    __syncthreads();
+    store_slice(xbuf + slot * GAMD_XLD, quarter, half, mine);
+    __syncthreads();
+    load_row_chain(xbuf + slot * GAMD_XLD, half, X);
+}
+
 // XCD-aware persistent work split: workgroup b is observed to run on XCD b % 8 (speed only, never
 // correctness).  Give each XCD one contiguous eighth of the tile range so that its private L2 sees a
 // compact slice of the node tables.  Returns the first tile and the stride via out params; caller

@@ -6,7 +6,17 @@
 
 enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD = 4, CNT_NCAND = 5, CNT_COUNT = 8 };
 // host-mapped, never cleared by the per-call memset: overflow must survive later steps of an enqueued MD run
-enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, STICKY_NCAND = 3, STICKY_COUNT = 4 };
+enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, STICKY_NCAND = 3,
+       STICKY_NONFINITE = 4,   // the decoder produced a non-finite force component (NaN / inf positions, or an operand
+                               // beyond the fp16 range in the split-fp16 edge MLP, which turns into inf / NaN downstream)
+       STICKY_COUNT = 8 };
+// device-resident flags, cleared by the host only (gamd_create, after a regrow):
+//   DEVFLAG_FROZEN     a neighbour buffer (edges or candidates) overflowed: the CSR of that call is truncated.  Node kernels
+//                      and every integrator kernel return without touching their outputs while it is set, so an enqueued MD
+//                      run stops at the last consistent state instead of integrating stale forces
+//   DEVFLAG_FROZEN_AT  2 * (index of the step inside the md_run call) + (0: before its first half, 1: before its second
+//                      half) of the first integrator kernel that found the flag set, -1 if none did: where to resume
+enum { DEVFLAG_FROZEN = 0, DEVFLAG_FROZEN_AT = 1, DEVFLAG_COUNT = 4 };
 
 // ---- neighbour build --------------------------------------------------------------------------
 struct NbrArgs {
@@ -19,6 +29,9 @@ struct NbrArgs {
     long long e_cap;       // edge capacity of col/erow/e_frag
     const float* pos;      // [n][3] caller positions (any image)
     const uint8_t* species;// [n] or null
+    const float* feat;     // [n] float node feature (nn_module.py:554 node_encoder input) or null: then (float)species
+    int self_loop;         // 1: append one self edge per atom at the end of its row (gamd_config.self_loop_mode)
+    int* devflags;         // [DEVFLAG_COUNT]
     float4* pos_w;         // [n] wrapped, original order
     float4* pos_s;         // [n] wrapped, sorted order; .w = species
     int* cell_of;          // [n]
@@ -64,6 +77,8 @@ struct EncArgs {
     const int* erow;
     const int* bond_nbr;       // [n][4] original-index bonded partners (-1 pad) or null
     const int* perm;           // sorted -> original (bond lookup)
+    const int* row_ptr;        // CSR rows (self_loop: the last edge of a row is the appended zero-feature loop)
+    int self_loop;             // gamd_config.self_loop_mode
     float box[3], half[3];
     float length_mean, length_std, gamma;
     int n_feat;                // 44 or 45
@@ -100,7 +115,10 @@ struct ConvEdgeArgs {
     const float* b1; const float* b3; const float* b4;                           // [128]
     float* partial;            // [pieces][128]
     long long e_cap;
-    long long* tdbg;           // profiling only: [blocks][8 waves][16] cycle sums (GAMD_CONV_VARIANT bit 4), or null
+    int split_wgs;             // > 0: hybrid launch.  k_conv_edge (split_wgs workgroups) takes the whole rounds of 4-tile
+                               // units, floor(units / split_wgs) per workgroup; k_conv_edge_small takes the tiles after them
+                               // (the launch tail, < 4 * split_wgs tiles).  Both kernels are bit-identical per tile.
+    long long* tdbg;           // profiling builds only: [blocks][8 waves][16] cycle sums, or null
 };
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
@@ -125,6 +143,8 @@ struct NodeLayerW {            // one conv layer's node-side parameters (device 
 struct NodeArgs {
     const int* counters;       // CNT_OVERFLOW set: the CSR is truncated and piece indices are meaningless -> do nothing
                                // (the host regrows the buffers and re-issues the call)
+    const int* devflags;       // DEVFLAG_FROZEN set: same
+    int* sticky;               // host-mapped; STICKY_NONFINITE is raised by the decoder
     int n;
     int mode;                  // 0: first (embed + pre(0)); 1: post(l-1) + pre(l); 2: post(L-1) + decoder
     // inputs
@@ -171,6 +191,8 @@ struct MdArgs {
     int use_rigid;             // 1: O,H,H triples are rigid (one thread per molecule)
     RigidWater rigid;
     unsigned long long seed; unsigned long long step;
+    int* devflags;             // [DEVFLAG_COUNT]: frozen -> return, first kernel to see it records 2 * step_index + half
+    int step_index;            // index of this step inside the gamd_md_run call
 };
 int launch_baoab_first(const MdArgs& a, hipStream_t st);    // B A O A  (hack_integrator.py:141-165)
 int launch_baoab_second(const MdArgs& a, hipStream_t st);   // B        (hack_integrator.py:175-178)
@@ -194,6 +216,8 @@ struct NhcArgs {
     double* state;             // [3*M + 2]: xi[M], vxi[M], G[M], scale, KE2
     double* partial;           // [n_blocks] per-block sums of m v^2
     int n_blocks;
+    int* devflags;             // as in MdArgs
+    int step_index;
 };
 int launch_nhc_first(const NhcArgs& a, hipStream_t st);     // propagateNHC; v *= scale; v += dt/2 f/m; x += dt v
 int launch_nhc_second(const NhcArgs& a, hipStream_t st);    // v += dt/2 f/m; propagateNHC; v *= scale

@@ -15,6 +15,18 @@
 
 namespace {
 
+// A neighbour buffer overflowed in an earlier force evaluation of this enqueued run: the forces are stale, so every
+// integrator kernel returns without touching x, v or the thermostat chain; the first one to notice records where the
+// run stopped (2 * step index + half) for the host to resume from after regrowing (gamd_sync_status).
+#define GAMD_MD_GATE(HALF)                                                                        \
+    do {                                                                                          \
+        if (a.devflags[DEVFLAG_FROZEN]) {                                                         \
+            if (blockIdx.x == 0 && threadIdx.x == 0 && a.devflags[DEVFLAG_FROZEN_AT] < 0)         \
+                a.devflags[DEVFLAG_FROZEN_AT] = 2 * a.step_index + (HALF);                        \
+            return;                                                                               \
+        }                                                                                         \
+    } while (0)
+
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
     const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
@@ -49,6 +61,7 @@ __device__ __forceinline__ float atom_inv_mass(const uint8_t* species, float inv
 }
 
 __global__ void k_baoab_first(MdArgs a) {
+    GAMD_MD_GATE(0);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     float xi[3];
@@ -68,6 +81,7 @@ __global__ void k_baoab_first(MdArgs a) {
 }
 
 __global__ void k_baoab_second(MdArgs a) {
+    GAMD_MD_GATE(1);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * a.n) return;
     a.v[i] += 0.5f * a.dt * a.len * atom_inv_mass(a.species, a.inv_mass, a.inv_mass_h, i / 3) * a.f[i];
@@ -155,6 +169,7 @@ __device__ __forceinline__ void wrap_mol(Vec3 (&x)[3], const float (&box)[3]) {
 
 // HackLangevinIntegrator with constraints, hack_integrator.py:141-165, one molecule per thread
 __global__ void k_baoab_first_rigid(MdArgs a) {
+    GAMD_MD_GATE(0);
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (3 * m >= a.n) return;
     Vec3 x[3], v[3], f[3];
@@ -190,6 +205,7 @@ __global__ void k_baoab_first_rigid(MdArgs a) {
 
 // HackHalfVelocityIntegrator with constraints, hack_integrator.py:177-178
 __global__ void k_baoab_second_rigid(MdArgs a) {
+    GAMD_MD_GATE(1);
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (3 * m >= a.n) return;
     Vec3 x[3], v[3], f[3];
@@ -206,6 +222,7 @@ __global__ void k_baoab_second_rigid(MdArgs a) {
 // (and, for rigid water, the velocity constraint that follows it: hack_integrator.py:427-428)
 template <bool KICK>
 __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
+    GAMD_MD_GATE(KICK ? 1 : 0);
     __shared__ double red[4];
     double s = 0.0;
     const double inv_len = 1.0 / (double)a.len;
@@ -247,6 +264,7 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
 // propagateNHC (hack_integrator.py:289-316), in double like OpenMM's global variables
 __global__ void k_nhc_chain(NhcArgs a) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (a.devflags[DEVFLAG_FROZEN]) return;                 // k_nhc_ke2 in front of it has recorded the position
     double KE2 = 0.0;
     for (int b = 0; b < a.n_blocks; ++b) KE2 += a.partial[b];
     const int M = a.M;
@@ -281,6 +299,7 @@ __global__ void k_nhc_chain(NhcArgs a) {
 
 // first half tail: v = scale*v; v += dt/2 f_last/m; x += dt v   (hack_integrator.py:274-280)
 __global__ void k_nhc_apply_first(NhcArgs a) {
+    GAMD_MD_GATE(0);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     const float scale = (float)a.state[3 * a.M];
@@ -296,6 +315,7 @@ __global__ void k_nhc_apply_first(NhcArgs a) {
 
 // the same with constraints: x1 = x + dt v; ConstrainPositions; v += (x - x1)/dt   (:277-280)
 __global__ void k_nhc_apply_first_rigid(NhcArgs a) {
+    GAMD_MD_GATE(0);
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (3 * m >= a.n) return;
     Vec3 x[3], v[3], f[3], x1[3], xc[3];
@@ -316,6 +336,7 @@ __global__ void k_nhc_apply_first_rigid(NhcArgs a) {
 }
 
 __global__ void k_nhc_apply_second(NhcArgs a) {
+    GAMD_MD_GATE(1);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * a.n) return;
     a.v[i] *= (float)a.state[3 * a.M];

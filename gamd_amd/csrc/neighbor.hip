@@ -23,6 +23,12 @@ __device__ __forceinline__ int cell_coord(float p, float box, int nc) {
 
 #define GAMD_GATE() do { if (a.gate && *a.gate == 0) return; } while (0)
 
+// node feature that rides along in pos_s.w: the caller's float feature (nn_module.py:554 feeds it to node_encoder), or
+// the species flag (O=1, H=0: water/test_script/test_nosehoover.py:82-89)
+__device__ __forceinline__ float node_feature(const NbrArgs& a, int v) {
+    return a.feat ? a.feat[v] : (a.species ? (float)a.species[v] : 0.f);
+}
+
 __global__ void k_bin(NbrArgs a) {
     GAMD_GATE();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,7 +115,7 @@ __global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
         if (lane < cnt) {
             a.perm[s + rank] = v;                 // ids are distinct -> ranks are a permutation
             float4 p = a.pos_w[v];
-            p.w = a.species ? (float)a.species[v] : 0.f;      // node feature rides along (O=1, H=0)
+            p.w = node_feature(a, v);
             a.pos_s[s + rank] = p;
             a.inv_perm[v] = s + rank;
         }
@@ -128,7 +134,7 @@ __global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
         for (int i = s + lane; i < e; i += 64) {
             const int v = ((volatile int*)a.perm)[i];
             float4 p = a.pos_w[v];
-            p.w = a.species ? (float)a.species[v] : 0.f;
+            p.w = node_feature(a, v);
             a.pos_s[i] = p;
             a.inv_perm[v] = i;
         }
@@ -191,7 +197,7 @@ __global__ void __launch_bounds__(256) k_count(NbrArgs a) {
     int cnt = 0;
     // both halves of a wave must run the same number of ballots: sweep a clamped atom, discard below
     sweep(a, live ? ctr : a.n - 1, l, [&](bool ok, int) { cnt += __popc(half_ballot(ok)); });
-    if (live && l == 0) a.deg[ctr] = cnt;
+    if (live && l == 0) a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
 }
 
 // row_ptr = exscan(deg); NA = inclusive count of non-empty segments that start off a chunk boundary;
@@ -205,7 +211,7 @@ __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
             const int nc = a.row_ptr[a.n];
             a.counters[CNT_NCAND] = nc;
             a.sticky[STICKY_NCAND] = nc;
-            if ((long long)nc > a.e_cap) a.sticky[STICKY_CAND_OVERFLOW] = 1;
+            if ((long long)nc > a.e_cap) { a.sticky[STICKY_CAND_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1; }
             a.sticky[STICKY_REBUILDS] += 1;
         }
         return;
@@ -217,7 +223,9 @@ __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
         const int E = a.row_ptr[a.n];
         a.counters[CNT_E] = E;
         a.counters[CNT_PIECES] = (E + GAMD_CHUNK - 1) / GAMD_CHUNK + a.na_excl[a.n];
-        if ((long long)E > a.e_cap) { a.counters[CNT_OVERFLOW] = 1; a.sticky[STICKY_EDGE_OVERFLOW] = 1; }
+        if ((long long)E > a.e_cap) {
+            a.counters[CNT_OVERFLOW] = 1; a.sticky[STICKY_EDGE_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1;
+        }
         a.counters[CNT_TILES] = (E + GAMD_TILE - 1) / GAMD_TILE;
     }
 }
@@ -237,6 +245,8 @@ __global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
         }
         w += __popc(m);
     });
+    // self_loop_mode 1: the loop DGL's in-place add_self_loop would append (nn_module.py:650-652), last in the row
+    if (a.self_loop && live && l == 0 && w < a.e_cap) { a.col[w] = c; if (a.erow) a.erow[w] = c; }
 }
 
 // per 16-edge chunk: first piece id and the bit mask of edges that close a destination segment
@@ -296,7 +306,7 @@ __global__ void k_regather(NbrArgs a) {
     if (s >= a.n) return;
     const int v = a.perm[s];
     float4 p = a.pos_w[v];
-    p.w = a.species ? (float)a.species[v] : 0.f;
+    p.w = node_feature(a, v);
     a.pos_s[s] = p;
 }
 
@@ -337,7 +347,8 @@ __global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
             cnt += __popc(m);
         }
     }
-    if (!FILL && live && l == 0) a.deg[ctr] = cnt;
+    if (FILL && a.self_loop && live && l == 0 && w < a.e_cap) { a.col[w] = c; a.erow[w] = c; }
+    if (!FILL && live && l == 0) a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
 }
 
 // ---- CSR from an explicit edge list (model-level forward([pos],[edge_idx]), nn_module.py:636-653) ----
@@ -348,12 +359,12 @@ __global__ void k_identity_sort(NbrArgs a) {
     p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);
     p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
     p.z = gamd_remainder(a.pos[3 * i + 2], a.box[2]);
-    p.w = a.species ? (float)a.species[i] : 0.f;
+    p.w = node_feature(a, i);
     a.pos_w[i] = p;
     a.pos_s[i] = p;
     a.perm[i] = i;
     a.inv_perm[i] = i;
-    a.deg[i] = 0;
+    a.deg[i] = a.self_loop ? 1 : 0;                        // the appended loop occupies the last slot of the row
 }
 
 __global__ void k_edges_count(NbrArgs a, const int* __restrict__ centre, const int* __restrict__ neigh, long long ne) {
@@ -385,7 +396,11 @@ __global__ void __launch_bounds__(256) k_edges_sort_rows(NbrArgs a, const int* _
     const long long s = a.row_ptr[row];
     long long e = a.row_ptr[row + 1];
     if (e > a.e_cap) e = a.e_cap;
-    const int cnt = (int)(e - s);
+    int cnt = (int)(e - s);
+    if (a.self_loop && cnt > 0) {                             // last slot of the row: the appended loop
+        --cnt;
+        if (lane == 0) { a.col[s + cnt] = row; a.erow[s + cnt] = row; }
+    }
     if (cnt <= 0) return;
     if (cnt <= 64) {
         const int v = lane < cnt ? tmp_eid[s + lane] : 0x7fffffff;
@@ -438,6 +453,7 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st) {
     c.cand_pass = 1;
     c.rc = a.rc_build; c.rc2 = a.rc2_build;
     c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
+    c.self_loop = 0;                                          // loops are appended by the exact filter, not kept as candidates
     hipLaunchKernelGGL(k_bin, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();          // also stores ref_pos
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_fill_cells, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();

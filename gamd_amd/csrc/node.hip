@@ -23,66 +23,14 @@
 
 namespace {
 
-constexpr int XLD = 132;                       // padded row stride of the exchange buffer (floats)
-
-// This wave's 16 KiB weight quarter (output features [32q, 32q+32)) as 16 float4 per lane, fetched from L2
-// in ONE batch: the kernel is latency-bound, so a GEMM must cost one L2 round trip, not sixteen.
-struct WQuarter { f32x4 w[16]; };
-
-__device__ __forceinline__ void load_wquarter(const float* __restrict__ Wp, int quarter, int lane, WQuarter& o) {
-    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 16 * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o.w[i] = W[i * 64];
-}
-
-// acc (this wave's 32 output features x 32 atoms, one C tile) += W[quarter] * X^T
-__device__ __forceinline__ void gemm_quarter(const WQuarter& wq, const f32x16 (&X)[4], f32x16& acc) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
-        }
-}
-
-// 16 floats of a plain row-major [128] row that belong to (quarter, half) in chain order
-__device__ __forceinline__ f32x16 load_slice(const float* __restrict__ row, int quarter, int half) {
-    f32x16 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 32 * quarter + 8 * q + 4 * half);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[q * 4 + j] = x[j];
-    }
-    return v;
-}
-
-__device__ __forceinline__ void store_slice(float* __restrict__ row, int quarter, int half, const f32x16& v) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = v[q * 4 + j];
-        *reinterpret_cast<f32x4*>(row + 32 * quarter + 8 * q + 4 * half) = x;
-    }
-}
-
-// every wave contributes its quarter; afterwards every wave holds the full row block in chain layout
-__device__ __forceinline__ void exchange(float* xbuf, int quarter, int slot, int half, const f32x16& mine,
-                                         f32x16 (&X)[4]) {
-    __syncthreads();                                        // previous readers are done
-    store_slice(xbuf + slot * XLD, quarter, half, mine);
-    __syncthreads();
-    load_row_chain(xbuf + slot * XLD, half, X);
-}
+constexpr int XLD = GAMD_XLD;                  // padded row stride of the exchange buffer (floats)
 
 __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) float xbuf[32 * XLD];
     __shared__ float obuf[4][32][3];
     __shared__ float red[2][4][32];
 
-    if (a.counters[CNT_OVERFLOW]) return;
+    if (a.counters[CNT_OVERFLOW] || a.devflags[DEVFLAG_FROZEN]) return;
 
     const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
     const int quarter = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -226,6 +174,7 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
                 const float v = ((obuf[0][slot][c] + obuf[1][slot][c]) + (obuf[2][slot][c] + obuf[3][slot][c])) + a.dec_b2[c];
                 a.forces_norm[3 * (size_t)orig + c] = v;
                 if (a.forces) a.forces[3 * (size_t)orig + c] = v * a.scale + a.shift;
+                if (!(fabsf(v) <= 3.0e38f)) a.sticky[STICKY_NONFINITE] = 1;      // NaN or inf
             }
         }
     }

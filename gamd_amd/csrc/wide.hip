@@ -20,17 +20,6 @@ namespace {
 
 constexpr int WIDE_ENC_W1_FLOATS = 4 * 6 * 64 * 4;
 
-__device__ __forceinline__ void wide_stage(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
-    asm volatile("" : "+v"(lane16));
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int chunk = k * 8 + wave;
-        const char* base = reinterpret_cast<const char*>(gw) + chunk * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane16),
-                                         (__attribute__((address_space(3))) void*)(ldsbuf + chunk * 256), 16, 0, 0);
-    }
-}
-
 // all of this wave's LDS DMA and loads have landed, then the workgroup meets
 __device__ __forceinline__ void wide_barrier() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -148,7 +137,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
         for (int ob = 0; ob < EHT; ++ob) {
             if (EHT > 1) {
                 wide_barrier();                            // previous readers of the slot are done
-                wide_stage(a.w3p + (size_t)ob * GAMD_WFRAG_FLOATS, ws, wave, lane16);
+                gamd_stage_weight<8>(a.w3p + (size_t)ob * GAMD_WFRAG_FLOATS, ws, wave, lane16);
                 wide_barrier();
             }
             load_bias_chain(vb3 + 128 * ob, half, Y[ob]);
@@ -171,6 +160,8 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { const float dd = Y[ob][t][r] - mean; s2 += dd * dd; }
         const float rstd = 1.0f / sqrtf(gamd_xhalf_sum(s2) * (1.0f / EH) + 1e-5f);
+        // self_loop_mode 1: the appended loop (last edge of its row) carries DGL's zero-filled embedding (nn_module.py:364)
+        const bool zero_row = a.self_loop && valid && x == (long long)a.row_ptr[dst + 1] - 1;
         if (active) {
             f32x4* out = (f32x4*)a.e_frag + (size_t)tile * EHT * 16 * 64;
 #pragma unroll
@@ -184,7 +175,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
                         const f32x4 b = *reinterpret_cast<const f32x4*>(&vbeta[f0]);
                         f32x4 v;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = (Y[ob][t][q * 4 + j] - mean) * rstd * g[j] + b[j];
+                        for (int j = 0; j < 4; ++j) v[j] = zero_row ? 0.f : (Y[ob][t][q * 4 + j] - mean) * rstd * g[j] + b[j];
                         out[((ob * 4 + t) * 4 + q) * 64 + lane] = v;
                     }
         }
@@ -217,7 +208,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
 
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; }
     if (tid < H) vb4[tid] = a.b4[tid];
-    wide_stage(a.w1p, lds, wave, lane16);
+    gamd_stage_weight<8>(a.w1p, lds, wave, lane16);
     wide_barrier();
 
     unsigned g = 0;                    // running phase counter: block g % NP sits in slot g & 1
@@ -225,7 +216,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
     // start the DMA of the next block into the other slot, hand back this phase's slot
     auto begin_phase = [&]() -> const f32x4* {
         const int nb = (blk + 1 == NP) ? 0 : blk + 1;
-        wide_stage(a.w1p + (size_t)nb * GAMD_WFRAG_FLOATS, lds + ((g + 1) & 1u) * GAMD_WFRAG_FLOATS, wave, lane16);
+        gamd_stage_weight<8>(a.w1p + (size_t)nb * GAMD_WFRAG_FLOATS, lds + ((g + 1) & 1u) * GAMD_WFRAG_FLOATS, wave, lane16);
         return (const f32x4*)(lds + (g & 1u) * GAMD_WFRAG_FLOATS);
     };
     auto end_phase = [&]() { wide_barrier(); ++g; blk = (blk + 1 == NP) ? 0 : blk + 1; };
@@ -368,38 +359,6 @@ __device__ __forceinline__ void wq_gemm(const WQ& wq, const f32x16 (&X)[4], f32x
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
 }
-__device__ __forceinline__ f32x16 sl_load(const float* __restrict__ row, int quarter, int half) {
-    f32x16 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(row + 32 * quarter + 8 * q + 4 * half);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[q * 4 + j] = x[j];
-    }
-    return v;
-}
-__device__ __forceinline__ void sl_store(float* __restrict__ row, int quarter, int half, const f32x16& v) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = v[q * 4 + j];
-        *reinterpret_cast<f32x4*>(row + 32 * quarter + 8 * q + 4 * half) = x;
-    }
-}
-
-// every wave contributes its quarter of each of NB 128-blocks; afterwards every wave holds the full rows
-template <int NB, int XLDW>
-__device__ __forceinline__ void wide_exchange(float* xbuf, int quarter, int slot, int half, const f32x16 (&mine)[NB],
-                                              f32x16 (&X)[NB][4]) {
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < NB; ++b) sl_store(xbuf + slot * XLDW + 128 * b, quarter, half, mine[b]);
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < NB; ++b) load_row_chain(xbuf + slot * XLDW + 128 * b, half, X[b]);
-}
-
 template <int HT>
 __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
     constexpr int H = 128 * HT;
@@ -408,7 +367,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
     __shared__ float obuf[4][32][3];
     __shared__ float red[2][4][32];
 
-    if (a.counters[CNT_OVERFLOW]) return;
+    if (a.counters[CNT_OVERFLOW] || a.devflags[DEVFLAG_FROZEN]) return;
 
     const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
     const int quarter = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -425,15 +384,15 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
 #pragma unroll
         for (int b = 0; b < HT; ++b) {
             if (a.node_emb) {
-                mine[b] = sl_load(a.node_emb + 128 * b, quarter, half);
+                mine[b] = load_slice(a.node_emb + 128 * b, quarter, half);
             } else {
                 const float f = a.pos_s[atom].w;
-                const f32x16 w = sl_load(a.enc_w + 128 * b, quarter, half);
-                mine[b] = sl_load(a.enc_b + 128 * b, quarter, half);
+                const f32x16 w = load_slice(a.enc_w + 128 * b, quarter, half);
+                mine[b] = load_slice(a.enc_b + 128 * b, quarter, half);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mine[b][r] = f * w[r] + mine[b][r];
             }
-            if (valid) sl_store(a.h_out + rowH + 128 * b, quarter, half, mine[b]);
+            if (valid) store_slice(a.h_out + rowH + 128 * b, quarter, half, mine[b]);
         }
     } else {
         // ---- post(l-1): agg = sum of this atom's pieces, in order -------------------------------
@@ -445,10 +404,10 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         for (int b = 0; b < HT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mine[b][r] = 0.f;
-        f32x16 acc = sl_load(a.P_in + rowD, quarter, half);
+        f32x16 acc = load_slice(a.P_in + rowD, quarter, half);
         f32x16 h_res[HT];
 #pragma unroll
-        for (int b = 0; b < HT; ++b) h_res[b] = sl_load(a.h_in + rowH + 128 * b, quarter, half);
+        for (int b = 0; b < HT; ++b) h_res[b] = load_slice(a.h_in + rowH + 128 * b, quarter, half);
         for (int k0 = 0; __any(k0 < np); k0 += 4) {
             f32x16 pc[4][HT];
 #pragma unroll
@@ -456,7 +415,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
                 const int kk = (k0 + k < np) ? k0 + k : (np > 0 ? np - 1 : 0);
                 const float* prow = a.partial + (size_t)(np > 0 ? p0 + kk : 0) * H;
 #pragma unroll
-                for (int b = 0; b < HT; ++b) pc[k][b] = sl_load(prow + 128 * b, quarter, half);
+                for (int b = 0; b < HT; ++b) pc[k][b] = load_slice(prow + 128 * b, quarter, half);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -465,7 +424,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
                     for (int b = 0; b < HT; ++b) mine[b] += pc[k][b];
                 }
         }
-        wide_exchange<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = agg
+        exchange_blocks<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = agg
 #pragma unroll
         for (int kb = 0; kb < HT; ++kb) {                                     // phi_edge: H -> 128
             wq_load(a.post.wpep + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
@@ -475,14 +434,14 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         for (int r = 0; r < 16; ++r) acc[r] = gamd_silu_hw(acc[r]);
         f32x16 one[1] = {acc};
         f32x16 X1[1][4];
-        wide_exchange<1, XLDW>(xbuf, quarter, slot, half, one, X1);           // X1 = SiLU(P + phi_edge(agg))
+        exchange_blocks<1, XLDW>(xbuf, quarter, slot, half, one, X1);           // X1 = SiLU(P + phi_edge(agg))
 #pragma unroll
         for (int ob = 0; ob < HT; ++ob) {                                     // phi: 128 -> H, residual
-            mine[ob] = sl_load(a.post.bphi + 128 * ob, quarter, half);
+            mine[ob] = load_slice(a.post.bphi + 128 * ob, quarter, half);
             wq_load(a.post.wphip + (size_t)ob * GAMD_WFRAG_FLOATS, quarter, lane, wq);
             wq_gemm(wq, X1[0], mine[ob]);
             mine[ob] += h_res[ob];
-            if (valid) sl_store(a.h_out + rowH + 128 * ob, quarter, half, mine[ob]);
+            if (valid) store_slice(a.h_out + rowH + 128 * ob, quarter, half, mine[ob]);
         }
     }
 
@@ -509,19 +468,19 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
         for (int b = 0; b < HT; ++b) {
-            const f32x16 g = sl_load(a.pre.ln_g + 128 * b, quarter, half), be = sl_load(a.pre.ln_b + 128 * b, quarter, half);
+            const f32x16 g = load_slice(a.pre.ln_g + 128 * b, quarter, half), be = load_slice(a.pre.ln_b + 128 * b, quarter, half);
 #pragma unroll
             for (int r = 0; r < 16; ++r) mine[b][r] = (mine[b][r] - mean) * rstd * g[r] + be[r];
-            if (valid) sl_store(a.hn_out + rowH + 128 * b, quarter, half, mine[b]);
+            if (valid) store_slice(a.hn_out + rowH + 128 * b, quarter, half, mine[b]);
         }
-        wide_exchange<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = hn
-        f32x16 acc = sl_load(a.pre.bS, quarter, half);
+        exchange_blocks<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = hn
+        f32x16 acc = load_slice(a.pre.bS, quarter, half);
 #pragma unroll
         for (int kb = 0; kb < HT; ++kb) {
             wq_load(a.pre.wsp + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
             wq_gemm(wq, X[kb], acc);
         }
-        if (valid) sl_store(a.S_out + rowD, quarter, half, acc);
+        if (valid) store_slice(a.S_out + rowD, quarter, half, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -529,18 +488,18 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
             wq_load(a.pre.wdp + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
             wq_gemm(wq, X[kb], acc);
         }
-        if (valid) sl_store(a.D_out + rowD, quarter, half, acc);
-        acc = sl_load(a.pre.bP, quarter, half);
+        if (valid) store_slice(a.D_out + rowD, quarter, half, acc);
+        acc = load_slice(a.pre.bP, quarter, half);
 #pragma unroll
         for (int kb = 0; kb < HT; ++kb) {
             wq_load(a.pre.wpdp + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
             wq_gemm(wq, X[kb], acc);
         }
-        if (valid) sl_store(a.P_out + rowD, quarter, half, acc);
+        if (valid) store_slice(a.P_out + rowD, quarter, half, acc);
     } else {
         // ---- decoder: Lin(H,128) GELU Lin(128,3); denormalise ------------------------------------
-        wide_exchange<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = h'
-        f32x16 acc = sl_load(a.dec_b1, quarter, half);
+        exchange_blocks<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = h'
+        f32x16 acc = load_slice(a.dec_b1, quarter, half);
 #pragma unroll
         for (int kb = 0; kb < HT; ++kb) {
             wq_load(a.dec_w1p + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
@@ -574,6 +533,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
                 const float v = ((obuf[0][slot][c] + obuf[1][slot][c]) + (obuf[2][slot][c] + obuf[3][slot][c])) + a.dec_b2[c];
                 a.forces_norm[3 * (size_t)orig + c] = v;
                 if (a.forces) a.forces[3 * (size_t)orig + c] = v * a.scale + a.shift;
+                if (!(fabsf(v) <= 3.0e38f)) a.sticky[STICKY_NONFINITE] = 1;      // NaN or inf
             }
         }
     }

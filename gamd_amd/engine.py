@@ -22,6 +22,9 @@ ArrayLike = Union[np.ndarray, torch.Tensor]
 
 KIND = {"lj": 0, "water": 1, "dynbox": 1}
 FLAVOUR = {"jaxmd": 0, "torch": 1}
+# what `fluid_graph.add_self_loop()` with its result discarded does (nn_module.py:650-652)
+SELF_LOOP = {"dgl07_noop": 0, "append_zero_feature_loops": 1}
+KSEL_FORCE_GENERIC_WIDTH, KSEL_NO_HYBRID_TAIL = 1, 2
 
 
 def _box3(box) -> np.ndarray:
@@ -45,7 +48,8 @@ class GamdForce:
                  bond: Optional[np.ndarray] = None, scaler: Tuple[float, float] = (0.0, 1.0),
                  nbr_flavour: str = "jaxmd", device: int = 0, keep_stages: bool = False,
                  edge_capacity: int = 0, cfg: Optional[ModelConfig] = None, edge_dtype: str = "f32",
-                 neighbor_skin: float = 0.0):
+                 neighbor_skin: float = 0.0, self_loop_mode: str = "dgl07_noop", kernel_select: int = 0,
+                 small_tile_limit: int = 0):
         self._h = C.c_void_p()
         self._lib = _lib.load()
         if not torch.cuda.is_available():
@@ -75,6 +79,10 @@ class GamdForce:
         c.encoding_size, c.edge_embedding_dim, c.hidden_dim = cfg.encoding_size, cfg.edge_embedding_dim, cfg.hidden_dim
         c.no_expand_edge = int(cfg.n_rbf == 0)
         c.neighbor_skin = float(neighbor_skin)      # > 0: Verlet-skin reuse (jax-md uses cutoff/6, graph_utils.py:24)
+        if self_loop_mode not in SELF_LOOP:
+            raise ValueError(f"self_loop_mode must be one of {sorted(SELF_LOOP)}")
+        c.self_loop_mode = SELF_LOOP[self_loop_mode]
+        c.kernel_select, c.small_tile_limit = int(kernel_select), int(small_tile_limit)
         self.edge_dtype = edge_dtype
         check(self._lib.gamd_create(C.byref(c), C.byref(self._h)), "gamd_create")
         self.keep_stages = keep_stages
@@ -90,6 +98,7 @@ class GamdForce:
                 raise ValueError("use_bond model needs the bond list")
             b = np.ascontiguousarray(np.asarray(bond, dtype=np.int32))
             check(self._lib.gamd_set_bonds(self._h, b.ctypes.data_as(C.c_void_p), b.shape[0]), "gamd_set_bonds")
+        self._feat = None
         self._out = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
         self._out_den = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
         self.last_status = 0
@@ -127,24 +136,39 @@ class GamdForce:
         return pos
 
     def _dev_species(self, species) -> Optional[torch.Tensor]:
+        """species / node feature [N] or [N,1] -> uint8 O=1/H=0 flags on the device (what the integrators pick masses
+        by).  A floating-point input is ALSO handed to the library as the float node feature the reference feeds to
+        node_encoder (nn_module.py:554): it need not be 0/1."""
         if species is None:
+            self._set_features(None)
             return None
         if isinstance(species, np.ndarray):
             species = torch.from_numpy(species)
         s = species.reshape(-1).to(device=self.device)
         if s.numel() != self.n:
             raise ValueError("species must have one entry per atom")
+        self._set_features(s.to(torch.float32).contiguous() if s.dtype.is_floating_point and self.cfg.kind != "lj" else None)
         return (s != 0).to(torch.uint8).contiguous()
+
+    def _set_features(self, feat: Optional[torch.Tensor]) -> None:
+        if feat is None and self._feat is None:
+            return
+        self._feat = feat                             # keeps the device buffer alive while the library points at it
+        check(self._lib.gamd_set_node_features(self._h, C.c_void_p(feat.data_ptr()) if feat is not None else None),
+              "gamd_set_node_features")
 
     def _box_arg(self, box):
         b = self.box if box is None else _box3(box)
         return (C.c_float * 3)(*[float(x) for x in b])
 
     # -- the hot path ----------------------------------------------------------------------------
-    def forward(self, pos: ArrayLike, box=None, species=None, denormalize: bool = False) -> torch.Tensor:
+    def forward(self, pos: ArrayLike, box=None, species=None, denormalize: bool = False,
+                inplace: bool = False) -> torch.Tensor:
         """pos [N,3] (any periodic image), box scalar/[3] (default: constructor box), species [N]
-        (O=1/H=0; ignored for LJ) -> network output [N,3] fp32 on the device, in the caller's atom
-        order.  Normalised like ``pnet_model(...)`` unless ``denormalize`` (then fp32 out*sqrt(var)+mean)."""
+        (O=1/H=0, or the float node feature of the water models; ignored for LJ) -> network output [N,3] fp32 on
+        the device, in the caller's atom order.  Normalised like ``pnet_model(...)`` unless ``denormalize`` (then
+        fp32 out*sqrt(var)+mean).  Returns a FRESH tensor like the reference's ``pnet_model(...)``; ``inplace=True``
+        returns the engine's persistent output buffer instead (overwritten by the next call: for MD loops)."""
         p = self._dev_pos(pos)
         s = self._dev_species(species)
         st = self._lib.gamd_forces(self._h, C.c_void_p(p.data_ptr()),
@@ -152,13 +176,16 @@ class GamdForce:
                                    self._box_arg(box), C.c_void_p(self._out.data_ptr()),
                                    C.c_void_p(self._out_den.data_ptr()), self._stream())
         self.last_status = check(st, "gamd_forces")
-        return self._out_den if denormalize else self._out
+        out = self._out_den if denormalize else self._out
+        return out if inplace else out.clone()
 
     __call__ = forward
 
-    def forward_edges(self, pos: ArrayLike, edge_idx, box=None, species=None, denormalize: bool = False) -> torch.Tensor:
+    def forward_edges(self, pos: ArrayLike, edge_idx, box=None, species=None, denormalize: bool = False,
+                      inplace: bool = False) -> torch.Tensor:
         """Model-level call of the reference, ``pnet_model([pos], [edge_idx])``: edge_idx [2,E] with row 0 =
-        centre, row 1 = neighbour (LJ/train_network_lj.py:183-184); the built-in radius search is bypassed."""
+        centre, row 1 = neighbour (LJ/train_network_lj.py:183-184); the built-in radius search is bypassed.
+        Returns a fresh tensor unless ``inplace``."""
         p = self._dev_pos(pos)
         s = self._dev_species(species)
         if isinstance(edge_idx, np.ndarray):
@@ -172,7 +199,8 @@ class GamdForce:
                                          C.c_void_p(self._out.data_ptr()), C.c_void_p(self._out_den.data_ptr()),
                                          self._stream())
         self.last_status = check(st, "gamd_forces_edges")
-        return self._out_den if denormalize else self._out
+        out = self._out_den if denormalize else self._out
+        return out if inplace else out.clone()
 
     def build_neighbors(self, pos: ArrayLike, box=None, species=None) -> int:
         p = self._dev_pos(pos)
@@ -279,16 +307,19 @@ class GamdForce:
                                    self._box_arg(box), C.byref(p), int(n_steps), self._stream())
         check(st, "gamd_md_run")
         if sync:
-            check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
+            self.last_status = check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
 
     def md_run_nhc(self, x: torch.Tensor, v: torch.Tensor, f: torch.Tensor, n_steps: int, chain_state: torch.Tensor = None,
                    dt_ps=0.002, mass_amu=39.9, temperature_k=100.0, frequency_per_ps=25.0, chain_length=10, num_mts=5,
                    num_yoshidasuzuki=5, ndf=None, box=None, species=None, sync: bool = True, mass_h_amu=0.0,
-                   length_per_nm=0.0, rigid_water: bool = False, r_oh=0.0, r_hh=0.0) -> torch.Tensor:
+                   length_per_nm=0.0, rigid_water: bool = False, r_oh=0.0, r_hh=0.0,
+                   remove_cm_motion: Optional[bool] = None) -> torch.Tensor:
         """Split Nose-Hoover-chain steps (hack_integrator.py:182-493).  Returns the chain state tensor
         (float64 [3*chain_length+2] on the device); pass it back in to continue a trajectory.
-        ``ndf`` defaults to 3N, or 3N - N (three constraints per molecule) with ``rigid_water``
-        (hack_integrator.py:226-235: particles*3 - constraints [- 3 with a CMMotionRemover])."""
+        ``ndf`` defaults to what hack_integrator.py:226-235 computes from the OpenMM System: 3 per particle, minus the
+        constraints (three per rigid molecule), minus 3 when the System holds a CMMotionRemover.
+        ``remove_cm_motion`` says whether it does: default True with ``rigid_water`` (the water drivers build an
+        openmmtools WaterBox, whose System carries one), False otherwise (the LJ drivers' ndf is 3N)."""
         for t in (x, v, f):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n, 3)
         reset = chain_state is None
@@ -296,8 +327,12 @@ class GamdForce:
             chain_state = torch.zeros(3 * chain_length + 2, dtype=torch.float64, device=self.device)
         assert chain_state.dtype == torch.float64 and chain_state.numel() == 3 * chain_length + 2
         s = self._dev_species(species)
+        if remove_cm_motion is None:
+            remove_cm_motion = bool(rigid_water)
+        if ndf is None:
+            ndf = (2 * self.n if rigid_water else 3 * self.n) - (3 if remove_cm_motion else 0)
         p = GamdNhcParams(dt_ps, mass_amu, temperature_k, frequency_per_ps, chain_length, num_mts, num_yoshidasuzuki,
-                          int(reset), float((2 * self.n if rigid_water else 3 * self.n) if ndf is None else ndf),
+                          int(reset), float(ndf),
                           mass_h_amu, length_per_nm, int(rigid_water), r_oh, r_hh, 0)
         st = self._lib.gamd_md_run_nhc(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()),
                                        C.c_void_p(f.data_ptr()), C.c_void_p(s.data_ptr()) if s is not None else None,
@@ -305,11 +340,18 @@ class GamdForce:
                                        self._stream())
         check(st, "gamd_md_run_nhc")
         if sync:
-            check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
+            self.last_status = check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
         return chain_state
 
     def sync_status(self) -> int:
+        """0, or 1 when an enqueued MD run overflowed a neighbour buffer, froze on the device and was resumed."""
         return check(self._lib.gamd_sync_status(self._h, self._stream()), "gamd_sync_status")
+
+    def nonfinite_seen(self) -> bool:
+        """True if any force evaluation since the last call produced a non-finite component (clears the flag)."""
+        flags = (C.c_int32 * 4)()
+        check(self._lib.gamd_get_device_flags(self._h, flags), "gamd_get_device_flags")
+        return bool(flags[0])
 
     def timing_enable(self, on: bool = True) -> None:
         check(self._lib.gamd_timing_enable(self._h, int(on)), "gamd_timing_enable")
@@ -327,9 +369,16 @@ class GamdForce:
         names = C.create_string_buffer(4096)
         ms = (C.c_float * 64)()
         n = C.c_int32()
-        st = self._lib.gamd_profile(self._h, C.c_void_p(p.data_ptr()),
-                                    C.c_void_p(s.data_ptr()) if s is not None else None, self._box_arg(box),
-                                    C.c_void_p(self._out.data_ptr()), self._stream(), names, 4096, ms, 64, C.byref(n))
-        check(st, "gamd_profile")
+        for _ in range(4):
+            st = self._lib.gamd_profile(self._h, C.c_void_p(p.data_ptr()),
+                                        C.c_void_p(s.data_ptr()) if s is not None else None, self._box_arg(box),
+                                        C.c_void_p(self._out.data_ptr()), self._stream(), names, 4096, ms, 64, C.byref(n))
+            check(st, "gamd_profile")
+            st = self._lib.gamd_sync_status(self._h, self._stream())
+            if st != -34:                          # -34: a neighbour buffer overflowed and was regrown -> replay
+                check(st, "gamd_sync_status")
+                break
+        else:
+            check(st, "gamd_sync_status")
         labels = names.value.decode().strip().split("\n")
         return list(zip(labels, [ms[i] for i in range(n.value)]))

@@ -66,8 +66,22 @@ typedef struct gamd_config {
                                 jax-md list (graph_utils.py:21-25 dr_threshold = cutoff/6, :36-44 update): candidates
                                 within cutoff + skin are rebuilt only when an atom has moved more than skin/2, the exact
                                 cutoff is re-applied every call, so the edge SET is the same either way */
-    int32_t reserved;
+    int32_t self_loop_mode;  /* what `fluid_graph.add_self_loop()` with its result DISCARDED does (nn_module.py:650-652, :364,
+                                :518).  0 = GAMD_SELF_LOOP_DGL07_NOOP (default): nothing — under the pinned DGL 0.7.0 (DGL >= 0.5)
+                                add_self_loop is functional and returns a new graph, so the graph that is used has no extra
+                                edges.  1 = GAMD_SELF_LOOP_APPEND_ZERO_FEATURE: what an in-place add_self_loop (DGL < 0.5) would
+                                have done: one extra edge i -> i per atom whose embedding e is DGL's zero fill (it is appended
+                                after edata['e'] was set).  The one reference semantic that cannot be executed in the build
+                                container (DGL absent), hence the switch.  fp32 edge dtype only. */
+    int32_t kernel_select;   /* 0 = automatic.  Bit flags for tests and tuning (never change results beyond fp32 rounding):
+                                GAMD_KSEL_FORCE_GENERIC_WIDTH (1): run a 128/128 configuration on the generic-width kernels
+                                of wide.hip; GAMD_KSEL_NO_HYBRID_TAIL (2): keep the whole conv-layer launch on the
+                                throughput kernel instead of finishing its last partial round on the latency kernel */
+    int32_t small_tile_limit;/* fp32 path: edge counts of at most this many 32-edge tiles run the latency-oriented conv kernel
+                                (one tile per 4-wave workgroup, bit-identical results).  0 = default (512), -1 = never */
 } gamd_config;
+enum { GAMD_SELF_LOOP_DGL07_NOOP = 0, GAMD_SELF_LOOP_APPEND_ZERO_FEATURE = 1 };
+enum { GAMD_KSEL_FORCE_GENERIC_WIDTH = 1, GAMD_KSEL_NO_HYBRID_TAIL = 2 };
 
 const char* gamd_version(void);
 const char* gamd_last_error(void);
@@ -100,9 +114,28 @@ int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds);
 int32_t gamd_forces_async(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
                           float* out_norm_dev, float* out_denorm_dev, void* stream);
 
-/* Wait for the stream, report 0 / -ERANGE-style overflow.  On overflow the buffers have been regrown
- * and the caller must re-issue the work (gamd_forces does that for you). */
+/* Float node features for the water models: feat_dev [n] fp32 (device, caller-owned, must stay valid for the calls
+ * that follow) is what the reference feeds to node_encoder = Linear(1 -> H) as `x` (nn_module.py:554, :403); NULL
+ * (default) = use (float)species, i.e. the O = 1 / H = 0 flag the drivers build (water/test_script/test_nosehoover.py:82-89).
+ * species_dev stays the integer type the integrators pick masses by. */
+int32_t gamd_set_node_features(gamd_handle* h, const float* feat_dev);
+
+/* Wait for the stream and report what the enqueued work ran into:
+ *   0    nothing.
+ *   1    a neighbour buffer overflowed inside an enqueued gamd_md_run / gamd_md_run_nhc: the device froze positions,
+ *        velocities and thermostat chain at the last consistent point (integrator and node kernels return while the
+ *        overflow flag is set), this call regrew the buffers, re-evaluated the forces there and finished the remaining
+ *        steps: the trajectory is the one an ample buffer would have produced.
+ *   -34  a neighbour buffer overflowed in gamd_forces_async: regrown, the caller must re-issue that call (gamd_forces
+ *        does it for you).
+ *   -33  non-finite forces in a reduced-precision edge dtype (bf16 / f16x3): an MFMA operand left the fp16 range
+ *        (|x| > 65504) or the input was not finite.  (The fp32 path returns non-finite forces silently, like the
+ *        reference; gamd_get_device_flags tells.) */
 int32_t gamd_sync_status(gamd_handle* h, void* stream);
+
+/* flags[0]: 1 if any force evaluation since the last call of this function produced a non-finite force component
+ * (then cleared); flags[1..3] reserved (0). */
+int32_t gamd_get_device_flags(gamd_handle* h, int32_t flags[4]);
 
 /* gamd_forces_async + gamd_sync_status + automatic regrow-and-retry; returns 0 or 1. */
 int32_t gamd_forces(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
@@ -135,6 +168,7 @@ enum {
     GAMD_DBG_COL = 2,       /* int32 [E]      source atom (sorted id) per CSR edge */
     GAMD_DBG_EFRAG = 3,     /* fp32  [ceil(E/32)][Eh/128][4][4][64][4]  e in fragment order */
     GAMD_DBG_FEAT = 4,      /* fp32  [E][48]  raw edge features (first 44|45, or 4|5 unexpanded, columns valid) */
+    GAMD_DBG_CYCLES = 5,    /* int64 [n_cu][8][16]  per-wave cycle sums of the instrumented conv-edge kernel (profiling build) */
     GAMD_DBG_H0 = 16        /* fp32  [n][H] residual stream h_l, sorted order: GAMD_DBG_H0 + l */
 };
 int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t bytes);
@@ -144,7 +178,8 @@ int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t byte
  *   force eval            predict_forces             LJ/test_script/test_langevin.py:108
  *   second half B         HackHalfVelocityIntegrator hack_integrator.py:175-178
  * x [n][3] Angstrom, v [n][3] Angstrom/ps, f [n][3] kJ/mol/nm (denormalised; in: forces at x, out: forces
- * at the new x).  Enqueues n_steps steps without synchronising. */
+ * at the new x).  Enqueues n_steps steps without synchronising; gamd_sync_status afterwards reports 0, or 1 when a
+ * neighbour buffer overflowed on the way (state frozen on the device, buffers regrown, run resumed and finished). */
 typedef struct gamd_md_params {
     float dt_ps;             /* 0.002 in the drivers */
     float mass_amu;          /* 39.9 for argon */

@@ -181,6 +181,23 @@ def conv_layer(sd, p: str, e: Tensor, hn: Tensor, src: Tensor, dst: Tensor) -> T
                "silu", 1, True)                                                # :147
 
 
+SELF_LOOP_MODES = ("dgl07_noop", "append_zero_feature_loops")
+
+
+def apply_self_loop_mode(e: Tensor, src: Tensor, dst: Tensor, n: int, mode: str):
+    """`fluid_graph.add_self_loop()` with the result discarded (nn_module.py:650-652, :518, :364).
+    "dgl07_noop": DGL >= 0.5 (pinned 0.7.0) returns a new graph, the one in use is unchanged.
+    "append_zero_feature_loops": an in-place add_self_loop (DGL < 0.5) appends one edge i -> i per node AFTER
+    edata['e'] was set, so the new edges carry DGL's zero-filled embedding (what oracle/ref_stubs.py does with
+    INPLACE_SELF_LOOP = True)."""
+    if mode == "dgl07_noop":
+        return e, src, dst
+    if mode != "append_zero_feature_loops":
+        raise ValueError(f"self_loop_mode must be one of {SELF_LOOP_MODES}")
+    loops = torch.arange(n, dtype=src.dtype)
+    return (torch.cat([e, torch.zeros((n, e.shape[1]), dtype=e.dtype)]), torch.cat([src, loops]), torch.cat([dst, loops]))
+
+
 def n_conv_layers(sd) -> int:
     n = 0
     while f"graph_conv.conv.{n}.src_affine.weight" in sd:
@@ -191,7 +208,7 @@ def n_conv_layers(sd) -> int:
 @torch.no_grad()
 def forward(sd: Dict[str, Tensor], pos: Tensor, edge_idx: Tensor, box,
             feat: Optional[Tensor] = None, bond: Optional[np.ndarray] = None,
-            stages: Optional[dict] = None) -> Tensor:
+            stages: Optional[dict] = None, self_loop_mode: str = "dgl07_noop") -> Tensor:
     """SimpleMDNetNew.forward (nn_module.py:672-685) when `feat` is None, else
     WaterMDNetNew.forward (nn_module.py:545-558).  edge_idx rows: centre, neighbour.
     Returns the *normalised* force [N,3]."""
@@ -208,6 +225,7 @@ def forward(sd: Dict[str, Tensor], pos: Tensor, edge_idx: Tensor, box,
         h = linear(sd, "node_encoder", feat)                                   # :554
     if stages is not None:
         stages["feat"], stages["e"], stages["h"] = f, e, [h]
+    e, src, dst = apply_self_loop_mode(e, src, dst, n, self_loop_mode)         # :650-652
     for l in range(n_conv_layers(sd)):                                         # :200-202
         hn = layer_norm(sd, f"graph_conv.norm_layers.{l}", h)
         h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst) + h
@@ -218,7 +236,7 @@ def forward(sd: Dict[str, Tensor], pos: Tensor, edge_idx: Tensor, box,
 
 @torch.no_grad()
 def forward_dynamic_box(sd, pos: Tensor, feat: Tensor, box, cutoff: float,
-                        stages: Optional[dict] = None) -> Tensor:
+                        stages: Optional[dict] = None, self_loop_mode: str = "dgl07_noop") -> Tensor:
     """WaterMDDynamicBoxNet.forward, nn_module.py:391-407 with build_graph
     :338-365 (md_module.get_neighbor: <=, no self; bond=None configs)."""
     edge_idx = neighbor_edges(pos, box, cutoff, "torch")
@@ -231,6 +249,7 @@ def forward_dynamic_box(sd, pos: Tensor, feat: Tensor, box, cutoff: float,
     src, dst = neigh, center
     if stages is not None:
         stages["feat"], stages["e"], stages["h"], stages["edge_idx"] = f, e, [h], edge_idx
+    e, src, dst = apply_self_loop_mode(e, src, dst, pos.shape[0], self_loop_mode)   # :364
     for l in range(n_conv_layers(sd)):
         hn = layer_norm(sd, f"graph_conv.norm_layers.{l}", h)
         h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst) + h

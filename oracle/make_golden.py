@@ -53,8 +53,9 @@ def margin_to_cutoff(pos32, box, cutoff):
 
 
 def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=None,
-                  bond=None, lmean=4.0, lstd=1.5, keep_h=True, edge_stride=1):
+                  bond=None, lmean=4.0, lstd=1.5, keep_h=True, edge_stride=1, inplace_self_loop=False):
     torch.manual_seed(1234)
+    ref_stubs.INPLACE_SELF_LOOP = bool(inplace_self_loop)
     sd = make_state_dict(cfg, seed, lmean, lstd)
     if cfg.kind == "lj":
         m = nn_module.SimpleMDNetNew(encoding_size=cfg.encoding_size, out_feats=3, box_size=box,
@@ -93,6 +94,7 @@ def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=Non
             out = m([posw], [edge_idx])
         else:
             out = m([posw], feat, [edge_idx])
+    ref_stubs.INPLACE_SELF_LOOP = False
     out = out.numpy()
     mean, var = scaler
     forces = out * np.sqrt(var) + mean          # denormalize, train_network_lj.py:128-131
@@ -106,6 +108,8 @@ def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=Non
                margin=np.float64(margin),
                cfg=np.array([cfg.kind, str(cfg.encoding_size), str(cfg.hidden_dim),
                              str(cfg.edge_embedding_dim), str(cfg.conv_layer), str(int(cfg.use_bond))]))
+    if inplace_self_loop:
+        rec["self_loop_inplace"] = np.int64(1)
     if keep_h:
         # h_0 .. h_L — enough to localise a diff to one layer
         rec["h_layers"] = np.stack([h.numpy() for h in hs])
@@ -118,7 +122,8 @@ def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=Non
           f"|F|max={np.abs(forces).max():.4g}")
 
 
-def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, lstd):
+def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, lstd, inplace_self_loop=False):
+    ref_stubs.INPLACE_SELF_LOOP = bool(inplace_self_loop)
     sd = make_state_dict(cfg, seed, lmean, lstd)
     m = nn_module.WaterMDDynamicBoxNet(in_feats=1, encoding_size=cfg.encoding_size, out_feats=3,
                                        bond=None, hidden_dim=cfg.hidden_dim, conv_layer=cfg.conv_layer,
@@ -135,7 +140,8 @@ def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, l
     edge_idx, dist, dist_norm, _ = md_module.get_neighbor(pos32, cutoff, torch.from_numpy(boxa))
     with torch.no_grad():
         out = m([pos32], feat, [boxa], cutoff).numpy()
-    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+    ref_stubs.INPLACE_SELF_LOOP = False
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), self_loop_inplace=np.int64(1 if inplace_self_loop else 0),
                         pos=pos32.numpy(), box=boxa, cutoff=np.float64(cutoff), seed=np.int64(seed),
                         length_mean=np.float64(lmean), length_std=np.float64(lstd),
                         edge_idx=edge_idx.numpy().astype(np.int32), dist_norm=dist_norm.numpy(),
@@ -151,6 +157,16 @@ def main():
     lj_pos = np.load(os.path.join(REF, "code/LJ/init_pos.npy"))          # [258,3] f32, in [0, 27.22]
     w_pos = np.load(os.path.join(REF, "code/water/init_pos.npy"))        # [774,3] f64, centred
     full = dict(encoding_size=128, hidden_dim=128, edge_embedding_dim=128, conv_layer=4)
+
+    # The other reading of `fluid_graph.add_self_loop()` (result discarded, nn_module.py:650-652, :364): an IN-PLACE
+    # add_self_loop as in DGL < 0.5.  The reference module is executed with a stub graph that mutates itself; these
+    # cases pin the build's self_loop_mode = 1 ("append_zero_feature_loops").  `--only-selfloop` writes just these.
+    run_fixed_box(nn_module, "lj258_selfloop_inplace_seed0", ModelConfig(kind="lj", **full), 0, lj_pos, 27.27, 7.5,
+                  SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, edge_stride=211, inplace_self_loop=True)
+    run_dynbox(nn_module, md_module, "dynbox384_selfloop_inplace_seed4", ModelConfig(kind="dynbox", **full), 4,
+               np.mod(w_pos[:384], 20.0), [20.0, 21.0, 22.5], 4.6, 3.1, 1.2, inplace_self_loop=True)
+    if "--only-selfloop" in sys.argv:
+        return
 
     # C1: the reference's own LJ snapshot, shipped LJ scaler, full-size model
     run_fixed_box(nn_module, "lj258_seed0", ModelConfig(kind="lj", **full), 0, lj_pos, 27.27, 7.5,

@@ -16,7 +16,12 @@ semantics listed in SURVEY.md §8(c):
 * `.local_scope()`                   -> context manager restoring the dicts
 * `.add_self_loop()`                 -> returns a NEW graph, receiver untouched
                                         (functional alias in DGL >= 0.5; call sites
-                                        nn_module.py:364,518,652 discard the result)
+                                        nn_module.py:364,518,652 discard the result).
+                                        `INPLACE_SELF_LOOP = True` switches the stub to the
+                                        OTHER reading (DGL < 0.5: the receiver itself gets
+                                        one i -> i edge per node, edge data zero-filled) so
+                                        that the build's self_loop_mode 1 has reference
+                                        outputs to be checked against
 * `.update_all(fn.src_mul_edge(a,b,m), fn.sum(m,o))`
                                      -> ndata[o][v] = sum_{u->v} ndata[a][u] * edata[b][uv]
                                         (zeros for nodes without in-edges)
@@ -27,6 +32,10 @@ import types
 import contextlib
 
 import torch
+
+
+# False: DGL >= 0.5 functional add_self_loop (the pinned DGL 0.7.0); True: in-place add_self_loop of DGL < 0.5
+INPLACE_SELF_LOOP = False
 
 
 class _StubGraph:
@@ -74,6 +83,11 @@ class _StubGraph:
         for k, v in self.edata.items():
             pad = torch.zeros((self._n,) + tuple(v.shape[1:]), dtype=v.dtype)
             g.edata[k] = torch.cat([v, pad])
+        if INPLACE_SELF_LOOP:
+            self._src, self._dst = g._src, g._dst
+            self.edata.clear()
+            self.edata.update(g.edata)
+            return self
         return g
 
     def update_all(self, msg, red):

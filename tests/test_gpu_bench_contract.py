@@ -1,4 +1,5 @@
-"""bench.py keeps the driver's contract: flags, exactly one JSON line on stdout, the required keys."""
+"""bench.py keeps the driver's contract: flags, exactly one JSON line on stdout, the required keys; N > 1 launches its
+own ranks."""
 import json
 import os
 import subprocess
@@ -10,9 +11,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", *flags],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+def _run(*flags, env=None, steps=6, warmup=2):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), *flags],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=e)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout
@@ -20,7 +25,7 @@ def _run(*flags):
 
 
 def test_default_line_has_the_contract_keys():
-    d = _run("--no-cpu-baseline")
+    d = _run("--no-cpu-baseline", "--no-secondary")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -35,12 +40,66 @@ def test_default_line_has_the_contract_keys():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
     assert r["launches"] == 4 * 6                         # four conv layers per timed step, timed live with HIP events
+    # the PMC traffic figure is reported only for the kernel sources it was measured on, otherwise null + a note
+    assert (r["traffic"] is not None) != ("traffic_note" in r)
+    g = r["neighbour_gather"]
+    assert g["bound"].startswith("mfma-bound") and 0.0 < g["frac_of_hbm_peak"] < 1.0
+    assert d["ensemble"]["boxes"] == 1 and len(d["ensemble"]["per_rank"]) == 1
 
 
 def test_split_fp16_line_is_labelled_as_such():
-    d = _run("--no-cpu-baseline", "--edge-dtype", "f16x3")
+    d = _run("--no-cpu-baseline", "--no-secondary", "--edge-dtype", "f16x3")
     assert d["dtype"].startswith("f16x3") and d["roofline"]["kernel"] == "k_conv_edge_f16x3"
     assert d["roofline"]["peak"] == 2500.0 and d["roofline"]["frac"] < 1.0
+
+
+def test_gpus_2_spawns_two_ranks_by_itself():
+    """`python bench.py --gpus 2` without torchrun: the parent starts one child per rank before touching a GPU and relays
+    rank 0's line.  Dry run of the N > 1 control flow on this one-GPU box (both ranks share device 0, gloo for the result
+    gather); on an 8-GPU node the same code puts rank r on device r with RCCL."""
+    d = _run("--gpus", "2", "--no-cpu-baseline", "--no-secondary", steps=4, warmup=1,
+             env={"GAMD_BENCH_SHARE_GPU": "1", "GAMD_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["config"]["boxes"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
+    assert d["config"]["launch"] == "self-spawned ranks"
+    ranks = d["ensemble"]["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["box_seed"] for r in ranks] == [1234, 1235]
+    assert ranks[0]["force_abs_sum"] != ranks[1]["force_abs_sum"] and ranks[0]["edges"] != ranks[1]["edges"]
+    assert d["ensemble"]["collective_on_step_path"] is False
+    # whole-job throughput = all ranks' atom-steps / max-over-ranks time
+    t_max = d["ms_per_step"] * 4e-3
+    assert abs(d["value"] - 2 * 10000 * 4 / t_max) / d["value"] < 1e-6
+    assert t_max >= max(r["seconds"] for r in ranks) * (1 - 1e-9)
+    assert "cpu_baseline" not in d and "secondary" not in d
+
+
+def test_gpus_2_without_a_second_device_fails_loudly():
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GAMD_BENCH_SHARE_GPU")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present")
+    assert p.returncode != 0 and p.stdout.strip() == "" and "only 1 HIP device" in p.stderr
+
+
+def test_secondary_block_kernels_list_and_cpu_baseline_on_c2():
+    """The full default line (what the driver records): C2 cpu_baseline on the timed run's own inputs, per-kernel
+    roofline entries, and the short C1 / C3 / C5 runs."""
+    d = _run(steps=10, warmup=3)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and "10000-atom" in cb["sample"] and cb["cores"] >= 1 and cb["host_threads"] >= cb["cores"]
+    assert cb["gpu_vs_cpu_rel_err"] < 1e-5 and cb["sample_2000"]["same_edge_count"] is True
+    assert d["value"] / cb["value"] > 10.0                                # north star: >= 10x the CPU path
+    names = [k["kernel"] for k in d["roofline"]["kernels"]]
+    assert names[0] == "k_edge_encode" and any(n.startswith("k_node") for n in names) and any("neighbour" in n for n in names)
+    enc = d["roofline"]["kernels"][0]
+    assert enc["bound"] == "mfma" and 0.3 < enc["frac"] < 1.0 and abs(enc["frac"] - enc["achieved"] / 157.3) < 1e-9
+    s = d["secondary"]
+    assert set(s) == {"c1", "c3", "c5", "c5b"}
+    assert s["c1"]["n_atoms"] == 258 and s["c3"]["n_atoms"] == 4170 and s["c5"]["n_atoms"] == 6000 and s["c5b"]["n_atoms"] == 8001
+    assert s["c5"]["dtype"] == "bf16" and s["c5"]["conv_kernel"]["bound"] == "hbm" and s["c3"]["dtype"] == "f32"
+    for v in s.values():
+        assert v["finite"] is True and v["value"] > 0 and abs(v["value"] - v["n_atoms"] * 20 / (v["ms_per_step"] * 20e-3)) / v["value"] < 1e-6
 
 
 def test_graft_entry_smoke_runs():

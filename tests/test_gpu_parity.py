@@ -181,17 +181,16 @@ def test_wide_and_unexpanded_configs_match_reference_golden(name):
     eng.close()
 
 
-def test_wide_kernels_reproduce_the_128_wide_path(monkeypatch):
-    """GAMD_FORCE_WIDE=1 routes the shipped 128-wide configuration through csrc/wide.hip: same goldens, same bar."""
+def test_wide_kernels_reproduce_the_128_wide_path():
+    """kernel_select = GAMD_KSEL_FORCE_GENERIC_WIDTH routes the shipped 128-wide configuration through csrc/wide.hip:
+    same goldens, same bar."""
     g, cfg, sd = load_golden("tip3p774_seed3")
     box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
     posw = torch.from_numpy(np.mod(g["pos"], box).astype(np.float32))
     species = g["node_feat"].reshape(-1) != 0
-    monkeypatch.setenv("GAMD_FORCE_WIDE", "1")
-    eng = _engine(sd, n, box, rc, bond=g["bond"], scaler=(g["scaler_mean"], g["scaler_var"]))
+    eng = _engine(sd, n, box, rc, bond=g["bond"], scaler=(g["scaler_mean"], g["scaler_var"]), kernel_select=1)
     out = eng.forward(posw, species=species).cpu().numpy()
     eng.close()
-    monkeypatch.delenv("GAMD_FORCE_WIDE")
     assert rel_err(out, g["out_norm"]) < TOL
     eng = _engine(sd, n, box, rc, bond=g["bond"], scaler=(g["scaler_mean"], g["scaler_var"]))
     out0 = eng.forward(posw, species=species).cpu().numpy()
@@ -521,7 +520,11 @@ def test_split_fp16_at_c2_size_against_the_fp32_path():
     assert rel_err(f16, f32) < TOL
 
 
-def test_small_system_conv_kernel_is_bit_identical_to_the_throughput_kernel(monkeypatch):
+# (small_tile_limit, kernel_select): throughput kernel only (never small, no hybrid tail) vs latency kernel only
+MAIN_ONLY, SMALL_ONLY = dict(small_tile_limit=-1, kernel_select=2), dict(small_tile_limit=1000000)
+
+
+def test_small_system_conv_kernel_is_bit_identical_to_the_throughput_kernel():
     """Below ~1 tile per SIMD the conv layer runs on conv_edge_small.hip (one tile shared by four waves).  Same
     floating-point operation order per output element as conv_edge.hip: the outputs must be equal bit for bit."""
     outs = {}
@@ -531,9 +534,8 @@ def test_small_system_conv_kernel_is_bit_identical_to_the_throughput_kernel(monk
         bond = g["bond"] if "bond" in g else None
         posw = torch.from_numpy(np.mod(g["pos"], box).astype(np.float32))
         species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
-        for limit in ("0", "1000000"):
-            monkeypatch.setenv("GAMD_CONV_SMALL_TILES", limit)
-            eng = _engine(sd, n, box, rc, bond=bond)
+        for limit, kw in (("0", MAIN_ONLY), ("1000000", SMALL_ONLY)):
+            eng = _engine(sd, n, box, rc, bond=bond, **kw)
             outs[limit] = eng.forward(posw, species=species).cpu().numpy().copy()
             eng.close()
         assert np.array_equal(outs["0"], outs["1000000"]), name
@@ -543,9 +545,8 @@ def test_small_system_conv_kernel_is_bit_identical_to_the_throughput_kernel(monk
         g, cfg, sd = load_golden(name)
         n = g["pos"].shape[0]
         species = g["node_feat"].reshape(-1) != 0
-        for limit in ("0", "1000000"):
-            monkeypatch.setenv("GAMD_CONV_SMALL_TILES", limit)
-            eng = _engine(sd, n, g["box"], float(g["cutoff"]), nbr_flavour="torch", cfg=cfg)
+        for limit, kw in (("0", MAIN_ONLY), ("1000000", SMALL_ONLY)):
+            eng = _engine(sd, n, g["box"], float(g["cutoff"]), nbr_flavour="torch", cfg=cfg, **kw)
             outs[limit] = eng.forward(torch.from_numpy(g["pos"]), box=g["box"], species=species).cpu().numpy().copy()
             eng.close()
         assert np.array_equal(outs["0"], outs["1000000"]), name

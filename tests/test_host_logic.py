@@ -125,3 +125,49 @@ def test_compat_wrappers_are_lazy_and_mirror_the_reference_signatures():
     assert lj.cuda() is lj and lj.eval() is lj
     with pytest.raises(RuntimeError, match="no weights"):
         lj._get_engine()
+
+
+def _bench(*flags, env=None):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GAMD_BENCH_SHARE_GPU")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], capture_output=True, text=True,
+                          timeout=300, cwd=root, env=e)
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`bench.py --gpus N` must never degrade silently to fewer ranks: without N visible devices it exits non-zero
+    before anything touches a GPU (round-1 verdict: it used to print n_gpus = 1)."""
+    if torch.cuda.device_count() >= 3:
+        pytest.skip("three devices present")
+    p = _bench("--gpus", "3", "--steps", "1", "--warmup", "0")
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "--gpus 3" in p.stderr and "HIP device" in p.stderr
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    p = _bench("--gpus", "3", "--steps", "1", "--warmup", "0", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and p.stdout.strip() == "" and "WORLD_SIZE=2" in p.stderr
+    p = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+def test_pmc_record_is_tied_to_kernel_sources():
+    """profiles/pmc_conv_edge.json carries the hash of the kernel sources it was measured on; bench.py prints
+    traffic = null (plus a note) when they no longer match."""
+    import json, importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    rec = json.load(open(os.path.join(root, "profiles", "pmc_conv_edge.json")))
+    assert "kernel_source_sha256_16" in rec and len(rec["kernel_source_sha256_16"]) == 16
+
+
+def test_self_loop_mode_names_agree_between_oracle_and_engine():
+    import gamd_oracle as orc
+    from gamd_amd.engine import SELF_LOOP
+    assert tuple(SELF_LOOP) == orc.SELF_LOOP_MODES and SELF_LOOP["dgl07_noop"] == 0

@@ -75,3 +75,46 @@ def test_state_dict_spec_counts():
     from gamd_amd.weights import ModelConfig, state_dict_spec
     n = sum(int(np.prod(s)) for s in state_dict_spec(ModelConfig(kind="lj")).values())
     assert n == 651565          # SURVEY.md §8a parameter inventory (incl. buffers-as-params)
+
+
+# ---- self_loop_mode: the one reference semantic that cannot be executed here (DGL absent) ----
+def _selfloop_lj():
+    g, cfg, sd = load_golden("lj258_selfloop_inplace_seed0")
+    box = float(g["box"])
+    posw = torch.from_numpy(np.mod(g["pos"], box)).float()
+    return g, sd, posw, torch.from_numpy(g["edge_idx"]).long(), box
+
+
+def test_self_loop_mode_append_matches_reference_with_inplace_add_self_loop():
+    """mode "append_zero_feature_loops" = the reference module run on a stub graph whose add_self_loop() mutates
+    the receiver (DGL < 0.5 semantics; oracle/ref_stubs.py INPLACE_SELF_LOOP)."""
+    g, sd, posw, edge_idx, box = _selfloop_lj()
+    assert int(g["self_loop_inplace"]) == 1
+    st = {}
+    out = orc.forward(sd, posw, edge_idx, box, stages=st, self_loop_mode="append_zero_feature_loops").numpy()
+    for l, h in enumerate(st["h"]):
+        assert rel_err(h.numpy(), g["h_layers"][l]) < 5e-6, f"layer {l}"
+    assert rel_err(out, g["out_norm"]) < 5e-6
+
+
+def test_self_loop_mode_default_is_the_dgl07_noop_and_differs():
+    """Same inputs and weights as lj258_seed0: the default mode reproduces THAT golden (functional add_self_loop,
+    result discarded), and the two readings really give different forces (so the switch is observable)."""
+    g1, sd, posw, edge_idx, box = _selfloop_lj()
+    g0, _, sd0 = load_golden("lj258_seed0")
+    assert np.array_equal(g0["edge_idx"], g1["edge_idx"]) and np.array_equal(g0["pos"], g1["pos"])
+    out = orc.forward(sd, posw, edge_idx, box).numpy()
+    assert rel_err(out, g0["out_norm"]) < 5e-6
+    assert rel_err(g1["out_norm"], g0["out_norm"]) > 1e-3
+    with pytest.raises(ValueError):
+        orc.forward(sd, posw, edge_idx, box, self_loop_mode="bogus")
+
+
+def test_self_loop_mode_append_dynamic_box():
+    g, cfg, sd = load_golden("dynbox384_selfloop_inplace_seed4")
+    g0 = load_golden("dynbox384_seed4")[0]
+    pos = torch.from_numpy(g["pos"])
+    out = orc.forward_dynamic_box(sd, pos, torch.from_numpy(g["node_feat"]), g["box"], float(g["cutoff"]),
+                                  self_loop_mode="append_zero_feature_loops").numpy()
+    assert rel_err(out, g["out_norm"]) < 5e-6
+    assert rel_err(g["out_norm"], g0["out_norm"]) > 1e-3
