@@ -109,11 +109,17 @@ def spawn_ranks(args) -> int:
     if rc != 0:
         print(f"bench.py: a rank exited with status {rc}", file=sys.stderr)
         return rc or 1
+    # rank 0's stdout carries the result line; anything else a library printed there (gloo announces its peers on
+    # stdout) goes to stderr so that this process still prints exactly ONE line
     lines = [l for l in out0.splitlines() if l.strip()]
-    if len(lines) != 1:
-        print(f"bench.py: rank 0 printed {len(lines)} lines, expected one JSON line", file=sys.stderr)
+    result = [l for l in lines if l.lstrip().startswith('{"metric"')]
+    for l in lines:
+        if l not in result:
+            print(l, file=sys.stderr)
+    if len(result) != 1:
+        print(f"bench.py: rank 0 printed {len(result)} result lines, expected one", file=sys.stderr)
         return 1
-    print(lines[0])
+    print(result[0])
     return 0
 
 

@@ -96,6 +96,12 @@ enum {
                         // they spend waiting for waves 4-7 anyway; waves 4-7 do it after the barrier, behind waves 0-3's MFMAs
     CV_PRIO_YOUNG = 8,  // static s_setprio 1 for waves 4-7
     CV_PRIO_GEMM = 16,  // s_setprio 1 around every wave's own MFMA stream
+    // timing ablations (WRONG results; profiling build only)
+    CV_ABL_NO_EPF = 32,     // no prefetch of the next tile's e (loaded after the barrier instead: exposed)
+    CV_ABL_P4_SILU = 64,    // phase 4's message / segment-sum post-op replaced by phase 3's SiLU
+    CV_ABL_NO_HN = 128,     // hn[src] gathers skipped
+    CV_ABL_NO_SD = 256,     // S[src] / D[dst] gathers skipped
+    CV_ABL_NO_STORE = 512,  // piece stores skipped
 };
 #ifndef CONV_PRODUCTION
 #define CONV_PRODUCTION 0
@@ -142,9 +148,9 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     const bool early = (V & CV_EARLY_INIT) && whalf == 0;
     if (V & CV_PRIO_YOUNG) { if (whalf == 1) __builtin_amdgcn_s_setprio(1); }
 
-    long long tacc[12];
+    long long tacc[16];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) tacc[i] = 0;
+    for (int i = 0; i < 16; ++i) tacc[i] = 0;
     long long tprev = 0;
 #define TMARK(i) do { if (TIME) { const long long tn__ = (long long)__builtin_readcyclecounter(); tacc[i] += tn__ - tprev; tprev = tn__; } } while (0)
 #define GEMM_PRIO(p) do { if (V & CV_PRIO_GEMM) __builtin_amdgcn_s_setprio(p); } while (0)
@@ -172,7 +178,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
         if (active) {
             load_e_tile(a.e_frag, tile, lane, RA);
-            load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
+            if (!(V & CV_ABL_NO_SD)) load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
         }
     }
     __syncthreads();
@@ -199,10 +205,10 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             gemm128_post<false>((const f32x4*)buf0, lane, RA, RB,
                                 [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
             GEMM_PRIO(0);
-            load_row_chain(a.S + (size_t)src * GAMD_H, half, RA);        // for phase 2's post-op
+            if (!(V & CV_ABL_NO_SD)) load_row_chain(a.S + (size_t)src * GAMD_H, half, RA);        // for phase 2's post-op
             TMARK(1);
         }
-        if (active) phase_barrier<16>(); else phase_barrier<0>();
+        if (active && !(V & CV_ABL_NO_SD)) phase_barrier<16>(); else phase_barrier<0>();
         TMARK(2);
         // ===== phase 2: RC = SiLU(W2 T1 + D[dst] + S[src])        in RB, S in RA =====
         stage(a.w3p, buf0);
@@ -214,18 +220,20 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             GEMM_PRIO(0);
             // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge); the source index of
             // edge (half, r) lives in lane rho(r, half) of `src`
+            if (!(V & CV_ABL_NO_HN)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int s = __shfl(src, rho, 64);
-                const float* hrow = a.hn + (size_t)s * GAMD_H + slot;
+                for (int r = 0; r < 16; ++r) {
+                    const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int s = __shfl(src, rho, 64);
+                    const float* hrow = a.hn + (size_t)s * GAMD_H + slot;
 #pragma unroll
-                for (int tp = 0; tp < 4; ++tp) RA[tp][r] = hrow[32 * tp];
+                    for (int tp = 0; tp < 4; ++tp) RA[tp][r] = hrow[32 * tp];
+                }
             }
             if (early) load_bias_chain(vb3, half, RB);                    // RB (T1) is free: phase 3's accumulators
             TMARK(4);
         }
-        if (active) phase_barrier<63>(); else phase_barrier<0>();
+        if (active && !(V & CV_ABL_NO_HN)) phase_barrier<63>(); else phase_barrier<0>();
         TMARK(5);
         // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
         stage(a.w4p, buf1);
@@ -263,6 +271,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
             GEMM_PRIO(1);
             gemm128_post<true>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
+                if (V & CV_ABL_P4_SILU) { RC[tp][r] = gamd_silu_hw(RC[tp][r]); return; }
                 const float prod = (r < nvalid) ? RA[tp][r] * RC[tp][r] : 0.f;
                 if (r == 0) RC[tp][0] = prod;
                 else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
@@ -276,12 +285,18 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             TMARK(10);
         }
         // prefetch the next tile's e (-> RA): in flight across the barrier
-        if (active_n) load_e_tile(a.e_frag, tile_n, lane, RA);
+        if (active_n && !(V & CV_ABL_NO_EPF)) load_e_tile(a.e_frag, tile_n, lane, RA);
         if (early && active_n) load_bias_chain(vb1, half, RB);            // RB (T4) is free: next tile's phase 1
-        if (active_n) phase_barrier<16>(); else phase_barrier<0>();
+        TMARK(12);
+        if (active_n && !(V & CV_ABL_NO_EPF)) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        TMARK(13);
+        __builtin_amdgcn_s_barrier();
         TMARK(11);
+        if (active_n && (V & CV_ABL_NO_EPF)) load_e_tile(a.e_frag, tile_n, lane, RA);
         // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge does
         // not close a segment, that edge too (the run continues in the next chunk as its own piece)
+        if (V & CV_ABL_NO_STORE) pend_ends = 0;
         while (__any(pend_ends != 0)) {
             if (pend_ends != 0) {
                 const int r = __builtin_ctz(pend_ends);
@@ -297,12 +312,13 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             }
         }
         // D[dst] of the next tile (C-in of its phase 2) -> RC, now free; lands during phase 1
-        if (active_n) load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
+        if (active_n && !(V & CV_ABL_NO_SD)) load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
+        TMARK(14);
         tile = tile_n; active = active_n; src = src_n; dst = dst_n;
     }
     if (TIME && a.tdbg && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) a.tdbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = tacc[i];
+        for (int i = 0; i < 16; ++i) a.tdbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = tacc[i];
     }
 #undef TMARK
 #undef GEMM_PRIO
@@ -330,7 +346,8 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     if (v < 0) { const char* s = getenv("GAMD_CONV_VARIANT"); v = s ? atoi(s) : CONV_PRODUCTION; }
     switch (v) {
 #define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
-        CASE(0); CASE(1); CASE(2); CASE(3); CASE(4); CASE(6); CASE(7); CASE(8); CASE(14); CASE(16); CASE(22);
+        CASE(0); CASE(1); CASE(2); CASE(8); CASE(16); CASE(33); CASE(65); CASE(129); CASE(257); CASE(513); CASE(993);
+        CASE(32); CASE(64); CASE(128); CASE(256); CASE(512); CASE(992);
 #undef CASE
         default: break;
     }

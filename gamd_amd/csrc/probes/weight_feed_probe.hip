@@ -56,6 +56,27 @@ __device__ __forceinline__ void gemm_l2(const f32x4* __restrict__ W, const f32x4
     for (int g = 0; g < 16; ++g) post(3, g);
 }
 
+// LDS-fed GEMM over TWO tiles held by one wave: every weight fragment read feeds 8 MFMAs
+template <typename WPtr, typename Post>
+__device__ __forceinline__ void gemm_lds2(WPtr W, int lane, const f32x16 (&X0)[4], const f32x16 (&X1)[4], f32x16 (&a0)[4],
+                                          f32x16 (&a1)[4], Post post) {
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = W[((tp * 4 + t) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a0[tp] = mfma32(w[j], X0[t][q * 4 + j], a0[tp]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a1[tp] = mfma32(w[j], X1[t][q * 4 + j], a1[tp]);
+                if (tp > 0) post(tp - 1, t * 4 + q);
+            }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) post(3, g);
+}
+
 template <int MODE, int D, int THREADS>
 __global__ void __launch_bounds__(THREADS, THREADS / 256) k(const float* __restrict__ W4, float* __restrict__ out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -67,7 +88,56 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k(const float* __restr
     auto Wm = [&](int m) { return W4 + (size_t)(m & 3) * GAMD_WFRAG_FLOATS; };
     auto silu_post = [&](int tp, int g) { acc[tp][g] = silu_hw(acc[tp][g]); };
 
-    if (MODE == 0 || MODE == 1) {
+    if (MODE == 5 || MODE == 6) {
+        // one wave per SIMD, two tiles per wave, LDS ring + barrier per GEMM; mode 6 adds per GEMM and tile a 16 KB streamed
+        // read consumed by the post-op plus 64 dword gathers (the kernel's e / S / D / hn traffic)
+        float* buf[2] = {lds, lds + GAMD_WFRAG_FLOATS};
+        f32x16 Y[4], acc1[4];
+        for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) { Y[t][r] = 0.002f * (lane + r - t); acc1[t][r] = 0.f; }
+        gamd_stage_weight<4>(Wm(0), buf[0], wave, lane16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                gamd_stage_weight<4>(Wm(m + 1), buf[(m + 1) & 1], wave, lane16);
+                for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) { acc[t][r] = 0.01f; acc1[t][r] = 0.02f; }
+                if (MODE == 6) {
+                    f32x16 S0[4], S1[4];
+                    const size_t tb = ((size_t)(blockIdx.x * 4 + wave) * 64 + ((it * 4 + m) & 63)) * 8192;
+                    const f32x4* gp = (const f32x4*)(W4 + 4 * GAMD_WFRAG_FLOATS + tb);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v0 = gp[(t * 4 + q) * 64 + lane], v1 = gp[1024 + (t * 4 + q) * 64 + lane];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { S0[t][q * 4 + j] = v0[j]; S1[t][q * 4 + j] = v1[j]; }
+                        }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned row = ((it * 16 + r) * 2654435761u + blockIdx.x * 97u + m) % 10000u;
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) {
+                            S0[tp][r] += W4[4 * GAMD_WFRAG_FLOATS + (size_t)row * 128 + 32 * tp + (lane & 31)];
+                            S1[tp][r] += W4[4 * GAMD_WFRAG_FLOATS + (size_t)(row + 77) * 128 + 32 * tp + (lane & 31)];
+                        }
+                    }
+                    gemm_lds2((const f32x4*)buf[m & 1], lane, X, Y, acc, acc1, [&](int tp, int g) {
+                        acc[tp][g] = silu_hw(acc[tp][g] + S0[tp][g]); acc1[tp][g] = silu_hw(acc1[tp][g] + S1[tp][g]); });
+                } else {
+                    gemm_lds2((const f32x4*)buf[m & 1], lane, X, Y, acc, acc1, [&](int tp, int g) {
+                        acc[tp][g] = silu_hw(acc[tp][g]); acc1[tp][g] = silu_hw(acc1[tp][g]); });
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { X[t] = acc[t]; Y[t] = acc1[t]; }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        float s1 = 0.f;
+        for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s1 += acc1[t][r] + Y[t][r];
+        out[blockIdx.x * 512 + tid + 256] = s1;
+    } else if (MODE == 0 || MODE == 1 || MODE == 7) {
         float* buf[2] = {lds, lds + GAMD_WFRAG_FLOATS};
         auto stage = [&](int m, float* dst) {
             if (MODE == 1) { if (wave >= 4) gamd_stage_weight<4>(Wm(m), dst, wave & 3, lane16); }
@@ -81,6 +151,26 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k(const float* __restr
             for (int m = 0; m < 4; ++m) {
                 stage(m + 1, buf[(m + 1) & 1]);
                 for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.01f;
+                if (MODE == 7) {
+                    f32x16 S0[4];
+                    const size_t tb = ((size_t)(blockIdx.x * 8 + wave) * 64 + ((it * 4 + m) & 63)) * 4096;
+                    const f32x4* gp = (const f32x4*)(W4 + 4 * GAMD_WFRAG_FLOATS + tb);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v0 = gp[(t * 4 + q) * 64 + lane];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) S0[t][q * 4 + j] = v0[j];
+                        }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned row = ((it * 16 + r) * 2654435761u + blockIdx.x * 97u + m) % 10000u;
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) S0[tp][r] += W4[4 * GAMD_WFRAG_FLOATS + (size_t)row * 128 + 32 * tp + (lane & 31)];
+                    }
+                    gemm_lds((const f32x4*)buf[m & 1], lane, X, acc, [&](int tp, int g) { acc[tp][g] = silu_hw(acc[tp][g] + S0[tp][g]); });
+                } else
                 gemm_lds((const f32x4*)buf[m & 1], lane, X, acc, silu_post);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) X[t] = acc[t];
@@ -138,14 +228,17 @@ double run(const float* dW, float* dOut, int iters) {
     k<MODE, D, threads><<<256, threads, ldsb>>>(dW, dOut, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double flop = 256.0 * (threads / 64) * iters * 4.0 * 256 * 4096.0;   // blocks*waves*tiles*GEMMs*MFMAs*flop
+    const double flop = 256.0 * (threads / 64) * iters * 4.0 * 256 * 4096.0 * ((MODE == 5 || MODE == 6) ? 2.0 : 1.0);
     return flop / (ms * 1e-3) / 1e12;
 }
 
 int main() {
     std::vector<float> W(4 * GAMD_WFRAG_FLOATS);
     for (size_t i = 0; i < W.size(); ++i) W[i] = ((i * 2654435761u) % 1000) * 1e-5f - 0.005f;
-    float *dW, *dOut; hipMalloc(&dW, W.size() * 4); hipMalloc(&dOut, 256 * 512 * 4);
+    // 4 weight matrices, then a 512 MiB region the streamed / gathered reads of modes 6 and 7 walk through
+    const size_t stream_floats = (size_t)256 * 8 * 64 * 4096;
+    float *dW, *dOut; hipMalloc(&dW, (W.size() + stream_floats) * 4); hipMalloc(&dOut, 256 * 1024 * 4);
+    hipMemset(dW, 0, (W.size() + stream_floats) * 4);
     hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
     const int iters = 100;      // tiles per wave
     for (int rep = 0; rep < 2; ++rep) {
@@ -157,6 +250,9 @@ int main() {
         printf("mode3 weights straight from L2, depth 16 (4 waves)         : %.1f TF\n", run<3, 16, 256>(dW, dOut, iters));
         printf("mode4 W1,W2 LDS-resident + W3,W4 from L2 depth 4 (8 waves) : %.1f TF\n", run<4, 4, 512>(dW, dOut, iters));
         printf("mode4 W1,W2 LDS-resident + W3,W4 from L2 depth 8 (4 waves) : %.1f TF\n", run<4, 8, 256>(dW, dOut, iters));
+        printf("mode5 LDS ring, 4 waves x 2 tiles each, barrier per GEMM       : %.1f TF\n", run<5, 4, 256>(dW, dOut, iters / 2));
+        printf("mode7 mode0 + 16 KB streamed + 64 gathers per GEMM (8 w x 1 t) : %.1f TF\n", run<7, 4, 512>(dW, dOut, iters));
+        printf("mode6 mode5 + the same traffic per tile (4 waves x 2 tiles)    : %.1f TF\n", run<6, 4, 256>(dW, dOut, iters / 2));
     }
     return 0;
 }

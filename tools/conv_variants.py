@@ -14,8 +14,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so")
-SEGMENTS = ["p1 pre", "p1 gemm+post+prefetch", "p1 barrier", "p2 pre", "p2 gemm+post+prefetch", "p2 barrier",
-            "p3 pre", "p3 gemm+post+prefetch", "p3 barrier", "p4 pre", "p4 gemm+segment-sum", "p4 barrier"]
+SEGMENTS = ["p1 pre (DMA issue, bias)", "p1 gemm+post+S gather issue", "p1 barrier", "p2 pre (DMA issue)",
+            "p2 gemm+post+hn gather issue", "p2 barrier", "p3 pre (DMA, idx loads, bias)", "p3 gemm+post", "p3 barrier",
+            "p4 pre (DMA issue, b4)", "p4 gemm+segment-sum", "p4 s_barrier", "p4 e-prefetch issue", "p4 vmcnt wait",
+            "piece stores + D gather issue"]
 
 
 def child():
@@ -49,7 +51,7 @@ def child():
            "sha": hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]}
     if rec["variant"] & 1:
         t = eng._dbg(5, (256, 8, 16), np.int64).astype(np.float64)
-        tot = t[:, :, :12].sum(-1)
+        tot = t[:, :, :15].sum(-1)
         rec["cycles"] = {"per_wave_total": float(tot.mean()),
                          "segments": {nm: [float(t[:, :, i].mean()), float(t[:, :4, i].mean()), float(t[:, 4:, i].mean())]
                                       for i, nm in enumerate(SEGMENTS)}}
