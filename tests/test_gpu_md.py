@@ -206,7 +206,7 @@ def test_rigid_water_nose_hoover_matches_oracle():
     steps = 3
     chain = eng.md_run_nhc(x, v, f, steps, dt_ps=dt, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, temperature_k=T,
                            frequency_per_ps=freq, chain_length=M, species=species, rigid_water=True,
-                           r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH)
+                           r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH, remove_cm_motion=False)
     st = orc.nhc_init(M, freq)
     kT, ndf = wl.KB * T, 2.0 * n
     for _ in range(steps):
