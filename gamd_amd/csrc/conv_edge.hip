@@ -92,8 +92,6 @@ enum {
     CV_TIME = 1,        // per-segment cycle counters -> a.tdbg
     CV_ASYM_DMA = 2,    // the weight DMA of a phase is issued by waves 4-7 only (16 x 1 KiB each): waves 0-3, which the
                         // SIMD arbiter serves first after a barrier, go straight to their first MFMA
-    CV_EARLY_INIT = 4,  // waves 0-3 initialise the next phase's accumulators (bias rows) BEFORE the barrier, in the time
-                        // they spend waiting for waves 4-7 anyway; waves 4-7 do it after the barrier, behind waves 0-3's MFMAs
     CV_PRIO_YOUNG = 8,  // static s_setprio 1 for waves 4-7
     CV_PRIO_GEMM = 16,  // s_setprio 1 around every wave's own MFMA stream
     // timing ablations (WRONG results; profiling build only)
@@ -126,10 +124,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     // Work unit = 4 tiles, one per SIMD.  Waves 0-3 and 4-7 of the workgroup take successive units of its list, so
     // the work is balanced to half an iteration (an iteration with only waves 0-3 active takes about half the
     // time: the two waves of a SIMD serialise their MFMA streams anyway).
-    int n_units = (n_tiles + 3) / 4;
-    // hybrid launch: whole rounds only (the same number of units for every workgroup); the remaining
-    // < 4 * gridDim.x tiles are k_conv_edge_small's, which splits each tile over four SIMDs
-    if (a.split_wgs > 0) n_units = (n_units / (int)gridDim.x) * (int)gridDim.x;
+    const int n_units = (n_tiles + 3) / 4;
     int first, end, step;
     gamd_xcd_range(n_units, blockIdx.x, gridDim.x, first, end, step);
     if (first >= end) return;
@@ -144,8 +139,6 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         if (V & CV_ASYM_DMA) { if (whalf == 1) gamd_stage_weight<4>(gw, buf, wsub, lane16); }
         else gamd_stage_weight<8>(gw, buf, wave, lane16);
     };
-    // accumulator initialisation of a phase: before the preceding barrier for waves 0-3, after it for waves 4-7
-    const bool early = (V & CV_EARLY_INIT) && whalf == 0;
     if (V & CV_PRIO_YOUNG) { if (whalf == 1) __builtin_amdgcn_s_setprio(1); }
 
     long long tacc[16];
@@ -182,7 +175,6 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         }
     }
     __syncthreads();
-    if (early && active) load_bias_chain(vb1, half, RB);
     if (TIME) tprev = (long long)__builtin_readcyclecounter();
     unsigned pend_ends = 0;           // piece stores of the tile just finished (issued after its last barrier)
     int pend_p = 0;
@@ -199,7 +191,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====
         stage(a.w2p, buf1);
         if (active) {
-            if (!early) load_bias_chain(vb1, half, RB);
+            load_bias_chain(vb1, half, RB);
             TMARK(0);
             GEMM_PRIO(1);
             gemm128_post<false>((const f32x4*)buf0, lane, RA, RB,
@@ -230,7 +222,6 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
                     for (int tp = 0; tp < 4; ++tp) RA[tp][r] = hrow[32 * tp];
                 }
             }
-            if (early) load_bias_chain(vb3, half, RB);                    // RB (T1) is free: phase 3's accumulators
             TMARK(4);
         }
         if (active && !(V & CV_ABL_NO_HN)) phase_barrier<63>(); else phase_barrier<0>();
@@ -249,13 +240,12 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
         }
         if (active) {
-            if (!early) load_bias_chain(vb3, half, RB);
+            load_bias_chain(vb3, half, RB);
             TMARK(6);
             GEMM_PRIO(1);
             gemm128_post<false>((const f32x4*)buf0, lane, RC, RB,
                                 [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
             GEMM_PRIO(0);
-            if (early) init_b4();                                         // RC (T3) is free: phase 4's accumulators
             TMARK(7);
         }
         phase_barrier<0>();
@@ -263,7 +253,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // ===== phase 4: RC = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
         stage(a.w1p, buf0);       // next tile's W1 (harmless on the last iteration)
         if (active) {
-            if (!early) init_b4();
+            init_b4();
             TMARK(9);
             // e_emb for this lane's 16 edges x 4 features, then message + segment sum (nn_module.py:142
             // u_mul_e -> sum).  In-stream part is branch-free: RC[tp][r] becomes the running sum of the
@@ -286,7 +276,6 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         }
         // prefetch the next tile's e (-> RA): in flight across the barrier
         if (active_n && !(V & CV_ABL_NO_EPF)) load_e_tile(a.e_frag, tile_n, lane, RA);
-        if (early && active_n) load_bias_chain(vb1, half, RB);            // RB (T4) is free: next tile's phase 1
         TMARK(12);
         if (active_n && !(V & CV_ABL_NO_EPF)) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -28,12 +28,8 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
     int E = a.counters[CNT_E];
     if ((long long)E > a.e_cap) E = (int)a.e_cap;
     const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
-    // hybrid launch (ConvEdgeArgs::split_wgs): k_conv_edge has taken the whole rounds of 4-tile units; this kernel
-    // finishes the launch tail, one tile per workgroup = a quarter tile per SIMD instead of a whole one
-    int tile_begin = 0;
-    if (a.split_wgs > 0) tile_begin = 4 * ((((n_tiles + 3) / 4) / a.split_wgs) * a.split_wgs);
 
-    for (int tile = tile_begin + blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
         const int src = valid ? a.col[x] : 0;

@@ -125,7 +125,7 @@ struct gamd_handle {
     const uint8_t* rigid_checked = nullptr;   // species pointer whose O,H,H layout has been validated
     MdPending pending;
     bool has_bonds = false;
-    bool hybrid_tail = true;
+
     // Verlet-skin reuse (cfg.neighbor_skin > 0)
     float skin = 0.f;
     DevBuf ref_pos, cand_deg, cand_ptr, cand_col;
@@ -450,10 +450,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
         if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
     }
-    // Large fp32 launches: the throughput kernel takes the whole rounds of work (every workgroup the same number of
-    // 4-tile units) and the latency kernel the < 4 * n_cu tiles that are left, a quarter tile per SIMD instead of a
-    // whole one: the launch tail shrinks from half a round to a fraction of it.  Bit-identical per tile either way.
-    const bool hybrid = h->hybrid_tail && !h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F32 && small_tiles == 0;
+
     for (int l = 0; l < h->L; ++l) {
         ConvEdgeArgs ca{};
         ca.counters = h->counters.as<int>();
@@ -466,7 +463,6 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
         ca.partial = h->partial.as<float>();
         ca.e_cap = h->e_cap;
-        ca.split_wgs = hybrid ? h->n_cu : 0;
         ca.tdbg = h->tdbg.as<long long>();
         if (h->timing) {
             if (h->tev_used + 2 > h->tev.size()) {
@@ -479,7 +475,6 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st)
             : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3(ca, h->n_cu, st)
             : small_tiles > 0 ? launch_conv_edge_small(ca, small_tiles, st) : launch_conv_edge(ca, h->n_cu, st);
-        if (r == 0 && hybrid) r = launch_conv_edge_small(ca, 4 * h->n_cu, st);
         if (r) return fail(-1, "conv edge launch failed (%d)", r);
         if (h->timing) { HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st)); h->tev_used += 2; }
         mark("conv_edge");
@@ -571,7 +566,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         return fail(-22, "unknown self_loop_mode %d", cfg->self_loop_mode);
     if (cfg->self_loop_mode != GAMD_SELF_LOOP_DGL07_NOOP && cfg->edge_dtype != GAMD_EDGE_F32)
         return fail(-22, "self_loop_mode 1 is built for the fp32 edge dtype only");
-    if (cfg->kernel_select & ~(GAMD_KSEL_FORCE_GENERIC_WIDTH | GAMD_KSEL_NO_HYBRID_TAIL))
+    if (cfg->kernel_select & ~GAMD_KSEL_FORCE_GENERIC_WIDTH)
         return fail(-22, "unknown kernel_select bits 0x%x", cfg->kernel_select);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -595,7 +590,6 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
     h->skin = cfg->neighbor_skin;
     if (cfg->small_tile_limit != 0) h->small_tile_limit = cfg->small_tile_limit < 0 ? -1 : cfg->small_tile_limit;
-    h->hybrid_tail = !(cfg->kernel_select & GAMD_KSEL_NO_HYBRID_TAIL);
     const bool forced = (cfg->kernel_select & GAMD_KSEL_FORCE_GENERIC_WIDTH) && cfg->edge_dtype == GAMD_EDGE_F32;
     h->wide_enc = generic || forced;
     h->wide_conv = H != 128 || Eh != 128 || forced;

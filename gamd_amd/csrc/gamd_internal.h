@@ -115,9 +115,6 @@ struct ConvEdgeArgs {
     const float* b1; const float* b3; const float* b4;                           // [128]
     float* partial;            // [pieces][128]
     long long e_cap;
-    int split_wgs;             // > 0: hybrid launch.  k_conv_edge (split_wgs workgroups) takes the whole rounds of 4-tile
-                               // units, floor(units / split_wgs) per workgroup; k_conv_edge_small takes the tiles after them
-                               // (the launch tail, < 4 * split_wgs tiles).  Both kernels are bit-identical per tile.
     long long* tdbg;           // profiling builds only: [blocks][8 waves][16] cycle sums, or null
 };
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);

@@ -24,7 +24,7 @@ KIND = {"lj": 0, "water": 1, "dynbox": 1}
 FLAVOUR = {"jaxmd": 0, "torch": 1}
 # what `fluid_graph.add_self_loop()` with its result discarded does (nn_module.py:650-652)
 SELF_LOOP = {"dgl07_noop": 0, "append_zero_feature_loops": 1}
-KSEL_FORCE_GENERIC_WIDTH, KSEL_NO_HYBRID_TAIL = 1, 2
+KSEL_FORCE_GENERIC_WIDTH = 1
 
 
 def _box3(box) -> np.ndarray:

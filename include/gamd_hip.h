@@ -73,15 +73,14 @@ typedef struct gamd_config {
                                 have done: one extra edge i -> i per atom whose embedding e is DGL's zero fill (it is appended
                                 after edata['e'] was set).  The one reference semantic that cannot be executed in the build
                                 container (DGL absent), hence the switch.  fp32 edge dtype only. */
-    int32_t kernel_select;   /* 0 = automatic.  Bit flags for tests and tuning (never change results beyond fp32 rounding):
+    int32_t kernel_select;   /* 0 = automatic.  Bit flags for tests (never change results beyond fp32 rounding):
                                 GAMD_KSEL_FORCE_GENERIC_WIDTH (1): run a 128/128 configuration on the generic-width kernels
-                                of wide.hip; GAMD_KSEL_NO_HYBRID_TAIL (2): keep the whole conv-layer launch on the
-                                throughput kernel instead of finishing its last partial round on the latency kernel */
+                                of wide.hip */
     int32_t small_tile_limit;/* fp32 path: edge counts of at most this many 32-edge tiles run the latency-oriented conv kernel
                                 (one tile per 4-wave workgroup, bit-identical results).  0 = default (512), -1 = never */
 } gamd_config;
 enum { GAMD_SELF_LOOP_DGL07_NOOP = 0, GAMD_SELF_LOOP_APPEND_ZERO_FEATURE = 1 };
-enum { GAMD_KSEL_FORCE_GENERIC_WIDTH = 1, GAMD_KSEL_NO_HYBRID_TAIL = 2 };
+enum { GAMD_KSEL_FORCE_GENERIC_WIDTH = 1 };
 
 const char* gamd_version(void);
 const char* gamd_last_error(void);

@@ -520,8 +520,8 @@ def test_split_fp16_at_c2_size_against_the_fp32_path():
     assert rel_err(f16, f32) < TOL
 
 
-# (small_tile_limit, kernel_select): throughput kernel only (never small, no hybrid tail) vs latency kernel only
-MAIN_ONLY, SMALL_ONLY = dict(small_tile_limit=-1, kernel_select=2), dict(small_tile_limit=1000000)
+# small_tile_limit: throughput kernel only (never small) vs latency kernel only
+MAIN_ONLY, SMALL_ONLY = dict(small_tile_limit=-1), dict(small_tile_limit=1000000)
 
 
 def test_small_system_conv_kernel_is_bit_identical_to_the_throughput_kernel():

@@ -1,5 +1,5 @@
 """GPU tests added in round 2: checkpoint-driven driver sequences, the self_loop_mode switch,
-float node features, hybrid launch tail, freeze-and-resume of an enqueued MD run after a neighbour-buffer overflow,
+float node features, freeze-and-resume of an enqueued MD run after a neighbour-buffer overflow,
 non-finite / operand-range flags, argument checks of the MD entry points, fresh output tensors, the two timing buckets
 of predict_forces(verbose=True), and the 8 001-network-atom reading of BASELINE config 5.  All through the C ABI."""
 from types import SimpleNamespace
@@ -193,23 +193,6 @@ def test_float_node_features_are_carried_not_binarised(kernel_select):
     w = ParticleNetLightningWater(state_dict=sd)
     fw = w.pnet_model([posw.cuda()], feat.cuda(), [edges.cuda()]).cpu().numpy()
     assert rel_err(fw, ref) < TOL
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# hybrid launch tail: throughput kernel for the whole rounds + latency kernel for the rest
-# ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n_atoms", [10000, 2600])
-def test_hybrid_tail_is_bit_identical_to_the_single_kernel_launch(n_atoms):
-    pos, box = workloads.lj_box(n_atoms, seed=77)
-    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
-    p = torch.from_numpy(pos).float()
-    a = _engine(sd, n_atoms, box, 10.2)                               # default: hybrid
-    b = _engine(sd, n_atoms, box, 10.2, kernel_select=2)              # GAMD_KSEL_NO_HYBRID_TAIL
-    fa, fb = a.forward(p).cpu().numpy(), b.forward(p).cpu().numpy()
-    assert a.counts()[0] == b.counts()[0] and a.counts()[0] > 32 * 600
-    assert np.array_equal(fa, fb)
-    assert np.array_equal(a.forward(p).cpu().numpy(), fa)
-    a.close(); b.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of k_conv_edge variants (profiling build, libgamd_hip_prof.so) on the C2 workload.
 
-    python tools/conv_variants.py 0 2 4 6 8 16 [--no-hybrid] [--cycles]
+    python tools/conv_variants.py 0 1 2 8 16 32 ...
 
 Every variant runs in its own process (the variant is latched per process by GAMD_CONV_VARIANT).  Prints one line per
 variant: average conv-layer time (HIP events around the launch, as bench.py does), TFLOP/s of the 131 072 FLOP/edge
@@ -31,8 +31,7 @@ def child():
     n = int(os.environ.get("CV_ATOMS", "10000"))
     pos, box = lj_box(n)
     sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
-    eng = GamdForce(sd, n, box, 3.0 * 3.4, scaler=SHIPPED_SCALERS["lj"],
-                    kernel_select=2 if os.environ.get("CV_NO_HYBRID") == "1" else 0)
+    eng = GamdForce(sd, n, box, 3.0 * 3.4, scaler=SHIPPED_SCALERS["lj"])
     p = torch.from_numpy(pos).float().cuda()
     for _ in range(3):
         out = eng.forward(p, inplace=True)
@@ -44,8 +43,7 @@ def child():
     eng.timing_enable(False)
     E = eng.counts()[0]
     n_tiles = (E + 31) // 32
-    hybrid = os.environ.get("CV_NO_HYBRID") != "1"
-    main_tiles = 4 * ((((n_tiles + 3) // 4) // 256) * 256) if hybrid else n_tiles
+    main_tiles = n_tiles
     rec = {"variant": int(os.environ.get("GAMD_CONV_VARIANT", "0")), "E": E, "main_tiles": main_tiles, "conv_us": ms / cnt * 1e3,
            "tflops": E * 131072 / (ms / cnt * 1e-3) / 1e12, "launches": cnt,
            "sha": hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]}
@@ -65,8 +63,6 @@ def main():
     rows = []
     for v in variants:
         env = dict(os.environ, GAMD_LIB=PROF, GAMD_CONV_VARIANT=str(v), CV_CHILD="1")
-        if "--no-hybrid" in sys.argv:
-            env["CV_NO_HYBRID"] = "1"
         p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in p.stdout.splitlines() if l.startswith("CVJSON ")]
         if p.returncode != 0 or not line:
