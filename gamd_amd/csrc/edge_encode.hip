@@ -18,6 +18,15 @@ namespace {
 constexpr int ENC_W1_FLOATS = 4 * 6 * 64 * 4;              // K padded to 48 (24 MFMA steps)
 constexpr int ENC_LDS_FLOATS = ENC_W1_FLOATS + 2 * GAMD_WFRAG_FLOATS + 5 * 128 + 64;
 
+// X = GELU(acc) on a 32 x 128 block.  ABL bit 1 (profiling build): x/2 instead (timing ablation, wrong results)
+template <int ABL>
+__device__ __forceinline__ void gelu_block(const f32x16 (&acc)[4], f32x16 (&X)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[t][r] = (ABL & 1) ? acc[t][r] * 0.5f : gamd_gelu_hw(acc[t][r]);
+}
+
 template <int NFEAT, int ABL>
 __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -91,10 +100,14 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         float F[24];
         F[0] = half ? ry / den : rx / den;
         F[1] = half ? d : rz / den;
+        if (!(ABL & 8) && a.rbf.uniform) {
+            gamd_rbf_chains(d, half, a.gamma * -1.4426950408889634f, a.rbf, F);
+        } else {
 #pragma unroll
-        for (int s = 2; s < 22; ++s) {
-            const float radial = d - cen[2 * (s - 2) + half];           // :261-263
-            F[s] = (ABL & 8) ? radial : __builtin_amdgcn_exp2f((a.gamma * -1.4426950408889634f) * (radial * radial));
+            for (int s = 2; s < 22; ++s) {
+                const float radial = d - cen[2 * (s - 2) + half];           // :261-263
+                F[s] = (ABL & 8) ? radial : __builtin_amdgcn_exp2f((a.gamma * -1.4426950408889634f) * (radial * radial));
+            }
         }
         F[22] = 0.f; F[23] = 0.f;
         if (NFEAT == 45) {
@@ -126,17 +139,11 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
                     if (4 * g + j < KSTEPS) acc[tp] = mfma32(w[j], F[4 * g + j], acc[tp]);
             }
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) X[t][r] = (ABL & 1) ? acc[t][r] * 0.5f : gamd_gelu_hw(acc[t][r]);
+        gelu_block<ABL>(acc, X);
         // ---- GEMM 2 ----
         load_bias_chain(vb2, half, acc);
         gemm128<false>((const f32x4*)w2, lane, X, acc);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) X[t][r] = (ABL & 1) ? acc[t][r] * 0.5f : gamd_gelu_hw(acc[t][r]);
+        gelu_block<ABL>(acc, X);
         // ---- GEMM 3 + LayerNorm ----
         load_bias_chain(vb3, half, acc);
         gemm128<false>((const f32x4*)w3, lane, X, acc);

@@ -106,6 +106,7 @@ struct gamd_handle {
     const float *node_emb = nullptr, *nenc_w = nullptr, *nenc_b = nullptr;
     const float *dec_w1p = nullptr, *dec_b1 = nullptr, *dec_w2 = nullptr, *dec_b2 = nullptr;
     float length_mean = 0.f, length_std = 1.f;
+    RbfGrid rbf{};                               // set when edge_expand.centers is a uniform grid
 
     // per-atom buffers
     DevBuf pos_w, pos_s, cell_of, perm, inv_perm, deg, row_ptr, na_excl, bond_nbr;
@@ -399,6 +400,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.n_feat = h->n_feat;
     ea.n_ksteps = (h->n_feat + 1) / 2;
     ea.centers = h->centers;
+    ea.rbf = h->rbf;
     ea.w1p = h->enc_w1p; ea.w2p = h->enc_w2p; ea.w3p = h->enc_w3p;
     ea.b1 = h->enc_b1; ea.b2 = h->enc_b2; ea.b3 = h->enc_b3;
     ea.ln_g = h->enc_lng; ea.ln_b = h->enc_lnb;
@@ -779,6 +781,20 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     }
     h->length_mean = lm->data[0];
     h->length_std = ls->data[0];
+    h->rbf = RbfGrid{};
+    if (expand) {
+        // RBFExpansion builds linspace(low, high, n) (nn_module.py:237-239): uniform up to fp32 rounding.  Anything else
+        // (hand-edited centres) keeps the exact per-centre form.
+        const double c0 = cen->data[0], delta = ((double)cen->data[39] - c0) / 39.0;
+        bool uniform = delta > 0.0;
+        for (int k = 0; k < 40 && uniform; ++k)
+            uniform = std::fabs((double)cen->data[k] - (c0 + k * delta)) <= 2.5e-7 * std::max(1.0, std::fabs(c0 + k * delta));
+        if (uniform) {
+            const double gexp = -(1.0 / 0.025) * 1.4426950408889634, s = 2.0 * delta;     // -gamma log2(e), chain step
+            h->rbf = RbfGrid{1, (float)c0, (float)delta, (float)(-2.0 * gexp * s), (float)(gexp * s * s),
+                             (float)std::exp2(2.0 * gexp * s * s)};
+        }
+    }
 
     if (h->wblob.ensure(sizeof(float) * bb.host.size(), false)) return fail(-12, "weight blob allocation failed");
     HIP_TRY(hipMemcpy(h->wblob.p, bb.host.data(), sizeof(float) * bb.host.size(), hipMemcpyHostToDevice));

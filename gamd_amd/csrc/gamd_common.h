@@ -76,18 +76,60 @@ __device__ __forceinline__ float gamd_silu_hw(float x) {    // v_exp_f32 + v_rcp
     const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
-// exact-erf GELU with erf from Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. ~2 ulp of the 1+erf
-// factor): one v_rcp, one v_exp, 5 FMAs; branch-free.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// GELU(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|), with the normal tail as ONE exponential of a polynomial:
+//     Phi(-a) = 2^Q(a),  Q = degree-6 least-squares fit of log2 Phi(-a) on [0, 6] weighted by a Phi(-a) (the factor the
+// error is multiplied by in the result).  |fit error| <= 1.1e-7 in |x| Phi(-|x|); evaluated in fp32 the result is within
+// 0.95 (half-ulp + 1.2e-7) of the exact erf-GELU (nn.GELU(), nn_module.py:41-42) on [-8, 8] — closer than the Abramowitz &
+// Stegun 7.1.26 erfc form used in round 1 (1.8) — with 10 VALU instructions (one v_exp_f32) instead of 17 (v_exp_f32 +
+// v_rcp_f32): measured 465 -> 432 us on k_edge_encode at C2 (tools/enc_variants.py; a packed v_pk_fma_f32 Horner chain
+// was slower than the scalar one).  Beyond |x| = 6 the tail is below 1e-9: the argument is
+// clamped there (one v_min with the |.| source modifier), which also keeps the fit's positive leading coefficient harmless.
+#define GAMD_GELU_Q0 -9.999880791e-01f
+#define GAMD_GELU_Q1 -1.151242852e+00f
+#define GAMD_GELU_Q2 -4.586574435e-01f
+#define GAMD_GELU_Q3 -5.355345458e-02f
+#define GAMD_GELU_Q4 8.167289197e-03f
+#define GAMD_GELU_Q5 -7.945232792e-04f
+#define GAMD_GELU_Q6 3.589583139e-05f
 __device__ __forceinline__ float gamd_gelu_hw(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float q = p * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);   // = 1 - erf(z) = erfc(z)
-    // 0.5 x (1 + erf(x/sqrt2)):  x >= 0: 0.5 x (2 - q);  x < 0: 0.5 x q
-    return 0.5f * x * (x >= 0.f ? 2.0f - q : q);
+    // v_med3_f32 instead of fminf / fmaxf: those canonicalise their operands first (one extra v_max each)
+    const float a = __builtin_amdgcn_fmed3f(fabsf(x), 0.0f, 6.0f);
+    float q = fmaf(GAMD_GELU_Q6, a, GAMD_GELU_Q5);
+    q = fmaf(q, a, GAMD_GELU_Q4);
+    q = fmaf(q, a, GAMD_GELU_Q3);
+    q = fmaf(q, a, GAMD_GELU_Q2);
+    q = fmaf(q, a, GAMD_GELU_Q1);
+    q = fmaf(q, a, GAMD_GELU_Q0);
+    return fmaf(-a, __builtin_amdgcn_exp2f(q), __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f));
+}
+// RBF expansion exp(-gamma (d - mu_k)^2) of the standardised length on a UNIFORM grid of centres mu_k = c0 + k delta
+// (nn_module.py:237-240: linspace(0, 1, 40), gamma = 40).  A lane holds every other centre (k = 2 j + half); along such a
+// chain, with u = d - mu and step s = 2 delta,
+//     g(u - s) = g(u) rho(u),   rho(u) = 2^(A u + B),   rho(u - s) = rho(u) C,
+//     A = -2 gexp s,  B = gexp s^2,  C = 2^(2 gexp s^2)     (gexp = -gamma log2 e)
+// so four chains of five centres cost 8 v_exp_f32 + 28 multiplies instead of 20 v_exp_f32 + 60 other instructions.  A chain is
+// restarted every five centres to keep the accumulated rounding below 5e-7 relative.  Underflow of a chain's first value
+// loses only values below 1e-27.  The host checks that the state_dict's centres are uniform (gamd_finalize_weights) and
+// falls back to the table otherwise.
+struct RbfGrid { int uniform; float c0, delta, A, B, C; };
+__device__ __forceinline__ void gamd_rbf_chains(float d, int half, float gexp, const RbfGrid& g, float (&F)[24]) {
+    const float s = 2.0f * g.delta;
+    const float dh = d - (g.c0 + (half ? g.delta : 0.0f));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float u0 = dh - (float)(5 * c) * s;
+        float v = __builtin_amdgcn_exp2f(gexp * (u0 * u0));
+        float rho = __builtin_amdgcn_exp2f(fmaf(g.A, u0, g.B));
+        F[2 + 5 * c] = v;
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+            v *= rho;
+            F[2 + 5 * c + j] = v;
+            if (j < 4) rho *= g.C;
+        }
+    }
 }
 
 // torch.remainder for floats (result takes the sign of the divisor)

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gamd_common.h"
 
 enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD = 4, CNT_NCAND = 5, CNT_COUNT = 8 };
 // host-mapped, never cleared by the per-call memset: overflow must survive later steps of an enqueued MD run
@@ -84,6 +85,7 @@ struct EncArgs {
     int n_feat;                // 44 or 45
     int n_ksteps;              // ceil(n_feat/2)
     const float* centers;      // [40]
+    RbfGrid rbf;               // uniform centres: recurrence along the grid instead of one exponential per centre
     const float* w1p;          // packed [4][6][64][4]  (K padded to 48)
     const float* w2p;          // packed 128x128
     const float* w3p;          // packed 128x128

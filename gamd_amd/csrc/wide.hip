@@ -87,7 +87,9 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
         for (int s = 0; s < 24; ++s) F[s] = 0.f;
         F[0] = half ? ry / den : rx / den;
         F[1] = half ? d : rz / den;
-        if (EXPAND) {
+        if (EXPAND && a.rbf.uniform) {
+            gamd_rbf_chains(d, half, a.gamma * -1.4426950408889634f, a.rbf, F);
+        } else if (EXPAND) {
 #pragma unroll
             for (int s = 2; s < 22; ++s) {
                 const float radial = d - cen[2 * (s - 2) + half];

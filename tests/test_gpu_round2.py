@@ -426,6 +426,30 @@ def test_predict_forces_verbose_prints_the_two_reference_buckets(capsys):
     assert rel_err(loud, quiet) < 1e-6 and rel_err(loud, g["forces"]) < TOL
 
 
+def test_non_uniform_rbf_centres_keep_the_exact_form():
+    """The encoder evaluates the 40 RBFs by recurrence along the uniform grid linspace(0, 1, 40) (nn_module.py:237-240).
+    `edge_expand.centers` is in the state_dict: if someone hands over other centres the kernel must fall back to one
+    exponential per centre.  Both paths against the oracle, stage by stage."""
+    g, cfg, sd = load_golden("lj258_seed0")
+    box, rc = float(g["box"]), float(g["cutoff"])
+    posw = torch.from_numpy(np.mod(g["pos"], box)).float()
+    for tag in ("uniform", "warped"):
+        sd2 = dict(sd)
+        if tag == "warped":
+            c = sd["edge_expand.centers"].clone()
+            sd2["edge_expand.centers"] = (c + 0.01 * torch.sin(7.0 * c)).float()
+        for ks in (0, 1):
+            eng = _engine(sd2, 258, box, rc, keep_stages=True, kernel_select=ks)
+            out = eng.forward(posw).cpu().numpy()
+            edges = torch.from_numpy(eng.debug_edges()).long()
+            st = {}
+            ref = orc.forward(sd2, posw, edges, box, stages=st).numpy()
+            assert rel_err(eng.debug_feat(44), st["feat"].numpy()) < TOL, (tag, ks)
+            assert rel_err(eng.debug_e(), st["e"].numpy()) < TOL, (tag, ks)
+            assert rel_err(out, ref) < TOL, (tag, ks)
+            eng.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE config 5, the other reading: 8 000 NETWORK atoms (SURVEY section 8 flags the ambiguity)
 # ---------------------------------------------------------------------------------------------------------------

@@ -171,3 +171,26 @@ def test_self_loop_mode_names_agree_between_oracle_and_engine():
     import gamd_oracle as orc
     from gamd_amd.engine import SELF_LOOP
     assert tuple(SELF_LOOP) == orc.SELF_LOOP_MODES and SELF_LOOP["dgl07_noop"] == 0
+
+
+def test_gelu_tail_polynomial_in_the_kernel_header_is_accurate():
+    """gamd_common.h evaluates GELU(x) = max(x,0) - |x| 2^Q(|x|) with a degree-6 fit Q of log2 Phi(-a) on [0, 6].  Re-evaluate it
+    in fp32 with the coefficients as written in the header and compare with the exact erf-GELU of nn.GELU()
+    (nn_module.py:41-42): within half an ulp of the result plus 1.2e-7 everywhere on [-10, 10]."""
+    import re
+    from scipy.special import ndtr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "gamd_amd", "csrc", "gamd_common.h")).read()
+    q = [np.float32(re.search(rf"#define GAMD_GELU_Q{i} (\S+)f", src).group(1)) for i in range(7)]
+    f = np.float32
+    x = np.linspace(-10, 10, 2000001).astype(f)
+    a = np.minimum(np.abs(x), f(6.0))
+    p = np.full_like(a, q[6])
+    for c in q[5::-1]:
+        p = (p * a + c).astype(f)
+    out = (np.maximum(x, f(0)) - (a * np.exp2(p).astype(f)).astype(f)).astype(f)
+    exact = x.astype(np.float64) * ndtr(x.astype(np.float64))
+    err = np.abs(out.astype(np.float64) - exact)
+    ulp = np.spacing(np.abs(exact).astype(f)).astype(np.float64)
+    assert (err / (0.5 * ulp + 1.2e-7)).max() < 1.6 and err.max() < 7e-7
+    assert err[np.abs(x) < 2.5].max() < 3.5e-7
