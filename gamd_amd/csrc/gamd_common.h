@@ -82,7 +82,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //     Phi(-a) = 2^Q(a),  Q = degree-6 least-squares fit of log2 Phi(-a) on [0, 6] weighted by a Phi(-a) (the factor the
 // error is multiplied by in the result).  |fit error| <= 1.1e-7 in |x| Phi(-|x|); evaluated in fp32 the result is within
 // 0.95 (half-ulp + 1.2e-7) of the exact erf-GELU (nn.GELU(), nn_module.py:41-42) on [-8, 8] — closer than the Abramowitz &
-// Stegun 7.1.26 erfc form used in round 1 (1.8) — with 10 VALU instructions (one v_exp_f32) instead of 17 (v_exp_f32 +
+// Stegun 7.1.26 erfc form used in round 1 (1.8) — with 11 VALU instructions (one v_exp_f32) instead of 17 (v_exp_f32 +
 // v_rcp_f32): measured 465 -> 432 us on k_edge_encode at C2 (tools/enc_variants.py; a packed v_pk_fma_f32 Horner chain
 // was slower than the scalar one).  Beyond |x| = 6 the tail is below 1e-9: the argument is
 // clamped there (one v_min with the |.| source modifier), which also keeps the fit's positive leading coefficient harmless.
@@ -102,7 +102,10 @@ __device__ __forceinline__ float gamd_gelu_hw(float x) {
     q = fmaf(q, a, GAMD_GELU_Q2);
     q = fmaf(q, a, GAMD_GELU_Q1);
     q = fmaf(q, a, GAMD_GELU_Q0);
-    return fmaf(-a, __builtin_amdgcn_exp2f(q), __builtin_amdgcn_fmed3f(x, 0.0f, 3.0e38f));
+    // max(x, 0) as x - clamp(x, -big, 0): exact for finite x, and unlike v_max / v_med3 (which return the non-NaN operand)
+    // it lets a NaN input through, so non-finite positions or weights still surface in the forces (STICKY_NONFINITE)
+    const float relu = x - __builtin_amdgcn_fmed3f(x, -3.0e38f, 0.0f);
+    return fmaf(-a, __builtin_amdgcn_exp2f(q), relu);
 }
 // RBF expansion exp(-gamma (d - mu_k)^2) of the standardised length on a UNIFORM grid of centres mu_k = c0 + k delta
 // (nn_module.py:237-240: linspace(0, 1, 40), gamma = 40).  A lane holds every other centre (k = 2 j + half); along such a
