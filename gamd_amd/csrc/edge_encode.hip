@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         // ---- GEMM 3 + LayerNorm ----
         load_bias_chain(vb3, half, acc);
         gemm128<false>((const f32x4*)w3, lane, X, acc);
-        if (!(ABL & 2)) layernorm_chain(acc, vg, vbeta, half, 1e-5f);
+        if (!(ABL & 2)) layernorm_chain_centered(acc, vg, vbeta, half, 1e-5f);     // W3, b3 arrive centred
         if (a.self_loop) {
             // self_loop_mode 1: the last edge of every row is the loop an in-place add_self_loop would have appended AFTER
             // edata['e'] was set (nn_module.py:649-652): its embedding is DGL's zero fill, not an encoded feature row

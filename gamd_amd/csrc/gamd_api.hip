@@ -765,8 +765,25 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     else if (f16x3_edges) pack_enc1_f16x3(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
     else pack_enc1(e0w->data.data(), F, bb.host.data() + o_e1);
     const size_t o_e2 = bf16_edges ? put_edge_bf16(e2w) : f16x3_edges ? put_edge_f16x3(e2w) : put_blocks(e2w, 1, 1);
-    const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : f16x3_edges ? put_edge_f16x3(e4w) : put_blocks(e4w, (int)EHT, 1);
-    const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(e4b), o_elg = put_vec(elg), o_elb = put_vec(elb);
+    // fp32 path: the last encoder Linear is stored with its OUTPUT rows centred, W' = W - mean over rows, b' = b - mean(b)
+    // (in double): y' = W' x + b' = y - mean(y) exactly in real arithmetic, so edge_layer_norm's mean subtraction
+    // (nn_module.py:646) is done here once instead of per edge; the kernels only normalise the variance
+    // (layernorm_chain_centered; wide.hip's generic LayerNorm sees a mean of ~0 and is unaffected).
+    HostTensor e4w_c = *e4w, e4b_c = *e4b;
+    if (!bf16_edges && !f16x3_edges) {
+        for (int64_t k = 0; k < 128; ++k) {
+            double m = 0.0;
+            for (int64_t o = 0; o < Eh; ++o) m += (double)e4w->data[(size_t)(o * 128 + k)];
+            m /= (double)Eh;
+            for (int64_t o = 0; o < Eh; ++o) e4w_c.data[(size_t)(o * 128 + k)] = (float)((double)e4w->data[(size_t)(o * 128 + k)] - m);
+        }
+        double mb = 0.0;
+        for (int64_t o = 0; o < Eh; ++o) mb += (double)e4b->data[(size_t)o];
+        mb /= (double)Eh;
+        for (int64_t o = 0; o < Eh; ++o) e4b_c.data[(size_t)o] = (float)((double)e4b->data[(size_t)o] - mb);
+    }
+    const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : f16x3_edges ? put_edge_f16x3(e4w) : put_blocks(&e4w_c, (int)EHT, 1);
+    const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(&e4b_c), o_elg = put_vec(elg), o_elb = put_vec(elb);
     const size_t o_cen = expand ? put_vec(cen) : bb.add(64);
     const size_t o_d1 = put_blocks(d0w, 1, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
     size_t o_emb = 0, o_nw = 0, o_nb = 0;

@@ -310,6 +310,29 @@ __device__ __forceinline__ void exchange(float* xbuf, int quarter, int slot, int
     load_row_chain(xbuf + slot * GAMD_XLD, half, X);
 }
 
+// The same for rows whose mean over the 128 features is zero BY CONSTRUCTION: the edge encoder's last Linear is packed
+// with its output rows centred (W - mean_rows(W), b - mean(b): gamd_finalize_weights), which is LayerNorm's mean
+// subtraction done once on the host instead of per edge (64 adds + 64 subtracts + a shuffle per 32 x 128 block).
+template <typename GPtr>
+__device__ __forceinline__ void layernorm_chain_centered(f32x16 (&X)[4], GPtr gamma, GPtr beta, int half, float eps) {
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v = fmaf(X[t][r], X[t][r], v);
+    const float var = gamd_xhalf_sum(v) * (1.0f / 128.0f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(&gamma[32 * t + 8 * q + 4 * half]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&beta[32 * t + 8 * q + 4 * half]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = fmaf(X[t][q * 4 + j] * rstd, g[j], b[j]);
+        }
+}
+
 // XCD-aware persistent work split: workgroup b is observed to run on XCD b % 8 (speed only, never
 // correctness).  Give each XCD one contiguous eighth of the tile range so that its private L2 sees a
 // compact slice of the node tables.  Returns the first tile and the stride via out params; caller
