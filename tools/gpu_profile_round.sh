@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round profile on the GPU box: bench lines, rocprofv3 kernel traces and PMC passes (each --pmc pass on its own, with
+# --kernel-trace only), summaries written under gpurun_out/$1/.  Usage (through gpurun): bash tools/gpu_profile_round.sh r02
+set -u
+tag=${1:-r02}
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
+B="python3 bench.py --no-cpu-baseline --no-secondary"
+python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
+python3 bench.py --no-cpu-baseline --no-secondary --edge-dtype f16x3 > $out/bench_f16x3.json 2>> $out/bench_default.err
+for w in c2 c3 c5 c5b c1 dft; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -- $B --steps 50 --warmup 5 --workload $w > $out/trace_$w.log 2>&1
+  python3 tools/profile_summary.py stats $out/trace_$w > $out/trace_$w.md
+done
+for w in c2 c5; do
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq_$w -- $B --steps 5 --warmup 2 --workload $w > $out/pmc_sq_$w.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch_$w -- $B --steps 5 --warmup 2 --workload $w > $out/pmc_fetch_$w.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write_$w -- $B --steps 5 --warmup 2 --workload $w > $out/pmc_write_$w.log 2>&1
+  python3 tools/profile_summary.py pmc $out/pmc_sq_$w $out/pmc_fetch_$w $out/pmc_write_$w > $out/pmc_$w.md
+done
+python3 tools/profile_summary.py pmcjson $out/pmc_fetch_c2 $out/pmc_write_c2 k_conv_edge $out/pmc_conv_edge.json > /dev/null
+# keep the merge-back small: only the summaries and the per-kernel stats csv
+find $out -name "*_kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*agent_info.csv" -delete
+ls -la $out | head -50
