@@ -118,6 +118,9 @@ struct gamd_handle {
     long long e_cap = 0;
     DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg;
     DevBuf counters, tdbg, tmp_eid, ke_partial;
+    DevBuf cnt2;                    // small systems in skin mode: two counter blocks used alternately (no per-call memset)
+    int cnt_parity = 0;
+    int* cur_counters = nullptr;    // the counter block of the call being enqueued
     int* counters_host = nullptr;   // pinned
     int* sticky_host = nullptr;     // pinned + mapped: overflow flags and rebuild count, written by kernels directly
     int* sticky_dev = nullptr;
@@ -227,7 +230,7 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
     a.erow = h->erow.as<int>();
     a.chunk_piece = h->chunk_piece.as<int>();
     a.chunk_mask = h->chunk_mask.as<unsigned>();
-    a.counters = h->counters.as<int>();
+    a.counters = h->cur_counters ? h->cur_counters : h->counters.as<int>();
     a.sticky = h->sticky_dev;
     if (h->skin > 0.f) {
         a.skin_half2 = 0.25f * h->skin * h->skin;
@@ -371,7 +374,18 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     };
     int r;
     mark("begin");
+    // small systems with Verlet-skin reuse: ping-pong counter blocks, 4 neighbour launches per call (neighbor.hip)
+    const bool small_skin = !el && h->skin > 0.f && h->n <= 1024;
+    int* counters_next = nullptr;
+    if (small_skin) {
+        h->cnt_parity ^= 1;
+        h->cur_counters = h->cnt2.as<int>() + h->cnt_parity * CNT_COUNT;
+        counters_next = h->cnt2.as<int>() + (1 - h->cnt_parity) * CNT_COUNT;
+    } else {
+        h->cur_counters = h->counters.as<int>();
+    }
     NbrArgs na = nbr_args(h, pos_dev, species_dev);
+    na.counters_next = counters_next;
     if (el) {
         if ((r = launch_csr_from_edges(na, el->centre, el->neigh, el->n, h->tmp_eid.as<int>(), st)))
             return fail(-1, "edge-list CSR launch failed (%d)", r);
@@ -385,7 +399,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     mark("neighbor_build");
 
     EncArgs ea{};
-    ea.counters = h->counters.as<int>();
+    ea.counters = h->cur_counters;
     ea.pos_s = h->pos_s.as<float4>();
     ea.col = h->col.as<int>();
     ea.erow = h->erow.as<int>();
@@ -418,7 +432,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     auto hptr = [&](int l) { return h->hbuf.as<float>() + (h->cfg.keep_stages ? (size_t)l * nh : (size_t)(l & 1) * nh); };
 
     NodeArgs no{};
-    no.counters = h->counters.as<int>();
+    no.counters = h->cur_counters;
     no.devflags = h->devflags.as<int>();
     no.sticky = h->sticky_dev;
     no.n = h->n;
@@ -455,7 +469,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
 
     for (int l = 0; l < h->L; ++l) {
         ConvEdgeArgs ca{};
-        ca.counters = h->counters.as<int>();
+        ca.counters = h->cur_counters;
         ca.col = h->col.as<int>(); ca.erow = h->erow.as<int>();
         ca.chunk_piece = h->chunk_piece.as<int>(); ca.chunk_mask = h->chunk_mask.as<unsigned>();
         ca.e_frag = h->e_frag.as<float>();
@@ -489,7 +503,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         if ((r = node(no))) return fail(-1, "node launch failed (%d)", r);
         mark(no.mode == 2 ? "node_last_decode" : "node_mid");
     }
-    HIP_TRY(hipMemcpyAsync(h->counters_host, h->counters.p, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->counters_host, h->cur_counters, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -617,6 +631,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->f_den.ensure(sizeof(float) * 3 * n, true);
     r |= h->tdbg.ensure(sizeof(long long) * 16 * 8 * 1024, true);
     r |= h->devflags.ensure(sizeof(int) * DEVFLAG_COUNT, true);
+    r |= h->cnt2.ensure(sizeof(int) * 2 * CNT_COUNT, true);
     if (r) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
     if ((r = clear_devflags(h))) { gamd_destroy(h); return r; }
     if (hipHostMalloc((void**)&h->counters_host, sizeof(int) * CNT_COUNT) != hipSuccess) {
@@ -654,6 +669,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     if (!h) return 0;
     DeviceGuard guard(h->dev);
     h->devflags.release();
+    h->cnt2.release();
     DevBuf* bufs[] = {&h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
@@ -891,6 +907,7 @@ int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t
     hipStream_t st = (hipStream_t)stream;
     for (int attempt = 0; attempt < 4; ++attempt) {
         if ((r = set_box(h, box))) return r;
+        h->cur_counters = h->counters.as<int>();
         NbrArgs na = nbr_args(h, pos_dev, species_dev);
         h->cand_valid = false;                                    // the exact build below reorders the atoms
         if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);

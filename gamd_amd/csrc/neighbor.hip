@@ -29,10 +29,7 @@ __device__ __forceinline__ float node_feature(const NbrArgs& a, int v) {
     return a.feat ? a.feat[v] : (a.species ? (float)a.species[v] : 0.f);
 }
 
-__global__ void k_bin(NbrArgs a) {
-    GAMD_GATE();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+__device__ __forceinline__ void d_bin(const NbrArgs& a, int i) {
     float4 p;
     p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);    // graph_utils.py:31 jnp.mod(pos, box)
     p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
@@ -44,6 +41,12 @@ __global__ void k_bin(NbrArgs a) {
                   cell_coord(p.z, a.box[2], a.nc[2]);
     a.cell_of[i] = c;
     atomicAdd(&a.cell_cnt[c], 1);
+}
+
+__global__ void k_bin(NbrArgs a) {
+    GAMD_GATE();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) d_bin(a, i);
 }
 
 // single-block exclusive scan, any length; out has n+1 entries (out[n] = total).  4 items per thread
@@ -90,23 +93,22 @@ __global__ void __launch_bounds__(1024) k_scan_cells(NbrArgs a) {
     block_exclusive_scan(a.ncell, [&](int i) { return a.cell_cnt[i]; }, a.cell_start);
 }
 
-__global__ void k_fill_cells(NbrArgs a) {
-    GAMD_GATE();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+__device__ __forceinline__ void d_fill_cells(const NbrArgs& a, int i) {
     const int c = a.cell_of[i];
     const int s = atomicAdd(&a.cell_fill[c], 1);
     a.perm[a.cell_start[c] + s] = i;
 }
 
+__global__ void k_fill_cells(NbrArgs a) {
+    GAMD_GATE();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) d_fill_cells(a, i);
+}
+
 // atomics above give an arbitrary order inside a cell; sort by original atom id so that the CSR
 // (and with it every floating-point summation order downstream) is bit-reproducible run to run.
 // One wave per cell: rank by counting (cells hold ~14 atoms), then gather the sorted positions.
-__global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
-    GAMD_GATE();
-    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (c >= a.ncell) return;
+__device__ __forceinline__ void d_sort_gather(const NbrArgs& a, int c, int lane) {
     const int s = a.cell_start[c], e = a.cell_start[c + 1], cnt = e - s;
     if (cnt <= 64) {
         const int v = lane < cnt ? a.perm[s + lane] : 0x7fffffff;
@@ -139,6 +141,12 @@ __global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
             a.inv_perm[v] = i;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
+    GAMD_GATE();
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (c < a.ncell) d_sort_gather(a, c, threadIdx.x & 63);
 }
 
 // 27-cell sweep shared by the count and the fill pass: one half-wave (32 lanes) per centre atom, lanes
@@ -189,10 +197,8 @@ __device__ __forceinline__ unsigned half_ballot(bool p) {
     return (unsigned)(m >> (threadIdx.x & 32));
 }
 
-__global__ void __launch_bounds__(256) k_count(NbrArgs a) {
-    GAMD_GATE();
-    const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int l = threadIdx.x & 31;
+// one half-wave per centre atom `ctr` (both halves of a wave must call this together, live or not)
+__device__ __forceinline__ void d_count(const NbrArgs& a, int ctr, int l) {
     const bool live = ctr < a.n;
     int cnt = 0;
     // both halves of a wave must run the same number of ballots: sweep a clamped atom, discard below
@@ -200,10 +206,14 @@ __global__ void __launch_bounds__(256) k_count(NbrArgs a) {
     if (live && l == 0) a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
 }
 
+__global__ void __launch_bounds__(256) k_count(NbrArgs a) {
+    GAMD_GATE();
+    d_count(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31);
+}
+
 // row_ptr = exscan(deg); NA = inclusive count of non-empty segments that start off a chunk boundary;
 // publishes E, the piece count and the overflow flag.
-__global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
-    GAMD_GATE();
+__device__ void d_scan_deg(const NbrArgs& a) {
     block_exclusive_scan(a.n, [&](int i) { return a.deg[i]; }, a.row_ptr);
     __syncthreads();
     if (a.cand_pass) {                                     // candidate CSR: only its size and overflow matter
@@ -230,10 +240,12 @@ __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
+__global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
     GAMD_GATE();
-    const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int l = threadIdx.x & 31;
+    d_scan_deg(a);
+}
+
+__device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l) {
     const bool live = ctr < a.n;
     const int c = live ? ctr : a.n - 1;
     long long w = a.row_ptr[c];
@@ -247,6 +259,35 @@ __global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
     });
     // self_loop_mode 1: the loop DGL's in-place add_self_loop would append (nn_module.py:650-652), last in the row
     if (a.self_loop && live && l == 0 && w < a.e_cap) { a.col[w] = c; if (a.erow) a.erow[w] = c; }
+}
+
+__global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
+    GAMD_GATE();
+    d_fill(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31);
+}
+
+// ---- small systems (n <= 1024), Verlet-skin mode: the whole gated candidate rebuild in ONE workgroup -----------------
+// The reference's own drivers run 258 / 774 atoms, where a step is bound by the ~4 us every kernel costs in the stream.
+// The rebuild runs once in 50-100 steps, so its seven gated launches (which return immediately otherwise) are merged
+// into one launch of a single 1024-thread workgroup; between the phases a workgroup barrier replaces the kernel boundary.
+__global__ void __launch_bounds__(1024) k_rebuild_small(NbrArgs a) {
+    GAMD_GATE();
+    const int tid = threadIdx.x;
+    for (int c = tid; c < a.ncell; c += 1024) { a.cell_cnt[c] = 0; a.cell_fill[c] = 0; }
+    __syncthreads();
+    if (tid < a.n) d_bin(a, tid);
+    __syncthreads();
+    block_exclusive_scan(a.ncell, [&](int i) { return a.cell_cnt[i]; }, a.cell_start);
+    __syncthreads();
+    if (tid < a.n) d_fill_cells(a, tid);
+    __syncthreads();
+    for (int c = tid >> 6; c < a.ncell; c += 16) d_sort_gather(a, c, tid & 63);
+    __syncthreads();
+    for (int base = 0; base < a.n; base += 32) d_count(a, base + (tid >> 5), tid & 31);
+    __syncthreads();
+    d_scan_deg(a);
+    __syncthreads();
+    for (int base = 0; base < a.n; base += 32) d_fill(a, base + (tid >> 5), tid & 31);
 }
 
 // per 16-edge chunk: first piece id and the bit mask of edges that close a destination segment
@@ -298,30 +339,22 @@ __global__ void k_skin_check(NbrArgs a) {
         moved = !(((dx * dx + dy * dy) + dz * dz) <= a.skin_half2);      // NaN positions force a rebuild too
     }
     if (moved) a.counters[CNT_REBUILD] = 1;
-}
-
-// current positions in the (frozen) sorted order
-__global__ void k_regather(NbrArgs a) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= a.n) return;
-    const int v = a.perm[s];
-    float4 p = a.pos_w[v];
-    p.w = node_feature(a, v);
-    a.pos_s[s] = p;
+    // current position in the (so far frozen) sorted order; a rebuild later in this call overwrites pos_s and the order
+    p.w = node_feature(a, i);
+    a.pos_s[a.inv_perm[i]] = p;
+    if (a.counters_next && i < CNT_COUNT) a.counters_next[i] = 0;
 }
 
 // exact cutoff on the candidate rows: one half-wave per centre atom, candidates keep their order
-template <bool FILL>
-__global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
-    const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int l = threadIdx.x & 31;
+template <bool FILL, typename RowPtr>
+__device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPtr row_ptr) {
     const bool live = ctr < a.n;
     const int c = live ? ctr : a.n - 1;
     const float4 pc = a.pos_s[c];
     long long s = a.cand_ptr[c], e = a.cand_ptr[c + 1];
     if (e > a.cand_cap) e = a.cand_cap;
     if (s > e) s = e;
-    long long w = FILL ? (long long)a.row_ptr[c] : 0;
+    long long w = FILL ? (long long)row_ptr[c] : 0;
     int cnt = 0;
     for (long long b0 = s; b0 < e; b0 += 32) {
         bool ok = false;
@@ -349,6 +382,93 @@ __global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
     }
     if (FILL && a.self_loop && live && l == 0 && w < a.e_cap) { a.col[w] = c; a.erow[w] = c; }
     if (!FILL && live && l == 0) a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
+    d_filter<FILL>(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31, a.row_ptr);
+}
+
+// Small systems (n <= 1024): exact-filter fill, the scan of the degrees and the chunk metadata in ONE launch.  Every
+// workgroup scans deg[] (and the off-boundary segment starts) itself into LDS, 4 atoms per thread, instead of waiting for
+// a separate single-workgroup scan kernel; it then fills its rows, and the chunk metadata is derived from the row
+// pointers alone (an edge closes a segment iff it is the last of its row), so it does not have to wait for other
+// workgroups' erow stores either.  Workgroup 0 publishes row_ptr / na_excl / the counters for the later kernels.
+__global__ void __launch_bounds__(256) k_filter_fill_small(NbrArgs a) {
+    __shared__ int s_rp[1025];
+    __shared__ int s_na[1025];
+    __shared__ int s_wave[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int v[4], f[4];
+    const int i0 = tid * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < a.n) ? a.deg[i0 + k] : 0;
+    int x = (v[0] + v[1]) + (v[2] + v[3]);
+    const int mine = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) s_wave[0][wv] = x;
+    __syncthreads();
+    int run = x - mine;
+    for (int w = 0; w < wv; ++w) run += s_wave[0][w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k <= a.n) s_rp[i0 + k] = run;
+        f[k] = (i0 + k < a.n && v[k] > 0 && (run % GAMD_CHUNK) != 0) ? 1 : 0;
+        run += v[k];
+    }
+    if (tid == 255 && a.n == 1024) s_rp[1024] = run;
+    int y2 = (f[0] + f[1]) + (f[2] + f[3]);
+    const int mine2 = y2;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(y2, d, 64); if (lane >= d) y2 += y; }
+    if (lane == 63) s_wave[1][wv] = y2;
+    __syncthreads();
+    int run2 = y2 - mine2;
+    for (int w = 0; w < wv; ++w) run2 += s_wave[1][w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + k <= a.n) s_na[i0 + k] = run2;
+        run2 += f[k];
+    }
+    if (tid == 255 && a.n == 1024) s_na[1024] = run2;
+    __syncthreads();
+    const int E_all = s_rp[a.n];
+    long long E = E_all;
+    if (E > a.e_cap) E = a.e_cap;
+    if (blockIdx.x == 0) {
+        for (int i = tid; i <= a.n; i += 256) { a.row_ptr[i] = s_rp[i]; a.na_excl[i] = s_na[i]; }
+        if (tid == 0) {
+            a.counters[CNT_E] = E_all;
+            a.counters[CNT_PIECES] = (E_all + GAMD_CHUNK - 1) / GAMD_CHUNK + s_na[a.n];
+            if ((long long)E_all > a.e_cap) {
+                a.counters[CNT_OVERFLOW] = 1; a.sticky[STICKY_EDGE_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1;
+            }
+            a.counters[CNT_TILES] = (E_all + GAMD_TILE - 1) / GAMD_TILE;
+        }
+    }
+    // rows of this workgroup: one half-wave per atom
+    d_filter<true>(a, (blockIdx.x * 256 + tid) >> 5, tid & 31, s_rp);
+    // chunk metadata, chunks strided over the whole grid; every chunk of every (partly) valid 32-edge tile is written
+    const int n_chunks = 2 * (int)((E + GAMD_TILE - 1) / GAMD_TILE);
+    for (int c = blockIdx.x * 256 + tid; c < n_chunks; c += gridDim.x * 256) {
+        const long long x0 = (long long)c * GAMD_CHUNK;
+        if (x0 >= E) { a.chunk_piece[c] = 0; a.chunk_mask[c] = 0; continue; }
+        int lo = 0, hi = a.n - 1;                         // last row with row_ptr <= x0 that is not empty up to x0: owner of edge x0
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_rp[mid] <= x0) lo = mid; else hi = mid - 1; }
+        int at = lo;
+        while (s_rp[at + 1] <= x0) ++at;                  // skip empty rows that share the offset
+        const int na_incl = s_na[at] + ((s_rp[at + 1] > s_rp[at] && (s_rp[at] % GAMD_CHUNK) != 0) ? 1 : 0);
+        a.chunk_piece[c] = c + na_incl;
+        unsigned mask = 0;
+        for (int r = 0; r < GAMD_CHUNK; ++r) {
+            const long long xe = x0 + r;
+            if (xe >= E) break;
+            while (s_rp[at + 1] <= xe) ++at;
+            if (xe == (long long)s_rp[at + 1] - 1 || xe == E - 1) mask |= 1u << r;
+        }
+        a.chunk_mask[c] = mask;
+    }
 }
 
 // ---- CSR from an explicit edge list (model-level forward([pos],[edge_idx]), nn_module.py:636-653) ----
@@ -444,8 +564,25 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
 
 int launch_neighbor_skin(const NbrArgs& a, hipStream_t st) {
     hipError_t e;
-    e = hipMemsetAsync(a.counters, 0, sizeof(int) * (CNT_COUNT + 2 * (size_t)a.ncell_cap), st); if (e) return (int)e;
     const int tb = 256, gb = (a.n + tb - 1) / tb, ga = (a.n + 7) / 8;
+    if (a.counters_next) {
+        // small system (n <= 1024): 4 launches and no memset node instead of 13 + 1 (counters ping-pong, cleared by
+        // k_skin_check; cell arrays cleared inside the gated rebuild)
+        hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
+        NbrArgs c = a;
+        c.gate = a.counters + CNT_REBUILD;
+        c.cand_pass = 1;
+        c.rc = a.rc_build; c.rc2 = a.rc2_build;
+        c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
+        c.self_loop = 0;
+        hipLaunchKernelGGL(k_rebuild_small, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
+        NbrArgs x = a;
+        x.ref_pos = nullptr;
+        hipLaunchKernelGGL(k_filter<false>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_filter_fill_small, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
+        return 0;
+    }
+    e = hipMemsetAsync(a.counters, 0, sizeof(int) * (CNT_COUNT + 2 * (size_t)a.ncell_cap), st); if (e) return (int)e;
     hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
     // candidate rebuild with rc + skin, every kernel gated on the flag k_skin_check has just written
     NbrArgs c = a;
@@ -464,7 +601,6 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st) {
     // exact list of this step
     NbrArgs x = a;
     x.ref_pos = nullptr;
-    hipLaunchKernelGGL(k_regather, dim3(gb), dim3(tb), 0, st, x); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter<false>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, x); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter<true>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
