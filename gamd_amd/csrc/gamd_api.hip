@@ -368,7 +368,7 @@ int fill_rigid(const gamd_handle* h, int rigid_water, float mass_o, float mass_h
 
 int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, float* out_norm_dev,
                     float* out_denorm_dev, hipStream_t st, hipEvent_t* evs, int* n_ev, std::vector<std::string>* labels,
-                    const EdgeList* el = nullptr) {
+                    const EdgeList* el = nullptr, const MdFuse* fuse = nullptr, bool copy_counters = true) {
     auto mark = [&](const char* label) {
         if (evs) { (void)hipEventRecord(evs[*n_ev], st); ++*n_ev; labels->push_back(label); }
     };
@@ -393,7 +393,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     } else if (h->skin > 0.f) {
         na.ref_pos = h->ref_pos.as<float4>();
         na.force_rebuild = h->cand_valid ? 0 : 1;
-        if ((r = launch_neighbor_skin(na, st))) return fail(-1, "neighbor (skin) launch failed (%d)", r);
+        if (fuse && !small_skin) return fail(-1, "internal: integrator halves can only be fused into the small-system path");
+        if ((r = launch_neighbor_skin(na, st, fuse))) return fail(-1, "neighbor (skin) launch failed (%d)", r);
         h->cand_valid = true;
     } else if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);
     mark("neighbor_build");
@@ -503,7 +504,10 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         if ((r = node(no))) return fail(-1, "node launch failed (%d)", r);
         mark(no.mode == 2 ? "node_last_decode" : "node_mid");
     }
-    HIP_TRY(hipMemcpyAsync(h->counters_host, h->cur_counters, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
+    // inside an enqueued MD run only the last step's counters are fetched (an overflow in any step reaches the host
+    // through the mapped sticky flags): one copy node less per step
+    if (copy_counters)
+        HIP_TRY(hipMemcpyAsync(h->counters_host, h->cur_counters, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -545,18 +549,36 @@ int clear_devflags(gamd_handle* h) {
 int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
     MdPending& p = h->pending;
     int r;
+    // Small systems (n <= 1024) in skin mode, plain BAOAB: the B of step s-1 and the B A O A of step s ride in the first
+    // kernel of step s's force evaluation (k_step_small): 2 launches less per step; the last B is launched on its own.
+    if (p.kind == 0 && !p.m.use_rigid && h->skin > 0.f && h->n <= 1024) {
+        for (long long s = s_begin; s < p.n_steps; ++s) {
+            p.m.step = p.first_step + (unsigned long long)s;
+            p.m.step_index = (int)s;
+            const MdFuse fuse{&p.m, s > s_begin ? 1 : 0, (skip_first && s == s_begin) ? 0 : 1};
+            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, &fuse,
+                                     s + 1 == p.n_steps)))
+                return r;
+        }
+        if (p.n_steps > s_begin) {
+            p.m.step_index = (int)(p.n_steps - 1);
+            if ((r = launch_baoab_second(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
+        }
+        return 0;
+    }
     for (long long s = s_begin; s < p.n_steps; ++s) {
         const bool first = !(skip_first && s == s_begin);
+        const bool last = s + 1 == p.n_steps;
         if (p.kind == 0) {
             p.m.step = p.first_step + (unsigned long long)s;
             p.m.step_index = (int)s;
             if (first && (r = launch_baoab_first(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
-            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr))) return r;
+            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, nullptr, last))) return r;
             if ((r = launch_baoab_second(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
         } else {
             p.a.step_index = (int)s;
             if (first && (r = launch_nhc_first(p.a, p.st))) return fail(-1, "integrator launch failed (%d)", r);
-            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr))) return r;
+            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, nullptr, last))) return r;
             if ((r = launch_nhc_second(p.a, p.st))) return fail(-1, "integrator launch failed (%d)", r);
         }
     }

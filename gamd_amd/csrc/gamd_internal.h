@@ -65,8 +65,13 @@ struct NbrArgs {
     long long cand_cap;
     float rc_build, rc2_build;   // rc + skin
 };
+struct MdArgs;
+// Integrator work that the small-system skin path (n <= 1024, NbrArgs::counters_next set) folds into its first kernel:
+// the second half (B) of the previous step and / or the first half (B A O A) of this one (plain BAOAB, no constraints).
+struct MdFuse { const MdArgs* md; int do_second, do_first; };
 int launch_neighbor_build(const NbrArgs& a, hipStream_t st);
-int launch_neighbor_skin(const NbrArgs& a, hipStream_t st);     // skin mode: check, gated candidate rebuild, exact filter
+// skin mode: check, gated candidate rebuild, exact filter.  fuse != null (small-system path only): see MdFuse
+int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse = nullptr);
 // CSR from a caller-supplied directed edge list (centre[e], neigh[e]); atoms keep the caller's order.
 // tmp_eid: [n_edges] scratch.  Rows keep the caller's edge order (deterministic).
 int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh, long long n_edges, int* tmp_eid,

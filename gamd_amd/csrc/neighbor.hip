@@ -13,6 +13,7 @@
 // makes the h[src] gathers of a destination tile land in a compact slice of the node tables.
 #include "gamd_common.h"
 #include "gamd_internal.h"
+#include "gamd_md_dev.h"
 
 namespace {
 
@@ -266,30 +267,6 @@ __global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
     d_fill(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31);
 }
 
-// ---- small systems (n <= 1024), Verlet-skin mode: the whole gated candidate rebuild in ONE workgroup -----------------
-// The reference's own drivers run 258 / 774 atoms, where a step is bound by the ~4 us every kernel costs in the stream.
-// The rebuild runs once in 50-100 steps, so its seven gated launches (which return immediately otherwise) are merged
-// into one launch of a single 1024-thread workgroup; between the phases a workgroup barrier replaces the kernel boundary.
-__global__ void __launch_bounds__(1024) k_rebuild_small(NbrArgs a) {
-    GAMD_GATE();
-    const int tid = threadIdx.x;
-    for (int c = tid; c < a.ncell; c += 1024) { a.cell_cnt[c] = 0; a.cell_fill[c] = 0; }
-    __syncthreads();
-    if (tid < a.n) d_bin(a, tid);
-    __syncthreads();
-    block_exclusive_scan(a.ncell, [&](int i) { return a.cell_cnt[i]; }, a.cell_start);
-    __syncthreads();
-    if (tid < a.n) d_fill_cells(a, tid);
-    __syncthreads();
-    for (int c = tid >> 6; c < a.ncell; c += 16) d_sort_gather(a, c, tid & 63);
-    __syncthreads();
-    for (int base = 0; base < a.n; base += 32) d_count(a, base + (tid >> 5), tid & 31);
-    __syncthreads();
-    d_scan_deg(a);
-    __syncthreads();
-    for (int base = 0; base < a.n; base += 32) d_fill(a, base + (tid >> 5), tid & 31);
-}
-
 // per 16-edge chunk: first piece id and the bit mask of edges that close a destination segment
 __global__ void k_chunk_meta(NbrArgs a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,9 +298,7 @@ __global__ void k_chunk_meta(NbrArgs a) {
 // Every call: wrap the positions and raise the rebuild flag if any atom has moved more than skin/2 since the
 // candidate list was built (or the host forces it).  jax-md does the same test in update_neighbor_lst
 // (graph_utils.py:36-44) with dr_threshold = cutoff/6.
-__global__ void k_skin_check(NbrArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+__device__ __forceinline__ bool d_skin_check(const NbrArgs& a, int i) {
     float4 p;
     p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);
     p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
@@ -338,11 +313,64 @@ __global__ void k_skin_check(NbrArgs a) {
         const float dz = gamd_min_image_wrapped(p.z - r.z, a.box[2], a.half[2]);
         moved = !(((dx * dx + dy * dy) + dz * dz) <= a.skin_half2);      // NaN positions force a rebuild too
     }
-    if (moved) a.counters[CNT_REBUILD] = 1;
     // current position in the (so far frozen) sorted order; a rebuild later in this call overwrites pos_s and the order
     p.w = node_feature(a, i);
     a.pos_s[a.inv_perm[i]] = p;
-    if (a.counters_next && i < CNT_COUNT) a.counters_next[i] = 0;
+    return moved;
+}
+
+__global__ void k_skin_check(NbrArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    if (d_skin_check(a, i)) a.counters[CNT_REBUILD] = 1;
+}
+
+// ---- small systems (n <= 1024), Verlet-skin mode: everything in front of the exact filter in ONE workgroup ------------
+// The reference's own drivers run 258 / 774 atoms, where a step is bound by the ~4-5 us every kernel costs in the stream,
+// not by work.  One 1024-thread workgroup (one thread per atom) therefore does, in this order:
+//   [B of the previous MD step] [B A O A of this step]     (plain BAOAB only: MdFuse; skipped when the run is frozen)
+//   wrap + displacement check, positions into the sorted order, clear of the other counter block
+//   the seven phases of the candidate rebuild, behind a workgroup-wide OR of the check (runs once in 50-100 steps),
+// with workgroup barriers where the large-system path has kernel boundaries: 1 launch instead of 11.
+__global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int do_second, int do_first) {
+    const int tid = threadIdx.x;
+    if (do_second | do_first) {
+        if (md.devflags[DEVFLAG_FROZEN]) {                 // GAMD_MD_GATE of integrate.hip for the fused halves
+            if (tid == 0 && md.devflags[DEVFLAG_FROZEN_AT] < 0)
+                md.devflags[DEVFLAG_FROZEN_AT] = do_second ? 2 * (md.step_index - 1) + 1 : 2 * md.step_index;
+        } else if (tid < a.n) {
+            if (do_second) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) d_baoab_second_dof(md, 3 * tid + d);
+            }
+            if (do_first) d_baoab_first_atom(md, tid);
+        }
+    }
+    const bool moved = tid < a.n ? d_skin_check(a, tid) : false;
+    if (tid < CNT_COUNT) a.counters_next[tid] = 0;
+    if (!__syncthreads_or(moved ? 1 : 0)) return;
+    if (tid == 0) a.counters[CNT_REBUILD] = 1;
+    // candidate pass: rc + skin, candidate arrays, no self loops (the exact filter appends them)
+    NbrArgs c = a;
+    c.cand_pass = 1;
+    c.rc = a.rc_build; c.rc2 = a.rc2_build;
+    c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
+    c.self_loop = 0;
+    for (int k = tid; k < c.ncell; k += 1024) { c.cell_cnt[k] = 0; c.cell_fill[k] = 0; }
+    __syncthreads();
+    if (tid < c.n) d_bin(c, tid);                           // also stores ref_pos
+    __syncthreads();
+    block_exclusive_scan(c.ncell, [&](int i) { return c.cell_cnt[i]; }, c.cell_start);
+    __syncthreads();
+    if (tid < c.n) d_fill_cells(c, tid);
+    __syncthreads();
+    for (int k = tid >> 6; k < c.ncell; k += 16) d_sort_gather(c, k, tid & 63);
+    __syncthreads();
+    for (int base = 0; base < c.n; base += 32) d_count(c, base + (tid >> 5), tid & 31);
+    __syncthreads();
+    d_scan_deg(c);
+    __syncthreads();
+    for (int base = 0; base < c.n; base += 32) d_fill(c, base + (tid >> 5), tid & 31);
 }
 
 // exact cutoff on the candidate rows: one half-wave per centre atom, candidates keep their order
@@ -562,20 +590,16 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
     return 0;
 }
 
-int launch_neighbor_skin(const NbrArgs& a, hipStream_t st) {
+int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     hipError_t e;
     const int tb = 256, gb = (a.n + tb - 1) / tb, ga = (a.n + 7) / 8;
     if (a.counters_next) {
-        // small system (n <= 1024): 4 launches and no memset node instead of 13 + 1 (counters ping-pong, cleared by
-        // k_skin_check; cell arrays cleared inside the gated rebuild)
-        hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
-        NbrArgs c = a;
-        c.gate = a.counters + CNT_REBUILD;
-        c.cand_pass = 1;
-        c.rc = a.rc_build; c.rc2 = a.rc2_build;
-        c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
-        c.self_loop = 0;
-        hipLaunchKernelGGL(k_rebuild_small, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
+        // small system (n <= 1024): 3 launches and no memset node instead of 13 + 1 (+ 2 integrator launches): counters
+        // ping-pong, cell arrays cleared inside the rebuild, integrator halves folded in
+        MdArgs md{};
+        if (fuse) md = *fuse->md;
+        hipLaunchKernelGGL(k_step_small, dim3(1), dim3(1024), 0, st, a, md, fuse ? fuse->do_second : 0, fuse ? fuse->do_first : 0);
+        GAMD_CHECK_LAUNCH();
         NbrArgs x = a;
         x.ref_pos = nullptr;
         hipLaunchKernelGGL(k_filter<false>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();

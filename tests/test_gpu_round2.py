@@ -275,6 +275,82 @@ def test_forward_after_overflow_in_md_run_is_clean():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# small systems (n <= 1024) in skin mode: 3 neighbour launches per call, integrator halves fused into the first one
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,flavour", [(258, "jaxmd"), (700, "jaxmd"), (1024, "jaxmd"), (384, "torch")])
+def test_small_system_skin_path_gives_the_exact_edge_set_every_step(n, flavour):
+    """Same contract as the large-system skin path (graph_utils.py:21-25,36-44), on the single-workgroup kernels: along a
+    random walk the edge SET equals the rebuild-every-call engine's at every step, forces agree to rounding, candidates
+    are rebuilt only now and then, and a jump forces an immediate rebuild."""
+    rng = np.random.default_rng(5)
+    rc, skin = 7.5, 1.25
+    pos, box = workloads.lj_box(n, seed=8)
+    sd = make_state_dict(ModelConfig(kind="lj"), 2, 5.0, 1.7)
+    exact = _engine(sd, n, box, rc, nbr_flavour=flavour)
+    reuse = _engine(sd, n, box, rc, neighbor_skin=skin, nbr_flavour=flavour)
+    x = pos.copy()
+    rebuilds = []
+    for step in range(36):
+        if step == 20:
+            x[7] += np.array([3.0, -2.0, 0.5])
+        p = torch.from_numpy(x).float()
+        f0, f1 = exact.forward(p).cpu().numpy(), reuse.forward(p).cpu().numpy()
+        assert exact.counts()[0] == reuse.counts()[0], step
+        assert np.array_equal(edge_set(exact.debug_edges()), edge_set(reuse.debug_edges())), step
+        assert rel_err(f1, f0) < TOL, step
+        rebuilds.append(reuse.skin_stats()[0])
+        x = x + rng.normal(0.0, 0.06, x.shape)
+    assert rebuilds[0] == 1 and rebuilds[20] == rebuilds[19] + 1 and 3 <= rebuilds[-1] < 12
+    exact.close(); reuse.close()
+
+
+def test_small_system_fused_md_steps_match_the_unfused_path():
+    """n <= 1024 with skin: B of step s-1 and B A O A of step s run inside the first neighbour kernel of step s.  Same
+    noise stream (seed, step, atom) and the same arithmetic as the stand-alone integrator kernels: against an engine
+    without skin (un-fused launches, exact rebuild) the trajectory agrees to the rounding of the row order, and calling
+    md_run step by step equals one call."""
+    n, rc = 300, 7.5
+    sd = make_state_dict(ModelConfig(kind="lj"), 2, 5.0, 1.7)
+    out = {}
+    for tag, kw, chunks in (("unfused", {}, [12]), ("fused", dict(neighbor_skin=rc / 6), [12]),
+                            ("fused_split", dict(neighbor_skin=rc / 6), [1, 4, 7])):
+        x, v, box = _md_state(n, 4)
+        eng = _engine(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"], **kw)
+        f = eng.forward(x, denormalize=True)
+        done = 0
+        for c in chunks:
+            eng.md_run(x, v, f, c, seed=11, first_step=done)
+            done += c
+        out[tag] = (x.cpu().numpy(), v.cpu().numpy(), f.cpu().numpy())
+        eng.close()
+    for a, b in zip(out["fused"], out["fused_split"]):
+        assert np.array_equal(a, b)
+    for a, b in zip(out["unfused"], out["fused"]):
+        assert np.isfinite(b).all() and rel_err(b, a) < 2e-5
+    assert not np.array_equal(out["fused"][0], _md_state(n, 4)[0].cpu().numpy())
+
+
+def test_small_system_fused_md_overflow_freezes_and_resumes():
+    n, rc, steps = 300, 7.5, 9
+    sd = make_state_dict(ModelConfig(kind="lj"), 2, 5.0, 1.7)
+    res = {}
+    for tag, cap in (("ample", 0), ("tiny", 1500)):
+        x, v, box = _md_state(n, 4)
+        e0 = _engine(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"])
+        f = e0.forward(x, denormalize=True)
+        e0.close()
+        eng = _engine(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"], edge_capacity=cap, neighbor_skin=rc / 6)
+        eng.md_run(x, v, f, steps, seed=3, sync=False)
+        assert eng.sync_status() == (1 if cap else 0)
+        res[tag] = (x.cpu().numpy(), v.cpu().numpy(), f.cpu().numpy())
+        eng.md_run(x, v, f, 2, seed=3, first_step=steps)
+        assert eng.last_status == 0 and torch.isfinite(x).all()
+        eng.close()
+    for a, b in zip(res["ample"], res["tiny"]):
+        assert np.isfinite(b).all() and rel_err(b, a) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # argument checks of the MD entry points (they used to skip what gamd_forces_async checks)
 # ---------------------------------------------------------------------------------------------------------------
 def test_md_entry_points_check_species_bonds_and_rigid_layout():
