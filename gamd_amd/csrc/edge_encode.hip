@@ -18,6 +18,43 @@ namespace {
 constexpr int ENC_W1_FLOATS = 4 * 6 * 64 * 4;              // K padded to 48 (24 MFMA steps)
 constexpr int ENC_LDS_FLOATS = ENC_W1_FLOATS + 2 * GAMD_WFRAG_FLOATS + 5 * 128 + 64;
 
+// Edge features of nn_module.py:603-634 (+ the bond flag of :510-511) for this lane's edge, already in the operand order of
+// the first GEMM: MFMA K step s covers features (2 s, 2 s + 1), lanes 0-31 supply the even one, lanes 32-63 the odd one.
+//   features: 0-2 unit vector, 3 standardised length d, 4-43 RBFs of d, 44 bond flag (NFEAT == 45)
+template <int NFEAT, int ABL, typename CPtr>
+__device__ __forceinline__ void edge_features(const EncArgs& a, CPtr cen, int src, int dst, const float4& ps, const float4& pd,
+                                              int half, float (&F)[24]) {
+    // nn_module.py:615-624
+    const float rx = gamd_min_image_wrapped(ps.x - pd.x, a.box[0], a.half[0]);
+    const float ry = gamd_min_image_wrapped(ps.y - pd.y, a.box[1], a.half[1]);
+    const float rz = gamd_min_image_wrapped(ps.z - pd.z, a.box[2], a.half[2]);
+    const float nrm = sqrtf((rx * rx + ry * ry) + rz * rz);
+    const float den = nrm + 1e-8f;
+    const float d = (nrm - a.length_mean) / a.length_std;          // :630
+    F[0] = half ? ry / den : rx / den;
+    F[1] = half ? d : rz / den;
+    if (!(ABL & 8) && a.rbf.uniform) {
+        gamd_rbf_chains(d, half, a.gamma * -1.4426950408889634f, a.rbf, F);
+    } else {
+#pragma unroll
+        for (int s = 2; s < 22; ++s) {
+            const float radial = d - cen[2 * (s - 2) + half];           // :261-263
+            F[s] = (ABL & 8) ? radial : __builtin_amdgcn_exp2f((a.gamma * -1.4426950408889634f) * (radial * radial));
+        }
+    }
+    F[22] = 0.f; F[23] = 0.f;
+    if (NFEAT == 45) {
+        // bond_graph.has_edges_between(centre, neigh), nn_module.py:510
+        float flag = 0.f;
+        if (a.bond_nbr) {
+            const int io = a.perm[dst], jo = a.perm[src];
+            const int4 nb = *reinterpret_cast<const int4*>(a.bond_nbr + 4 * (size_t)io);
+            flag = (nb.x == jo || nb.y == jo || nb.z == jo || nb.w == jo) ? 1.f : 0.f;
+        }
+        F[22] = half ? 0.f : flag;
+    }
+}
+
 // X = GELU(acc) on a 32 x 128 block.  ABL bit 1 (profiling build): x/2 instead (timing ablation, wrong results)
 template <int ABL>
 __device__ __forceinline__ void gelu_block(const f32x16 (&acc)[4], f32x16 (&X)[4]) {
@@ -90,36 +127,8 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
         const int src = src_c, dst = dst_c;
-        // nn_module.py:615-624
-        const float rx = gamd_min_image_wrapped(ps.x - pd.x, a.box[0], a.half[0]);
-        const float ry = gamd_min_image_wrapped(ps.y - pd.y, a.box[1], a.half[1]);
-        const float rz = gamd_min_image_wrapped(ps.z - pd.z, a.box[2], a.half[2]);
-        const float nrm = sqrtf((rx * rx + ry * ry) + rz * rz);
-        const float den = nrm + 1e-8f;
-        const float d = (nrm - a.length_mean) / a.length_std;          // :630
         float F[24];
-        F[0] = half ? ry / den : rx / den;
-        F[1] = half ? d : rz / den;
-        if (!(ABL & 8) && a.rbf.uniform) {
-            gamd_rbf_chains(d, half, a.gamma * -1.4426950408889634f, a.rbf, F);
-        } else {
-#pragma unroll
-            for (int s = 2; s < 22; ++s) {
-                const float radial = d - cen[2 * (s - 2) + half];           // :261-263
-                F[s] = (ABL & 8) ? radial : __builtin_amdgcn_exp2f((a.gamma * -1.4426950408889634f) * (radial * radial));
-            }
-        }
-        F[22] = 0.f; F[23] = 0.f;
-        if (NFEAT == 45) {
-            // bond_graph.has_edges_between(centre, neigh), nn_module.py:510
-            float flag = 0.f;
-            if (a.bond_nbr) {
-                const int io = a.perm[dst], jo = a.perm[src];
-                const int4 nb = *reinterpret_cast<const int4*>(a.bond_nbr + 4 * (size_t)io);
-                flag = (nb.x == jo || nb.y == jo || nb.z == jo || nb.w == jo) ? 1.f : 0.f;
-            }
-            F[22] = half ? 0.f : flag;
-        }
+        edge_features<NFEAT, ABL>(a, cen, src, dst, ps, pd, half, F);
         if (a.feat_dbg && valid) {
 #pragma unroll
             for (int s = 0; s < 24; ++s) a.feat_dbg[x * 48 + 2 * s + half] = F[s];
@@ -175,7 +184,92 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
     }
 }
 
+// ---- small edge counts (the reference's own drivers: 258 LJ atoms, 6 000 edges = 190 tiles) -----------------------------
+// The persistent kernel above spends ~10 us staging 152 KiB of weights into LDS per workgroup before its first tile: too
+// long when there is less than one tile per workgroup.  Here one 32-edge tile is shared by the four waves of a 256-thread
+// workgroup (conv_edge_small.hip's scheme): wave w computes output features [32 w, 32 w + 32) of each of the three GEMMs
+// from its weight quarter read straight from L2, applies GELU to its 16 values per lane (a quarter of the VALU work per
+// wave), and the 128-wide rows are re-assembled through LDS between the GEMMs.  Same operations in the same order per
+// output element as k_edge_encode (including the LayerNorm sums: per 32-feature block, then a fixed tree): bit-identical.
+template <int NFEAT>
+__global__ void __launch_bounds__(256) k_edge_encode_small(EncArgs a) {
+    __shared__ __attribute__((aligned(16))) float xbuf[32 * GAMD_XLD];
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
+    const int quarter = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    long long E = a.counters[CNT_E];
+    if (E > a.e_cap) E = a.e_cap;
+    const int n_tiles = (int)((E + GAMD_TILE - 1) / GAMD_TILE);
+    constexpr int KSTEPS = (NFEAT + 1) / 2;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
+        const bool valid = x < E;
+        const int src = valid ? a.col[x] : 0, dst = valid ? a.erow[x] : 0;
+        const float4 ps = a.pos_s[src], pd = a.pos_s[dst];
+        f32x4 w1[6];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) w1[g] = ((const f32x4*)a.w1p)[(quarter * 6 + g) * 64 + lane];
+        WQuarter wa, wb;
+        load_wquarter(a.w2p, quarter, lane, wa);
+        float F[24];
+        edge_features<NFEAT, 0>(a, a.centers, src, dst, ps, pd, half, F);
+        if (a.feat_dbg && valid && quarter == 0) {
+#pragma unroll
+            for (int s = 0; s < 24; ++s) a.feat_dbg[x * 48 + 2 * s + half] = F[s];
+        }
+        // GEMM 1 + GELU
+        f32x16 acc = load_slice(a.b1, quarter, half), X[4];
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            if (4 * g >= KSTEPS) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * g + j < KSTEPS) acc = mfma32(w1[g][j], F[4 * g + j], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = gamd_gelu_hw(acc[r]);
+        exchange(xbuf, quarter, slot, half, acc, X);
+        // GEMM 2 + GELU
+        acc = load_slice(a.b2, quarter, half);
+        load_wquarter(a.w3p, quarter, lane, wb);
+        gemm_quarter<false>(wa, X, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = gamd_gelu_hw(acc[r]);
+        exchange(xbuf, quarter, slot, half, acc, X);
+        // GEMM 3 (rows arrive centred) + LayerNorm
+        acc = load_slice(a.b3, quarter, half);
+        gemm_quarter<false>(wb, X, acc);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v = fmaf(acc[r], acc[r], v);
+        __syncthreads();                                   // previous tile's readers of red[] are done
+        red[quarter][lane] = v;
+        __syncthreads();
+        const float var = gamd_xhalf_sum((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * (1.0f / 128.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const f32x16 g = load_slice(a.ln_g, quarter, half), b = load_slice(a.ln_b, quarter, half);
+        const bool zero_row = a.self_loop && valid && x == (long long)a.row_ptr[dst + 1] - 1;      // appended loop: e = 0
+        f32x4* out = (f32x4*)a.e_frag + (size_t)tile * 16 * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = zero_row ? 0.f : fmaf(acc[q * 4 + j] * rstd, g[q * 4 + j], b[q * 4 + j]);
+            out[(quarter * 4 + q) * 64 + lane] = o;
+        }
+    }
+}
+
 }  // namespace
+
+int launch_edge_encode_small(const EncArgs& a, int n_blocks, hipStream_t st) {
+    if (a.n_feat == 44) hipLaunchKernelGGL((k_edge_encode_small<44>), dim3(n_blocks), dim3(256), 0, st, a);
+    else if (a.n_feat == 45) hipLaunchKernelGGL((k_edge_encode_small<45>), dim3(n_blocks), dim3(256), 0, st, a);
+    else return -22;
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}
 
 template <int ABL>
 static int launch_abl(const EncArgs& a, int n_blocks, hipStream_t st) {

@@ -422,9 +422,20 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.e_frag = h->e_frag.as<float>();
     ea.e_cap = h->e_cap;
     ea.feat_dbg = h->cfg.keep_stages ? h->feat_dbg.as<float>() : nullptr;
+    // fp32 path, few tiles (measured crossover ~500 tiles, half a tile per SIMD): the latency-oriented kernels, one tile
+    // per 4-wave workgroup (conv_edge_small.hip, k_edge_encode_small).  They are bit-identical to the throughput kernels, so
+    // the choice (from the last known edge count, or the density estimate before the first call) never shows in the results.
+    int small_tiles = 0;
+    if (h->cfg.edge_dtype == GAMD_EDGE_F32) {
+        const long long e_est = el ? el->n + (na.self_loop ? h->n : 0)
+                                   : (h->counters_host[CNT_E] > 0 ? (long long)h->counters_host[CNT_E] : (long long)((double)h->e_cap / 1.5));
+        const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
+        if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
+    }
     r = h->wide_enc ? launch_edge_encode_wide(ea, h->EHT, h->n_cu, st)
         : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_edge_encode_bf16(ea, h->n_cu, st)
-        : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_edge_encode_f16x3(ea, h->n_cu, st) : launch_edge_encode(ea, h->n_cu, st);
+        : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_edge_encode_f16x3(ea, h->n_cu, st)
+        : small_tiles > 0 ? launch_edge_encode_small(ea, small_tiles, st) : launch_edge_encode(ea, h->n_cu, st);
     if (r) return fail(-1, "edge encode launch failed (%d)", r);
     mark("edge_encode");
 
@@ -457,16 +468,6 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     if ((r = node(no))) return fail(-1, "node(0) launch failed (%d)", r);
     mark("node_first");
 
-    // fp32 path, few tiles (measured crossover ~500 tiles, half a tile per SIMD): the latency-oriented kernel, one tile per workgroup.  Both kernels are
-    // bit-identical, so the choice (from the last known edge count, or the density estimate before the first call) never
-    // shows in the results.
-    int small_tiles = 0;
-    if (h->cfg.edge_dtype == GAMD_EDGE_F32) {
-        const long long e_est = el ? el->n + (na.self_loop ? h->n : 0)
-                                   : (h->counters_host[CNT_E] > 0 ? (long long)h->counters_host[CNT_E] : (long long)((double)h->e_cap / 1.5));
-        const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
-        if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
-    }
 
     for (int l = 0; l < h->L; ++l) {
         ConvEdgeArgs ca{};

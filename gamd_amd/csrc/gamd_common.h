@@ -315,12 +315,16 @@ __device__ __forceinline__ void exchange(float* xbuf, int quarter, int slot, int
 // subtraction done once on the host instead of per edge (64 adds + 64 subtracts + a shuffle per 32 x 128 block).
 template <typename GPtr>
 __device__ __forceinline__ void layernorm_chain_centered(f32x16 (&X)[4], GPtr gamma, GPtr beta, int half, float eps) {
-    float v = 0.f;
+    // sum of squares per 32-feature block, then a fixed tree over the blocks: the order the small-system encoder
+    // (one block per wave, edge_encode.hip) reproduces, so both give the same bits
+    float vt[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+        vt[t] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v = fmaf(X[t][r], X[t][r], v);
-    const float var = gamd_xhalf_sum(v) * (1.0f / 128.0f);
+        for (int r = 0; r < 16; ++r) vt[t] = fmaf(X[t][r], X[t][r], vt[t]);
+    }
+    const float var = gamd_xhalf_sum((vt[0] + vt[1]) + (vt[2] + vt[3])) * (1.0f / 128.0f);
     const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int t = 0; t < 4; ++t)

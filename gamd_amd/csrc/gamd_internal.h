@@ -103,6 +103,8 @@ struct EncArgs {
     float* feat_dbg;           // optional [e_cap][48] raw features (debug/parity), or null
 };
 int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st);
+// small edge counts: one tile per 4-wave workgroup, weights straight from L2, bit-identical to launch_edge_encode
+int launch_edge_encode_small(const EncArgs& a, int n_blocks, hipStream_t st);
 int launch_edge_encode_bf16(const EncArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
 int launch_edge_encode_f16x3(const EncArgs& a, int n_blocks, hipStream_t st);  // w*p = [hi | lo] fp16 fragments, e_frag pre-split
 // generic widths (wide.hip): n_feat in {4, 5, 44, 45}; w3p = eht packed blocks W3[128 ob : 128 ob + 128, :],
