@@ -256,6 +256,15 @@ void pack128(const float* W, float* out, int ld = 128) {
                         out[((((tp * 4 + t) * 4 + q) * 64 + lane) * 4) + j] = W[(size_t)n * ld + k];
                     }
 }
+// W [128 out][128 in] -> operand order of node.hip's 16x16x4 chain: block (ob, blk) = 16 output features x 16 inputs,
+// lane (i = lane & 15, g = lane >> 4) holds W[16 ob + i][16 blk + 4 g + 0..3]; a wave's quarter (ob = 2 w, 2 w + 1) is contiguous
+void pack16(const float* W, float* out, int ld = 128) {
+    for (int ob = 0; ob < 8; ++ob)
+        for (int blk = 0; blk < 8; ++blk)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r)
+                    out[(((ob * 8 + blk) * 64 + lane) * 4) + r] = W[(size_t)(16 * ob + (lane & 15)) * ld + 16 * blk + 4 * (lane >> 4) + r];
+}
 // encoder first layer W [128][n_feat]: MFMA step s covers features (2s, 2s+1); K padded to 48
 void pack_enc1(const float* W, int n_feat, float* out) {
     for (int tp = 0; tp < 4; ++tp)
@@ -737,6 +746,14 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
                         bb.host.data() + o + (size_t)(ob * KB + kb) * GAMD_WFRAG_FLOATS, 128 * KB);
         return o;
     };
+    // node-side matrices: the 128-wide node kernel (node.hip) runs on 16x16x4 MFMAs with its own operand order; the
+    // generic-width node kernel of wide.hip keeps the 32x32x2 fragment blocks
+    auto put_node = [&](const HostTensor* t, int OB, int KB) {
+        if (h->wide_conv) return put_blocks(t, OB, KB);
+        size_t o = bb.add(GAMD_WFRAG_FLOATS);
+        pack16(t->data.data(), bb.host.data() + o);
+        return o;
+    };
     const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16;       // 128-wide only (gamd_create)
     const bool f16x3_edges = h->cfg.edge_dtype == GAMD_EDGE_F16X3;     // 128-wide only (gamd_create)
     auto put_edge_f16x3 = [&](const HostTensor* t) {
@@ -781,12 +798,12 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         }
         o.b1 = put_vec(ea0b); o.b3 = put_vec(t1b); o.b4 = put_vec(t3b);
         o.lng = put_vec(ng); o.lnb = put_vec(nb);
-        o.wsp = put_blocks(sw, 1, (int)HT); o.wdp = put_blocks(dw, 1, (int)HT); o.wpdp = put_blocks(pdw, 1, (int)HT);
+        o.wsp = put_node(sw, 1, (int)HT); o.wdp = put_node(dw, 1, (int)HT); o.wpdp = put_node(pdw, 1, (int)HT);
         o.bS = bb.add(128);
         for (int i = 0; i < 128; ++i) bb.host[o.bS + i] = (sb->data[i] + db->data[i]) + ea2b->data[i];
         o.bP = bb.add(128);
         for (int i = 0; i < 128; ++i) bb.host[o.bP + i] = pdb->data[i] + peb->data[i];
-        o.wpep = put_blocks(pew, 1, (int)HT); o.wphip = put_blocks(phw, (int)HT, 1); o.bphi = put_vec(phb);
+        o.wpep = put_node(pew, 1, (int)HT); o.wphip = put_node(phw, (int)HT, 1); o.bphi = put_vec(phb);
     }
     const HostTensor *e0w = get("edge_encoder.mlp_layer.0.weight", {128, (int64_t)F}), *e0b = get("edge_encoder.mlp_layer.0.bias", {128});
     const HostTensor *e2w = get("edge_encoder.mlp_layer.2.weight", {128, 128}), *e2b = get("edge_encoder.mlp_layer.2.bias", {128});
@@ -824,7 +841,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : f16x3_edges ? put_edge_f16x3(e4w) : put_blocks(&e4w_c, (int)EHT, 1);
     const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(&e4b_c), o_elg = put_vec(elg), o_elb = put_vec(elb);
     const size_t o_cen = expand ? put_vec(cen) : bb.add(64);
-    const size_t o_d1 = put_blocks(d0w, 1, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
+    const size_t o_d1 = put_node(d0w, 1, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
     size_t o_emb = 0, o_nw = 0, o_nb = 0;
     if (h->cfg.kind == GAMD_KIND_LJ) {
         const HostTensor* emb = get("node_emb", {1, H});

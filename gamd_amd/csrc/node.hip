@@ -12,166 +12,229 @@
 //   post(l): agg = sum of this atom's partial-sum pieces, in order   (:142)
 //            h' = phi(P + phi_edge(agg)) + h                    (:147, :202 residual)
 //
-// N is small (10^4 rows): the kernel is latency-bound, not throughput-bound, so a 32-atom tile is
-// split over the 4 waves of a workgroup by OUTPUT feature quarter: wave w computes features
-// [32w, 32w+32) of every GEMM (64 MFMAs instead of 256, its 16 KiB weight quarter read straight from
-// L2), and the full 128-wide activation row is re-assembled through a 16.5 KiB LDS exchange buffer
-// between chained GEMMs.  Activations are in the chain layout of gamd_common.h throughout.
+// N is small (258 ... 10^4 rows): the kernel is bound by the latency of five chained 128x128 GEMMs, not by throughput.
+// Work unit: a tile of 16 atoms per 256-thread workgroup, on v_mfma_f32_16x16x4_f32.  Wave w computes output features
+// [32 w, 32 w + 32) of every GEMM (two 16-feature row blocks = two independent accumulators, 64 MFMAs of 32 cycles =
+// 2 048 matrix cycles per GEMM: half of what a 32-atom tile on the 32x32x2 form needs, because a dependent chain there
+// cannot go below 64 MFMAs x 64 cycles however few atoms the tile holds) from its 16 KiB weight quarter, fetched from L2
+// in one batch one GEMM ahead; the 128-wide rows are re-assembled through an 8 KiB LDS exchange buffer between GEMMs.
+// Twice as many, half as long workgroups also spread better: 10 000 atoms = 625 tiles over 256 CUs (<= 3 per CU, 1.5
+// old-tile times) instead of 313 (2 per CU on 57 CUs, 2 old-tile times).
+//
+// "chain16" register layout of a 16-atom x 128-feature block: lane (a = lane & 15 atom, g = lane >> 4),
+//     XB[blk][r]  <->  atom a, feature 16 blk + 4 g + r          (blk 0..7, r 0..3: 8 float4 per lane)
+// which is at once the C/D layout of Y^T = W X^T on 16x16x4 (D row = 4 g + r of the 16-feature block, column = atom) and
+// the B operand of the next GEMM with the K index taken in the order (blk, r, g); the weights are packed to match
+// (pack16 in gamd_api.hip):  Wp[((ob * 8 + blk) * 64 + lane)][r] = W[16 ob + (lane & 15)][16 blk + 4 (lane >> 4) + r].
 #include "gamd_common.h"
 #include "gamd_internal.h"
-#include <cstdlib>
 
 namespace {
 
+constexpr int NT = 16;                         // atoms per tile
 constexpr int XLD = GAMD_XLD;                  // padded row stride of the exchange buffer (floats)
 
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc[o] (features 16 (2 w + o) + 4 g + r of atom a) += W[quarter w] * X^T; the two row blocks alternate so that the two
+// dependent accumulator chains (40-cycle latency, 32-cycle issue) keep the pipe full
+__device__ __forceinline__ void gemm16(const WQuarter& wq, const f32x4 (&XB)[8], f32x4 (&acc)[2]) {
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[0] = mfma16(wq.w[blk][r], XB[blk][r], acc[0]);
+            acc[1] = mfma16(wq.w[8 + blk][r], XB[blk][r], acc[1]);
+        }
+}
+
+// this lane's 2 x 4 floats of a plain row-major [128] row: features 16 (2 w + o) + 4 g + 0..3
+__device__ __forceinline__ void load16(const float* __restrict__ row, int w, int g, f32x4 (&v)[2]) {
+    v[0] = *reinterpret_cast<const f32x4*>(row + 32 * w + 4 * g);
+    v[1] = *reinterpret_cast<const f32x4*>(row + 32 * w + 16 + 4 * g);
+}
+__device__ __forceinline__ void store16(float* __restrict__ row, int w, int g, const f32x4 (&v)[2]) {
+    *reinterpret_cast<f32x4*>(row + 32 * w + 4 * g) = v[0];
+    *reinterpret_cast<f32x4*>(row + 32 * w + 16 + 4 * g) = v[1];
+}
+
+// every wave contributes its 32 features; afterwards every lane holds its share of the full rows in chain16 layout
+__device__ __forceinline__ void exchange16(float* xbuf, int w, int a, int g, const f32x4 (&mine)[2], f32x4 (&XB)[8]) {
+    __syncthreads();                                        // previous readers are done
+    store16(xbuf + a * XLD, w, g, mine);
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) XB[blk] = *reinterpret_cast<const f32x4*>(xbuf + a * XLD + 16 * blk + 4 * g);
+}
+
+// sum over the four lane groups g of an atom (lanes a, a + 16, a + 32, a + 48)
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
 __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
-    __shared__ __attribute__((aligned(16))) float xbuf[32 * XLD];
-    __shared__ float obuf[4][32][3];
-    __shared__ float red[2][4][32];
+    __shared__ __attribute__((aligned(16))) float xbuf[NT * XLD];
+    __shared__ float obuf[4][NT][3];
+    __shared__ float red[2][4][NT];
 
     if (a.counters[CNT_OVERFLOW] || a.devflags[DEVFLAG_FROZEN]) return;
 
-    const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
-    const int quarter = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int atom_raw = blockIdx.x * GAMD_TILE + slot;
+    const int lane = threadIdx.x & 63, la = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int atom_raw = blockIdx.x * NT + la;
     const bool valid = atom_raw < a.n;
     const int atom = valid ? atom_raw : a.n - 1;
     const size_t row = (size_t)atom * GAMD_H;
 
-    f32x16 X[4];          // full activation row block (chain layout)
-    f32x16 mine;          // this wave's output quarter
+    f32x4 XB[8];          // full activation rows (chain16 layout)
+    f32x4 mine[2];        // this wave's 32 output features
     WQuarter wa, wb;      // double-buffered weight quarters
 
     if (a.mode == 0) {
         if (a.node_emb) {
-            mine = load_slice(a.node_emb, quarter, half);
+            load16(a.node_emb, w, g, mine);
         } else {
-            const float f = a.pos_s[atom].w;                       // species feature (O=1, H=0)
-            const f32x16 w = load_slice(a.enc_w, quarter, half);
-            mine = load_slice(a.enc_b, quarter, half);
+            const float f = a.pos_s[atom].w;                       // node feature (O = 1, H = 0, or the caller's float)
+            f32x4 ww[2];
+            load16(a.enc_w, w, g, ww);
+            load16(a.enc_b, w, g, mine);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mine[r] = f * w[r] + mine[r];
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[o][r] = f * ww[o][r] + mine[o][r];
         }
-        if (valid) store_slice(a.h_out + row, quarter, half, mine);
-        load_wquarter(a.pre.wsp, quarter, lane, wa);
+        if (valid) store16(a.h_out + row, w, g, mine);
+        load_wquarter(a.pre.wsp, w, lane, wa);
     } else {
-        // ---- post(l-1): aggregate this quarter's slice of the pieces, in order ------------------
+        // ---- post(l-1): aggregate this wave's slice of the atom's pieces, in order -------------------
         const int rp0 = a.row_ptr[atom], dg = a.deg[atom];
         const int na_incl = a.na_excl[atom] + ((dg > 0 && (rp0 % GAMD_CHUNK) != 0) ? 1 : 0);
         const int p0 = rp0 / GAMD_CHUNK + na_incl;
         const int np = dg > 0 ? ((rp0 + dg - 1) / GAMD_CHUNK - rp0 / GAMD_CHUNK + 1) : 0;
-        // pieces are fetched in batches of 8 (one memory round trip for the usual 4-6 pieces per atom) and
-        // summed in piece order
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] = 0.f;
-        const f32x16 p_in = load_slice(a.P_in + row, quarter, half);     // also in flight now
-        const f32x16 h_res = load_slice(a.h_in + row, quarter, half);
+        mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mine[1] = mine[0];
+        f32x4 p_in[2], h_res[2];
+        load16(a.P_in + row, w, g, p_in);                          // in flight during the aggregation
+        load16(a.h_in + row, w, g, h_res);
+        // pieces are fetched in batches of 8 (one memory round trip for the usual 4-6 pieces per atom), summed in piece order
         for (int k0 = 0; __any(k0 < np); k0 += 8) {
-            f32x16 pc[8];
+            f32x4 pc[8][2];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int kk = (k0 + k < np) ? k0 + k : (np > 0 ? np - 1 : 0);
-                pc[k] = load_slice(a.partial + (size_t)(np > 0 ? p0 + kk : 0) * GAMD_H, quarter, half);
+                load16(a.partial + (size_t)(np > 0 ? p0 + kk : 0) * GAMD_H, w, g, pc[k]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (k0 + k < np) mine += pc[k];
+                if (k0 + k < np) { mine[0] += pc[k][0]; mine[1] += pc[k][1]; }
         }
-        load_wquarter(a.post.wpep, quarter, lane, wa);            // in flight during the exchange
-        exchange(xbuf, quarter, slot, half, mine, X);            // X = agg
-        mine = p_in;
-        load_wquarter(a.post.wphip, quarter, lane, wb);           // next GEMM's weights behind this one
-        gemm_quarter(wa, X, mine);
+        load_wquarter(a.post.wpep, w, lane, wa);                  // in flight during the exchange
+        exchange16(xbuf, w, la, g, mine, XB);                     // XB = agg
+        mine[0] = p_in[0]; mine[1] = p_in[1];
+        load_wquarter(a.post.wphip, w, lane, wb);                 // next GEMM's weights behind this one
+        gemm16(wa, XB, mine);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] = gamd_silu_hw(mine[r]);
-        exchange(xbuf, quarter, slot, half, mine, X);            // X = SiLU(P + phi_edge(agg))
-        mine = load_slice(a.post.bphi, quarter, half);
-        if (a.mode != 2) load_wquarter(a.pre.wsp, quarter, lane, wa); else load_wquarter(a.dec_w1p, quarter, lane, wa);
-        gemm_quarter(wb, X, mine);
-        mine += h_res;                                            // residual
-        if (valid) store_slice(a.h_out + row, quarter, half, mine);
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[o][r] = gamd_silu_hw(mine[o][r]);
+        exchange16(xbuf, w, la, g, mine, XB);                     // XB = SiLU(P + phi_edge(agg))
+        load16(a.post.bphi, w, g, mine);
+        if (a.mode != 2) load_wquarter(a.pre.wsp, w, lane, wa); else load_wquarter(a.dec_w1p, w, lane, wa);
+        gemm16(wb, XB, mine);
+        mine[0] += h_res[0]; mine[1] += h_res[1];                 // residual
+        if (valid) store16(a.h_out + row, w, g, mine);
     }
 
     if (a.mode != 2) {
-        // ---- pre(l): LayerNorm over the row = two cross-wave reductions of per-atom partial sums ----
+        // ---- pre(l): LayerNorm over the row = reductions over the 4 lane groups and the 4 waves ----
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ps += mine[r];
-        ps = gamd_xhalf_sum(ps);
-        if (half == 0) red[0][quarter][slot] = ps;
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ps += mine[o][r];
+        ps = group_sum(ps);
+        if (g == 0) red[0][w][la] = ps;
         __syncthreads();
-        const float mean = ((red[0][0][slot] + red[0][1][slot]) + (red[0][2][slot] + red[0][3][slot])) * (1.0f / 128.0f);
+        const float mean = ((red[0][0][la] + red[0][1][la]) + (red[0][2][la] + red[0][3][la])) * (1.0f / 128.0f);
         float pv = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float d = mine[r] - mean; pv += d * d; }
-        pv = gamd_xhalf_sum(pv);
-        if (half == 0) red[1][quarter][slot] = pv;
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = mine[o][r] - mean; pv += d * d; }
+        pv = group_sum(pv);
+        if (g == 0) red[1][w][la] = pv;
         __syncthreads();
-        const float var = ((red[1][0][slot] + red[1][1][slot]) + (red[1][2][slot] + red[1][3][slot])) * (1.0f / 128.0f);
+        const float var = ((red[1][0][la] + red[1][1][la]) + (red[1][2][la] + red[1][3][la])) * (1.0f / 128.0f);
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         {
-            const f32x16 g = load_slice(a.pre.ln_g, quarter, half), b = load_slice(a.pre.ln_b, quarter, half);
+            f32x4 gg[2], bb[2];
+            load16(a.pre.ln_g, w, g, gg);
+            load16(a.pre.ln_b, w, g, bb);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mine[r] = (mine[r] - mean) * rstd * g[r] + b[r];
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[o][r] = (mine[o][r] - mean) * rstd * gg[o][r] + bb[o][r];
         }
-        if (valid && !a.hn_perm) store_slice(a.hn_out + row, quarter, half, mine);
-        exchange(xbuf, quarter, slot, half, mine, X);            // X = hn
+        if (valid && !a.hn_perm) store16(a.hn_out + row, w, g, mine);
+        exchange16(xbuf, w, la, g, mine, XB);                     // XB = hn
         if (a.hn_perm) {
             // feature-permuted copy for the row-layout gather of conv_edge_f16x3.hip, written from the assembled rows
             // in the exchange buffer: position 4 c + j holds feature 32 j + c, one coalesced 16-byte store per (atom, c)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 2; ++k) {
                 const int idx = k * 256 + threadIdx.x, at = idx >> 5, c = idx & 31;
                 const float* xr = xbuf + at * XLD + c;
                 const f32x4 v = {xr[0], xr[32], xr[64], xr[96]};
-                const int atom_k = blockIdx.x * GAMD_TILE + at;
+                const int atom_k = blockIdx.x * NT + at;
                 if (atom_k < a.n) *reinterpret_cast<f32x4*>(a.hn_out + (size_t)atom_k * GAMD_H + 4 * c) = v;
             }
         }
-        mine = load_slice(a.pre.bS, quarter, half);
-        load_wquarter(a.pre.wdp, quarter, lane, wb);
-        gemm_quarter(wa, X, mine);
-        if (valid) store_slice(a.S_out + row, quarter, half, mine);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r] = 0.f;
-        load_wquarter(a.pre.wpdp, quarter, lane, wa);
-        gemm_quarter(wb, X, mine);
-        if (valid) store_slice(a.D_out + row, quarter, half, mine);
-        mine = load_slice(a.pre.bP, quarter, half);
-        gemm_quarter(wa, X, mine);
-        if (valid) store_slice(a.P_out + row, quarter, half, mine);
+        load16(a.pre.bS, w, g, mine);
+        load_wquarter(a.pre.wdp, w, lane, wb);
+        gemm16(wa, XB, mine);
+        if (valid) store16(a.S_out + row, w, g, mine);
+        mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mine[1] = mine[0];
+        load_wquarter(a.pre.wpdp, w, lane, wa);
+        gemm16(wb, XB, mine);
+        if (valid) store16(a.D_out + row, w, g, mine);
+        load16(a.pre.bP, w, g, mine);
+        gemm16(wa, XB, mine);
+        if (valid) store16(a.P_out + row, w, g, mine);
     } else {
         // ---- decoder: Lin(128,128) GELU Lin(128,3); denormalise -------------------------------
-        exchange(xbuf, quarter, slot, half, mine, X);            // X = h'
-        mine = load_slice(a.dec_b1, quarter, half);
-        gemm_quarter(wa, X, mine);
-        float o[3] = {0.f, 0.f, 0.f};
+        exchange16(xbuf, w, la, g, mine, XB);                     // XB = h'
+        load16(a.dec_b1, w, g, mine);
+        gemm16(wa, XB, mine);
+        float o3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int f0 = 32 * quarter + 8 * q + 4 * half;
-            f32x4 g;
+        for (int o = 0; o < 2; ++o) {
+            const int f0 = 32 * w + 16 * o + 4 * g;
+            f32x4 gl;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = gamd_gelu_hw(mine[q * 4 + j]);
+            for (int r = 0; r < 4; ++r) gl[r] = gamd_gelu_hw(mine[o][r]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(a.dec_w2 + c * GAMD_H + f0);
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(a.dec_w2 + c * GAMD_H + f0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[c] += w[j] * g[j];
+                for (int r = 0; r < 4; ++r) o3[c] += ww[r] * gl[r];
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) o[c] = gamd_xhalf_sum(o[c]);
-        if (half == 0) {
+        for (int c = 0; c < 3; ++c) o3[c] = group_sum(o3[c]);
+        if (g == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) obuf[quarter][slot][c] = o[c];
+            for (int c = 0; c < 3; ++c) obuf[w][la][c] = o3[c];
         }
         __syncthreads();
-        if (quarter == 0 && half == 0 && valid) {
+        if (w == 0 && g == 0 && valid) {
             const int orig = a.perm[atom];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = ((obuf[0][slot][c] + obuf[1][slot][c]) + (obuf[2][slot][c] + obuf[3][slot][c])) + a.dec_b2[c];
+                const float v = ((obuf[0][la][c] + obuf[1][la][c]) + (obuf[2][la][c] + obuf[3][la][c])) + a.dec_b2[c];
                 a.forces_norm[3 * (size_t)orig + c] = v;
                 if (a.forces) a.forces[3 * (size_t)orig + c] = v * a.scale + a.shift;
                 if (!(fabsf(v) <= 3.0e38f)) a.sticky[STICKY_NONFINITE] = 1;      // NaN or inf
@@ -182,9 +245,8 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
 
 }  // namespace
 
-int launch_node(const NodeArgs& a0, hipStream_t st) {
-    const NodeArgs& a = a0;
-    const int nb = (a.n + GAMD_TILE - 1) / GAMD_TILE;
+int launch_node(const NodeArgs& a, hipStream_t st) {
+    const int nb = (a.n + NT - 1) / NT;
     hipLaunchKernelGGL(k_node, dim3(nb), dim3(256), 0, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
