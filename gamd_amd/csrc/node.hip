@@ -38,16 +38,51 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// acc[o] (features 16 (2 w + o) + 4 g + r of atom a) += W[quarter w] * X^T; the two row blocks alternate so that the two
-// dependent accumulator chains (40-cycle latency, 32-cycle issue) keep the pipe full
-__device__ __forceinline__ void gemm16(const WQuarter& wq, const f32x4 (&XB)[8], f32x4 (&acc)[2]) {
+// A wave's 16 KiB weight quarter is consumed as two K halves of 8 float4 per lane, h.w[o * 4 + b] = block (ob = 2 w + o,
+// blk = 4 half + b), and fetched from L2 one HALF ahead of the MFMAs that use it (the first half of a GEMM during the
+// exchange in front of it, the second during its first 32 MFMAs): 64 live weight registers instead of the 128 of a
+// whole-quarter double buffer.  That keeps the kernel at <= 168 VGPRs = three workgroups per CU, so the 625 tiles of a
+// 10 000-atom box are all resident and their latency phases overlap.
+struct WHalf { f32x4 w[8]; };
+__device__ __forceinline__ void load_whalf(const float* __restrict__ Wp, int w, int lane, int half, WHalf& h) {
+    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)w * 16 * 64 + lane;
 #pragma unroll
-    for (int blk = 0; blk < 8; ++blk)
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) h.w[o * 4 + b] = W[(o * 8 + 4 * half + b) * 64];
+}
+
+// acc[o] (features 16 (2 w + o) + 4 g + r of atom a) += W[quarter w][:, K half] * X^T; the two row blocks alternate so that
+// the two dependent accumulator chains (40-cycle latency, 32-cycle issue) keep the pipe full
+__device__ __forceinline__ void gemm16_half(const WHalf& h, int half, const f32x4 (&XB)[8], f32x4 (&acc)[2]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            acc[0] = mfma16(wq.w[blk][r], XB[blk][r], acc[0]);
-            acc[1] = mfma16(wq.w[8 + blk][r], XB[blk][r], acc[1]);
+            acc[0] = mfma16(h.w[b][r], XB[4 * half + b][r], acc[0]);
+            acc[1] = mfma16(h.w[4 + b][r], XB[4 * half + b][r], acc[1]);
         }
+}
+
+// One 128x128 GEMM.  On entry `wn` holds (or has in flight) the FIRST K half of this GEMM's weights W; on exit it holds the
+// first half of `next` (the matrix of the GEMM that follows; NEXT = false: none).  The compiler barriers pin the fetches
+// where they are written: hipcc otherwise hoists every load to the top of the kernel and pays with 50 more registers.
+template <bool NEXT>
+__device__ __forceinline__ void gemm16(const float* W, const float* next, WHalf& wn, const f32x4 (&XB)[8], f32x4 (&acc)[2], int w, int lane) {
+    WHalf cur = wn;
+    asm volatile("" ::: "memory");
+    load_whalf(W, w, lane, 1, wn);                          // second half: lands during the first half's 32 MFMAs
+    asm volatile("" ::: "memory");
+    gemm16_half(cur, 0, XB, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = wn;
+    if (NEXT) {
+        asm volatile("" ::: "memory");
+        load_whalf(next, w, lane, 0, wn);                   // next GEMM's first half: lands during the second half + exchange
+        asm volatile("" ::: "memory");
+    }
+    gemm16_half(cur, 1, XB, acc);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // this lane's 2 x 4 floats of a plain row-major [128] row: features 16 (2 w + o) + 4 g + 0..3
@@ -75,7 +110,7 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
-__global__ void __launch_bounds__(256) k_node(NodeArgs a) {
+__global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) float xbuf[NT * XLD];
     __shared__ float obuf[4][NT][3];
     __shared__ float red[2][4][NT];
@@ -91,7 +126,7 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
 
     f32x4 XB[8];          // full activation rows (chain16 layout)
     f32x4 mine[2];        // this wave's 32 output features
-    WQuarter wa, wb;      // double-buffered weight quarters
+    WHalf wn;             // the weight half that the next 32 MFMAs need (fetched one half ahead)
 
     if (a.mode == 0) {
         if (a.node_emb) {
@@ -107,7 +142,7 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
                 for (int r = 0; r < 4; ++r) mine[o][r] = f * ww[o][r] + mine[o][r];
         }
         if (valid) store16(a.h_out + row, w, g, mine);
-        load_wquarter(a.pre.wsp, w, lane, wa);
+        load_whalf(a.pre.wsp, w, lane, 0, wn);
     } else {
         // ---- post(l-1): aggregate this wave's slice of the atom's pieces, in order -------------------
         const int rp0 = a.row_ptr[atom], dg = a.deg[atom];
@@ -118,7 +153,6 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
         mine[1] = mine[0];
         f32x4 p_in[2], h_res[2];
         load16(a.P_in + row, w, g, p_in);                          // in flight during the aggregation
-        load16(a.h_in + row, w, g, h_res);
         // pieces are fetched in batches of 8 (one memory round trip for the usual 4-6 pieces per atom), summed in piece order
         for (int k0 = 0; __any(k0 < np); k0 += 8) {
             f32x4 pc[8][2];
@@ -131,19 +165,19 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
             for (int k = 0; k < 8; ++k)
                 if (k0 + k < np) { mine[0] += pc[k][0]; mine[1] += pc[k][1]; }
         }
-        load_wquarter(a.post.wpep, w, lane, wa);                  // in flight during the exchange
+        asm volatile("" ::: "memory");                            // the weight fetch stays behind the piece loads (registers)
+        load_whalf(a.post.wpep, w, lane, 0, wn);                  // in flight during the exchange
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = agg
         mine[0] = p_in[0]; mine[1] = p_in[1];
-        load_wquarter(a.post.wphip, w, lane, wb);                 // next GEMM's weights behind this one
-        gemm16(wa, XB, mine);
+        gemm16<true>(a.post.wpep, a.post.wphip, wn, XB, mine, w, lane);
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[o][r] = gamd_silu_hw(mine[o][r]);
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = SiLU(P + phi_edge(agg))
         load16(a.post.bphi, w, g, mine);
-        if (a.mode != 2) load_wquarter(a.pre.wsp, w, lane, wa); else load_wquarter(a.dec_w1p, w, lane, wa);
-        gemm16(wb, XB, mine);
+        load16(a.h_in + row, w, g, h_res);                        // residual: lands during the GEMM
+        gemm16<true>(a.post.wphip, a.mode != 2 ? a.pre.wsp : a.dec_w1p, wn, XB, mine, w, lane);
         mine[0] += h_res[0]; mine[1] += h_res[1];                 // residual
         if (valid) store16(a.h_out + row, w, g, mine);
     }
@@ -193,22 +227,20 @@ __global__ void __launch_bounds__(256) k_node(NodeArgs a) {
             }
         }
         load16(a.pre.bS, w, g, mine);
-        load_wquarter(a.pre.wdp, w, lane, wb);
-        gemm16(wa, XB, mine);
+        gemm16<true>(a.pre.wsp, a.pre.wdp, wn, XB, mine, w, lane);
         if (valid) store16(a.S_out + row, w, g, mine);
         mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         mine[1] = mine[0];
-        load_wquarter(a.pre.wpdp, w, lane, wa);
-        gemm16(wb, XB, mine);
+        gemm16<true>(a.pre.wdp, a.pre.wpdp, wn, XB, mine, w, lane);
         if (valid) store16(a.D_out + row, w, g, mine);
         load16(a.pre.bP, w, g, mine);
-        gemm16(wa, XB, mine);
+        gemm16<false>(a.pre.wpdp, nullptr, wn, XB, mine, w, lane);
         if (valid) store16(a.P_out + row, w, g, mine);
     } else {
         // ---- decoder: Lin(128,128) GELU Lin(128,3); denormalise -------------------------------
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = h'
         load16(a.dec_b1, w, g, mine);
-        gemm16(wa, XB, mine);
+        gemm16<false>(a.dec_w1p, nullptr, wn, XB, mine, w, lane);
         float o3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
