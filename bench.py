@@ -65,7 +65,8 @@ def parse_args():
     ap.add_argument("--skin", type=float, default=1.0 / 6.0,
                     help="Verlet-skin reuse of the neighbour candidates, in units of the cutoff (the reference's jax-md "
                          "list uses 1/6, graph_utils.py:24, and so does the default here); 0 = exact cell-list rebuild "
-                         "every step.  The edge set is identical either way (LJ workloads only)")
+                         "every step.  The edge set is identical either way (not used by the dft workload, whose reference "
+                         "searches from scratch every call)")
     ap.add_argument("--edge-dtype", default="f32", choices=["f32", "f16x3"],
                     help="c2 / c3. f32 (default, the headline): fp32 MFMA, bit-exact fp32 FMAs.  f16x3: the same GEMMs on the "
                          "fp16 matrix pipe with every operand split into hi + lo fp16 (3 MFMAs per product term, fp32 "
@@ -185,8 +186,11 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         if w.dtype_name == "f16x3":
             w.kernel_name = "k_conv_edge_f16x3"
         w.cutoff = 4.2
+        # the water drivers search neighbours with the same jax-md NeighborSearcher (dr_threshold = cutoff / 6) as the LJ
+        # one (water/train_network_tip3p.py:100-118, graph_utils.py:21-25): same Verlet-skin reuse
         w.eng = GamdForce(w.sd, pos.shape[0], box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS[scal], device=dev,
-                          edge_dtype=w.dtype_name)
+                          edge_dtype=w.dtype_name, neighbor_skin=skin * w.cutoff)
+        w.uses_skin = skin > 0
         w.mass = wk.MASS_O
         w.md_extra = dict(mass_h_amu=wk.MASS_H, rigid_water=True, r_oh=wk.TIP3P_R_OH, r_hh=wk.TIP3P_R_HH)
         w.label = (f"{name.upper()}: {nmol} rigid water molecules (SETTLE on device) = {pos.shape[0]} network atoms, cutoff 4.2 A, "
@@ -342,7 +346,7 @@ def main():
     torch.cuda.set_device(dev)
     ddev = f"cuda:{dev}" if (ctx.distributed and backend == "nccl") else "cpu"
 
-    skin = args.skin if args.workload in ("c1", "c2") else 0.0
+    skin = args.skin if args.workload != "dft" else 0.0          # md_module.get_neighbor searches from scratch every call
     w = build_workload(args.workload, ctx, dev, skin, args.edge_dtype)
     dt, dt_max, conv_ms, conv_n = timed_run(w, args.steps, args.warmup, ctx, dev, ddev)
     n_edges = w.eng.counts()[0]
@@ -431,7 +435,7 @@ def main():
         sec = {}
         w.eng.close()
         for name in ("c1", "c3", "c5", "c5b"):
-            s = build_workload(name, ctx, dev, args.skin if name == "c1" else 0.0, "f32")
+            s = build_workload(name, ctx, dev, args.skin, "f32")
             sdt, _, sconv_ms, sconv_n = timed_run(s, 20, 5, ctx, dev, ddev)
             se = s.eng.counts()[0]
             ok = bool(torch.isfinite(s.x).all().item() and torch.isfinite(s.f).all().item())
