@@ -224,7 +224,8 @@ def timed_run(w, steps, warmup, ctx, dev, ddev):
     ens.barrier(ctx)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    conv_ms, conv_n = w.eng.timing_read()
+    w.stages = w.eng.timing_read_stages()          # live HIP events of the timed region, per stage
+    conv_ms, conv_n = w.stages["conv_edge"]
     w.eng.timing_enable(False)
     return dt, ens.max_over_ranks(dt, ctx, device=ddev), conv_ms, conv_n
 
@@ -404,31 +405,33 @@ def main():
                                            "gather is reachable only by the bf16 kernel (see secondary c5)"}
     single = ctx.world == 1
     if single and not args.no_secondary:
-        # per-kernel figures of the other MFMA kernels from event-timed replays of one force evaluation
-        ms, per_eval = stage_replays(w)
+        # the other MFMA kernels, from the same live HIP events of the timed region as the conv kernel: the edge encoder has
+        # its own event pair; the node kernel between two conv layers is the interval between their event pairs (both
+        # kernel boundaries included).  The neighbour stage comes from event-timed replays afterwards.
         F = 45 if w.species is not None else 44
         kern = []
-        if "edge_encode" in ms and w.dtype_name == "f32" and args.workload in ("c1", "c2", "c3"):
-            fl = n_edges * 2.0 * (F * 128 + 2 * 128 * 128)
-            kern.append({"kernel": "k_edge_encode", "bound": "mfma", "flop_per_launch": fl, "avg_launch_ms": ms["edge_encode"],
-                         "achieved": fl / (ms["edge_encode"] * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": fl / (ms["edge_encode"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": 1})
-        if "node_mid" in ms and args.workload in ("c1", "c2", "c3", "c5", "c5b"):
-            fl = w.n_atoms * 10.0 * 128 * 128
-            kern.append({"kernel": "k_node (post + pre of a middle layer)", "bound": "latency (one round of 32-atom tiles)",
-                         "flop_per_launch": fl, "avg_launch_ms": ms["node_mid"],
-                         "achieved": fl / (ms["node_mid"] * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": fl / (ms["node_mid"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "launches_per_step": per_eval.get("node_mid", 0) + 2,
-                         "node_ms_per_step": ms.get("node_first", 0.0) + ms["node_mid"] * per_eval.get("node_mid", 0)
-                                             + ms.get("node_last_decode", 0.0)})
+        enc_ms, enc_n = w.stages["edge_encode"]
+        node_ms, node_n = w.stages["node_mid"]
+        if enc_n and w.dtype_name == "f32" and args.workload in ("c1", "c2", "c3"):
+            fl, t = n_edges * 2.0 * (F * 128 + 2 * 128 * 128), enc_ms / enc_n
+            kern.append({"kernel": "k_edge_encode", "bound": "mfma", "flop_per_launch": fl, "avg_launch_ms": t, "launches": enc_n,
+                         "achieved": fl / (t * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / (t * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "launches_per_step": 1})
+        if node_n and args.workload in ("c1", "c2", "c3", "c5", "c5b"):
+            fl, t = w.n_atoms * 10.0 * 128 * 128, node_ms / node_n
+            kern.append({"kernel": "k_node (post + pre between two conv layers)", "bound": "latency (16-atom tiles, 5 chained GEMMs)",
+                         "flop_per_launch": fl, "avg_launch_ms": t, "launches": node_n,
+                         "achieved": fl / (t * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / (t * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "launches_per_step": 5, "node_ms_per_step_estimate": 5 * t,
+                         "note": "interval between the conv layers' event pairs: the kernel plus its two boundaries (~3 us)"})
+        ms, per_eval = stage_replays(w, reps=4)
         if "neighbor_build" in ms:
             kern.append({"kernel": "neighbour stage (skin check + exact filter | cell-list build, CSR, chunk metadata)",
                          "bound": "latency / hbm (tiny)", "avg_stage_ms": ms["neighbor_build"],
                          "bytes_algorithmic": 12.0 * w.n_atoms + 8.0 * n_edges})
         rl["kernels"] = kern
-        rl["kernels_note"] = ("event-bracketed stages of gamd_profile replays after the timed region (8 evaluations); each "
-                              "figure includes the launch gap in front of the kernel")
+        rl["kernels_note"] = "k_edge_encode / k_node: live HIP events over the timed region; neighbour stage: 4 event-timed replays"
     if single and not args.no_cpu_baseline and args.workload == "c2":
         line["cpu_baseline"] = cpu_baseline(w, dev)
     if single and not args.no_secondary and args.workload == "c2":

@@ -142,6 +142,7 @@ struct gamd_handle {
     // live timing of the conv-edge kernel (gamd_timing_*)
     bool timing = false;
     std::vector<hipEvent_t> tev;     // pairs (start, stop)
+    std::vector<int> tev_kind;       // per pair: 0 = conv-layer edge kernel(s) of layer l, 1 = edge encoder; -(l+1) coded below
     size_t tev_used = 0;
 };
 
@@ -441,11 +442,27 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
         if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
     }
+    auto tev_begin = [&](int kind) -> int {
+        if (!h->timing) return 0;
+        if (h->tev_used + 2 > h->tev.size())
+            for (int k = 0; k < 256; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->tev.push_back(e); h->tev_kind.push_back(0); }
+        h->tev_kind[h->tev_used] = kind;
+        HIP_TRY(hipEventRecord(h->tev[h->tev_used], st));
+        return 0;
+    };
+    auto tev_end = [&]() -> int {
+        if (!h->timing) return 0;
+        HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st));
+        h->tev_used += 2;
+        return 0;
+    };
+    if ((r = tev_begin(100))) return r;                         // kind 100: edge encoder
     r = h->wide_enc ? launch_edge_encode_wide(ea, h->EHT, h->n_cu, st)
         : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_edge_encode_bf16(ea, h->n_cu, st)
         : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_edge_encode_f16x3(ea, h->n_cu, st)
         : small_tiles > 0 ? launch_edge_encode_small(ea, small_tiles, st) : launch_edge_encode(ea, h->n_cu, st);
     if (r) return fail(-1, "edge encode launch failed (%d)", r);
+    if ((r = tev_end())) return r;
     mark("edge_encode");
 
     const size_t nh = (size_t)h->n * (size_t)h->H;
@@ -491,19 +508,14 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.partial = h->partial.as<float>();
         ca.e_cap = h->e_cap;
         ca.tdbg = h->tdbg.as<long long>();
-        if (h->timing) {
-            if (h->tev_used + 2 > h->tev.size()) {
-                for (int k = 0; k < 256; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->tev.push_back(e); }
-            }
-            HIP_TRY(hipEventRecord(h->tev[h->tev_used], st));
-        }
+        if ((r = tev_begin(l))) return r;                        // kind l: conv-layer edge kernel of layer l
         r = h->wide_conv ? (small_tiles > 0 ? launch_conv_edge_small_wide(ca, h->EHT, h->HT, small_tiles, st)
                                             : launch_conv_edge_wide(ca, h->EHT, h->HT, h->n_cu, st))
             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st)
             : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3(ca, h->n_cu, st)
             : small_tiles > 0 ? launch_conv_edge_small(ca, small_tiles, st) : launch_conv_edge(ca, h->n_cu, st);
         if (r) return fail(-1, "conv edge launch failed (%d)", r);
-        if (h->timing) { HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st)); h->tev_used += 2; }
+        if ((r = tev_end())) return r;
         mark("conv_edge");
 
         no.mode = (l == h->L - 1) ? 2 : 1;
@@ -1240,16 +1252,34 @@ int32_t gamd_timing_enable(gamd_handle* h, int32_t enable) {
 
 int32_t gamd_timing_read(gamd_handle* h, void* stream, double* total_ms, int64_t* n_launches) {
     if (!h || !total_ms || !n_launches) return fail(-22, "null argument");
+    double ms[3];
+    int64_t cnt[3];
+    int r = gamd_timing_read_stages(h, stream, ms, cnt);
+    if (r) return r;
+    *total_ms = ms[0];
+    *n_launches = cnt[0];
+    return 0;
+}
+
+int32_t gamd_timing_read_stages(gamd_handle* h, void* stream, double total_ms[3], int64_t n[3]) {
+    if (!h || !total_ms || !n) return fail(-22, "null argument");
     DeviceGuard guard(h->dev);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    double tot = 0.0;
+    for (int k = 0; k < 3; ++k) { total_ms[k] = 0.0; n[k] = 0; }
     for (size_t i = 0; i + 1 < h->tev_used; i += 2) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, h->tev[i], h->tev[i + 1]));
-        tot += t;
+        const int kind = h->tev_kind[i];
+        const int slot = kind == 100 ? 1 : 0;
+        total_ms[slot] += t;
+        n[slot] += 1;
+        // the node kernel between two conv layers of one force evaluation: stop of layer l -> start of layer l + 1
+        if (kind != 100 && i + 3 < h->tev_used && h->tev_kind[i + 2] == kind + 1) {
+            HIP_TRY(hipEventElapsedTime(&t, h->tev[i + 1], h->tev[i + 2]));
+            total_ms[2] += t;
+            n[2] += 1;
+        }
     }
-    *total_ms = tot;
-    *n_launches = (int64_t)(h->tev_used / 2);
     return 0;
 }
 

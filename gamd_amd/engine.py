@@ -362,6 +362,13 @@ class GamdForce:
         check(self._lib.gamd_timing_read(self._h, self._stream(), C.byref(tot), C.byref(cnt)), "gamd_timing_read")
         return tot.value, cnt.value
 
+    def timing_read_stages(self):
+        """{stage: (summed ms, count)} since timing_enable(True) for 'conv_edge', 'edge_encode' and 'node_mid' (the node
+        kernel between two conv layers, kernel boundaries included); synchronises."""
+        ms, cnt = (C.c_double * 3)(), (C.c_int64 * 3)()
+        check(self._lib.gamd_timing_read_stages(self._h, self._stream(), ms, cnt), "gamd_timing_read_stages")
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(("conv_edge", "edge_encode", "node_mid"))}
+
     def profile(self, pos: ArrayLike, box=None, species=None):
         """Event-timed single forward: list of (kernel label, ms)."""
         p = self._dev_pos(pos)

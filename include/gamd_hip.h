@@ -241,6 +241,10 @@ int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* specie
  * enable.  Used by bench.py for roofline.achieved. */
 int32_t gamd_timing_enable(gamd_handle* h, int32_t enable);
 int32_t gamd_timing_read(gamd_handle* h, void* stream, double* total_ms, int64_t* n_launches);
+/* The same events split by stage: [0] conv-layer edge kernel (= gamd_timing_read), [1] edge encoder (its own event pair),
+ * [2] the node kernel between two conv layers (from the stop event of layer l to the start event of layer l + 1, so it
+ * includes the two kernel boundaries around it). */
+int32_t gamd_timing_read_stages(gamd_handle* h, void* stream, double total_ms[3], int64_t n_launches[3]);
 
 #ifdef __cplusplus
 }
