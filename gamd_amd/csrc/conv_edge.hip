@@ -210,21 +210,22 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             gemm128_post<false>((const f32x4*)buf1, lane, RB, RC,
                                 [&](int tp, int g) { RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]); });
             GEMM_PRIO(0);
-            // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge); the source index of
+            // hn[src] rows for phase 4 (row layout: lane = features 4 slot .. 4 slot + 3 -- W4's output rows are packed in
+            // that order, gamd_finalize_weights -- reg = edge): one 16-byte load per edge; the source index of
             // edge (half, r) lives in lane rho(r, half) of `src`
             if (!(V & CV_ABL_NO_HN)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
                     const int s = __shfl(src, rho, 64);
-                    const float* hrow = a.hn + (size_t)s * GAMD_H + slot;
+                    const f32x4 hv = *(const f32x4*)(a.hn + (size_t)s * GAMD_H + 4 * slot);
 #pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) RA[tp][r] = hrow[32 * tp];
+                    for (int tp = 0; tp < 4; ++tp) RA[r >> 2][(r & 3) * 4 + tp] = hv[tp];      // load lands in place
                 }
             }
             TMARK(4);
         }
-        if (active && !(V & CV_ABL_NO_HN)) phase_barrier<63>(); else phase_barrier<0>();
+        if (active && !(V & CV_ABL_NO_HN)) phase_barrier<16>(); else phase_barrier<0>();
         TMARK(5);
         // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
         stage(a.w4p, buf1);
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             GEMM_PRIO(1);
             gemm128_post<true>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
                 if (V & CV_ABL_P4_SILU) { RC[tp][r] = gamd_silu_hw(RC[tp][r]); return; }
-                const float prod = (r < nvalid) ? RA[tp][r] * RC[tp][r] : 0.f;
+                const float prod = (r < nvalid) ? RA[r >> 2][(r & 3) * 4 + tp] * RC[tp][r] : 0.f;
                 if (r == 0) RC[tp][0] = prod;
                 else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
             });
@@ -290,13 +291,15 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             if (pend_ends != 0) {
                 const int r = __builtin_ctz(pend_ends);
                 pend_ends &= pend_ends - 1;
+                f32x4 pv;
 #pragma unroll
                 for (int tp = 0; tp < 4; ++tp) {
                     float v = RC[tp][0];
 #pragma unroll
                     for (int k = 1; k < 16; ++k) v = (r == k) ? RC[tp][k] : v;
-                    a.partial[(size_t)pend_p * GAMD_H + 32 * tp + slot] = v;
+                    pv[tp] = v;
                 }
+                *(f32x4*)(a.partial + (size_t)pend_p * GAMD_H + 4 * slot) = pv;
                 ++pend_p;
             }
         }

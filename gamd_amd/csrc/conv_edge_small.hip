@@ -29,6 +29,9 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
     if ((long long)E > a.e_cap) E = (int)a.e_cap;
     const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
 
+    // feature of (output block ob, this wave's row `slot`) in phase 4: the 128-wide fp32 W4 is packed with its output rows
+    // permuted (packed row 32 q + s = feature 4 s + q, what conv_edge.hip's 16-byte hn loads / piece stores want)
+    auto feat4 = [&](int ob) { return WIDE ? 128 * ob + 32 * quarter + slot : 4 * slot + quarter; };
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
@@ -59,7 +62,7 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
             const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int s = __shfl(src, rho, 64);
 #pragma unroll
-            for (int ob = 0; ob < HT; ++ob) hn_q[ob][r] = a.hn[(size_t)s * H + 128 * ob + 32 * quarter + slot];
+            for (int ob = 0; ob < HT; ++ob) hn_q[ob][r] = a.hn[(size_t)s * H + feat4(ob)];
         }
         const unsigned mask = a.chunk_mask[tile * 2 + half];
         const int p0 = a.chunk_piece[tile * 2 + half];
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = gamd_silu_hw(acc[r]);
         exchange(xbuf, quarter, slot, half, acc, X);
-        // phase 4 (F2: lane = feature 128 ob + 32 quarter + slot, register = edge): e_emb, message, segment sum
+        // phase 4 (F2: lane = feature feat4(ob), register = edge): e_emb, message, segment sum
         const unsigned keep_bits = ~(mask << 1);
         unsigned ends0 = mask;
         if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends0 |= 1u << (nvalid - 1);
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
                     float v = acc[0];
 #pragma unroll
                     for (int k = 1; k < 16; ++k) v = (r == k) ? acc[k] : v;
-                    a.partial[(size_t)p * H + 128 * ob + 32 * quarter + slot] = v;
+                    a.partial[(size_t)p * H + feat4(ob)] = v;
                     ++p;
                 }
             }

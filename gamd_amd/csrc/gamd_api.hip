@@ -797,6 +797,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             !pdb || !pew || !peb || !phw || !phb || !ng || !nb)
             return -2;
         Off& o = lo[l];
+        HostTensor b4_perm;
         if (bf16_edges) {
             o.w1p = put_edge_bf16(ea0w); o.w2p = put_edge_bf16(ea2w); o.w3p = put_edge_bf16(t1w); o.w4p = put_edge_bf16(t3w);
         } else if (f16x3_edges) {
@@ -806,7 +807,23 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             o.w1p = put_blocks(ea0w, 1, (int)EHT);
             o.w2p = put_blocks(ea2w, 1, 1);
             o.w3p = put_blocks(t1w, 1, 1);
-            o.w4p = put_blocks(t3w, (int)HT, 1);
+            if (h->wide_conv) {
+                o.w4p = put_blocks(t3w, (int)HT, 1);
+            } else {
+                // 128-wide kernels (conv_edge.hip, conv_edge_small.hip): output row 32 q + s of the packed W4 is feature
+                // 4 s + q, so a lane of the last GEMM's F2 output holds four CONSECUTIVE features of each edge — hn[src]
+                // is gathered and the pieces are stored 16 bytes at a time.  b4 is stored in the same order.
+                HostTensor wp = *t3w;
+                b4_perm = *t3b;
+                for (int q = 0; q < 4; ++q)
+                    for (int s = 0; s < 32; ++s) {
+                        std::copy(t3w->data.begin() + (size_t)(4 * s + q) * 128, t3w->data.begin() + (size_t)(4 * s + q + 1) * 128,
+                                  wp.data.begin() + (size_t)(32 * q + s) * 128);
+                        b4_perm.data[32 * q + s] = t3b->data[4 * s + q];
+                    }
+                o.w4p = put_blocks(&wp, 1, 1);
+                t3b = &b4_perm;
+            }
         }
         o.b1 = put_vec(ea0b); o.b3 = put_vec(t1b); o.b4 = put_vec(t3b);
         o.lng = put_vec(ng); o.lnb = put_vec(nb);
