@@ -88,23 +88,27 @@ __device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, in
 // Kernel variants (template bit mask).  CV_TIME is the s_memtime instrumentation; the others are scheduling choices
 // that do not change any result bit.  The release library instantiates CONV_PRODUCTION only; libgamd_hip_prof.so
 // (-DGAMD_PROFILING) also builds the other combinations and selects one with GAMD_CONV_VARIANT for A/B timing.
+// (Round-2 variants that were measured and dropped — DMA by waves 4-7 only, s_setprio schemes, gather / store ablations —
+// are recorded in profiles/r02_conv_edge_experiments.md.)
 enum {
-    CV_TIME = 1,        // per-segment cycle counters -> a.tdbg
-    CV_ASYM_DMA = 2,    // the weight DMA of a phase is issued by waves 4-7 only (16 x 1 KiB each): waves 0-3, which the
-                        // SIMD arbiter serves first after a barrier, go straight to their first MFMA
-    CV_PRIO_YOUNG = 8,  // static s_setprio 1 for waves 4-7
-    CV_PRIO_GEMM = 16,  // s_setprio 1 around every wave's own MFMA stream
-    // timing ablations (WRONG results; profiling build only)
-    CV_ABL_NO_EPF = 32,     // no prefetch of the next tile's e (loaded after the barrier instead: exposed)
-    CV_ABL_P4_SILU = 64,    // phase 4's message / segment-sum post-op replaced by phase 3's SiLU
-    CV_ABL_NO_HN = 128,     // hn[src] gathers skipped
-    CV_ABL_NO_SD = 256,     // S[src] / D[dst] gathers skipped
-    CV_ABL_NO_STORE = 512,  // piece stores skipped
+    CV_TIME = 1,         // per-segment cycle counters -> a.tdbg
+    CV_SYM_GATHER = 2,   // every wave issues its gathers BEFORE the phase barrier (round-1 schedule; see below)
+    CV_TRACKED_DMA = 4,  // the weight copy through __builtin_amdgcn_global_load_lds (compiler-tracked: see gamd_stage_weight_raw)
 };
 #ifndef CONV_PRODUCTION
 #define CONV_PRODUCTION 0
 #endif
 
+// Gather schedule.  Of the two waves of a SIMD the one with the lower id is served first after a barrier (measured:
+// waves 0-3 wait ~18 000 ticks at the barrier behind their own GEMM, waves 4-7 wait as long in front of theirs).  A gather
+// (32 distinct rows per instruction) or a streaming prefetch occupies the CU's address path for thousands of cycles, and the
+// weight copy of the next phase — which every wave must get issued before its first MFMA — queues behind whatever was
+// issued last.  So:
+//   * waves 0-3 issue the gathers for the next phase right after their GEMM, BEFORE the barrier: the address path is idle
+//     then (waves 4-7 are in their GEMM) and the loads are long done when the barrier opens;
+//   * waves 4-7 reach the barrier last; gathers issued there would sit in the queue in front of everybody's weight copy.
+//     They issue them AFTER the barrier and after their own weight copy, at the start of the phase, where they have a whole
+//     GEMM of waiting in front of them anyway.
 template <int V>
 __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     constexpr bool TIME = (V & CV_TIME) != 0;
@@ -130,26 +134,26 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     if (first >= end) return;
     const int n_iter = ((end - first + step - 1) / step + 1) / 2;
     const int wsub = wave & 3, whalf = wave >> 2;
+    const bool early = (V & CV_SYM_GATHER) ? true : whalf == 0;       // gathers before (true) / after (false) the barrier
     auto tile_of = [&](int it) {              // this wave's tile in iteration `it`, or n_tiles (inactive)
         const int u = first + (2 * it + whalf) * step;
         return (it < n_iter && u < end) ? u * 4 + wsub : n_tiles;
     };
     // L2 -> LDS copy of the next phase's weight matrix
     auto stage = [&](const float* gw, float* buf) {
-        if (V & CV_ASYM_DMA) { if (whalf == 1) gamd_stage_weight<4>(gw, buf, wsub, lane16); }
-        else gamd_stage_weight<8>(gw, buf, wave, lane16);
+        if (V & CV_TRACKED_DMA) gamd_stage_weight<8>(gw, buf, wave, lane16);
+        else gamd_stage_weight_raw<8>(gw, buf, wave, lane16);
     };
-    if (V & CV_PRIO_YOUNG) { if (whalf == 1) __builtin_amdgcn_s_setprio(1); }
 
     long long tacc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) tacc[i] = 0;
     long long tprev = 0;
 #define TMARK(i) do { if (TIME) { const long long tn__ = (long long)__builtin_readcyclecounter(); tacc[i] += tn__ - tprev; tprev = tn__; } } while (0)
-#define GEMM_PRIO(p) do { if (V & CV_PRIO_GEMM) __builtin_amdgcn_s_setprio(p); } while (0)
 
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
     stage(a.w1p, buf0);
+    stage(a.w2p, buf1);                          // phase 1's copy (inside the loop it is issued at the previous tile's boundary 4)
 
     // three 64-register sets rotate through the roles {GEMM input, GEMM output, prefetched gather}
     f32x16 RA[4], RB[4], RC[4];
@@ -171,13 +175,41 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
         if (active) {
             load_e_tile(a.e_frag, tile, lane, RA);
-            if (!(V & CV_ABL_NO_SD)) load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
+            load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
         }
     }
+    asm volatile("" ::"v"(src), "v"(dst));      // compiler-visible wait for the index loads (see phase 4)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (TIME) tprev = (long long)__builtin_readcyclecounter();
     unsigned pend_ends = 0;           // piece stores of the tile just finished (issued after its last barrier)
     int pend_p = 0;
+
+    // S[src] rows, phase 2's post-op (chain layout, -> RA)
+    auto gather_S = [&]() { load_row_chain(a.S + (size_t)src * GAMD_H, half, RA); };
+    // hn[src] rows for phase 4 (-> RA; row layout: lane = features 4 slot .. 4 slot + 3 -- W4's output rows are packed in
+    // that order, gamd_finalize_weights -- reg = edge): one 16-byte load per edge; the source index of edge (half, r)
+    // lives in lane rho(r, half) of `src`
+    auto gather_hn = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int s = __shfl(src, rho, 64);
+            const f32x4 hv = *(const f32x4*)(a.hn + (size_t)s * GAMD_H + 4 * slot);
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) RA[r >> 2][(r & 3) * 4 + tp] = hv[tp];      // load lands in place
+        }
+    };
+
+    // Phase boundary: barrier (every wave's share of the weight copy issued one boundary earlier has landed: at most N
+    // younger VMEM operations may still be in flight) + the copy for the phase after the next barrier.  Waves that gather
+    // early pass it AFTER their gathers, the others BEFORE: the branch is around the barrier, not around the loads, so
+    // both groups run the same gather code into the same registers.
+#define BOUNDARY(COND, N, STAGE_STMT)                               \
+    do {                                                            \
+        if (COND) phase_barrier<N>(); else phase_barrier<0>();      \
+        STAGE_STMT;                                                 \
+    } while (0)
 
     for (int it = 0; it < n_iter; ++it) {
         const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
@@ -189,46 +221,33 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         int src_n = 0, dst_n = 0;
 
         // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====
-        stage(a.w2p, buf1);
+        // (W2 -> buf1 was issued at the previous boundary)
         if (active) {
             load_bias_chain(vb1, half, RB);
             TMARK(0);
-            GEMM_PRIO(1);
             gemm128_post<false>((const f32x4*)buf0, lane, RA, RB,
                                 [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
-            GEMM_PRIO(0);
-            if (!(V & CV_ABL_NO_SD)) load_row_chain(a.S + (size_t)src * GAMD_H, half, RA);        // for phase 2's post-op
             TMARK(1);
         }
-        if (active && !(V & CV_ABL_NO_SD)) phase_barrier<16>(); else phase_barrier<0>();
+        // boundary 1: S[src] -> RA for phase 2's post-op; W3 -> buf0.  Younger than the copy of W2: e, D (late) / D, S (early)
+        if (!early) BOUNDARY(active, 16, stage(a.w3p, buf0));
         TMARK(2);
+        if (active) gather_S();
+        TMARK(3);
+        if (early) BOUNDARY(active, 16, stage(a.w3p, buf0));
         // ===== phase 2: RC = SiLU(W2 T1 + D[dst] + S[src])        in RB, S in RA =====
-        stage(a.w3p, buf0);
         if (active) {
-            TMARK(3);
-            GEMM_PRIO(1);
             gemm128_post<false>((const f32x4*)buf1, lane, RB, RC,
                                 [&](int tp, int g) { RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]); });
-            GEMM_PRIO(0);
-            // hn[src] rows for phase 4 (row layout: lane = features 4 slot .. 4 slot + 3 -- W4's output rows are packed in
-            // that order, gamd_finalize_weights -- reg = edge): one 16-byte load per edge; the source index of
-            // edge (half, r) lives in lane rho(r, half) of `src`
-            if (!(V & CV_ABL_NO_HN)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int s = __shfl(src, rho, 64);
-                    const f32x4 hv = *(const f32x4*)(a.hn + (size_t)s * GAMD_H + 4 * slot);
-#pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) RA[r >> 2][(r & 3) * 4 + tp] = hv[tp];      // load lands in place
-                }
-            }
             TMARK(4);
         }
-        if (active && !(V & CV_ABL_NO_HN)) phase_barrier<16>(); else phase_barrier<0>();
+        // boundary 2: hn[src] -> RA for phase 4; W4 -> buf1.  Younger than the copy of W3: S (late) / hn (early)
+        if (!early) BOUNDARY(active, 16, stage(a.w4p, buf1));
         TMARK(5);
+        if (active) gather_hn();
+        TMARK(6);
+        if (early) BOUNDARY(active, 16, stage(a.w4p, buf1));
         // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
-        stage(a.w4p, buf1);
         unsigned mask = 0;
         int p0 = 0;
         // small index loads for phase 4 / the next tile go first: done long before the barrier needs vmcnt(0)
@@ -242,51 +261,48 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         }
         if (active) {
             load_bias_chain(vb3, half, RB);
-            TMARK(6);
-            GEMM_PRIO(1);
+            TMARK(7);
             gemm128_post<false>((const f32x4*)buf0, lane, RC, RB,
                                 [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
-            GEMM_PRIO(0);
-            TMARK(7);
+            TMARK(8);
         }
+        // boundary 3 (nothing to gather): everything has landed behind it
         phase_barrier<0>();
-        TMARK(8);
+        // The index loads of phase 3 are complete, but hipcc cannot see a wait written in assembly: it would keep them on
+        // its scoreboard and later flush vmcnt(0) — in front of the piece-store loop, at the next tile's first use of src,
+        // and before it re-initialises src_n.  Naming the registers here makes it emit its wait now, where it costs nothing.
+        asm volatile("" ::"v"(mask), "v"(p0), "v"(src_n), "v"(dst_n));
+        stage(a.w1p, buf0);       // next tile's W1 (harmless on the last iteration: drained at boundary 4)
+        TMARK(9);
         // ===== phase 4: RC = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
-        stage(a.w1p, buf0);       // next tile's W1 (harmless on the last iteration)
         if (active) {
             init_b4();
-            TMARK(9);
             // e_emb for this lane's 16 edges x 4 features, then message + segment sum (nn_module.py:142
             // u_mul_e -> sum).  In-stream part is branch-free: RC[tp][r] becomes the running sum of the
             // messages of the current piece (reset after every edge that closes a destination segment).
             const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
-            GEMM_PRIO(1);
             gemm128_post<true>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
-                if (V & CV_ABL_P4_SILU) { RC[tp][r] = gamd_silu_hw(RC[tp][r]); return; }
                 const float prod = (r < nvalid) ? RA[r >> 2][(r & 3) * 4 + tp] * RC[tp][r] : 0.f;
                 if (r == 0) RC[tp][0] = prod;
                 else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
             });
-            GEMM_PRIO(0);
-            // piece stores are deferred past the barrier (vmcnt counts stores too: issued here they would sit
-            // in front of the prefetch loads and the counted wait below would wait for their write latency)
+            // piece stores are deferred past the boundary (vmcnt counts stores too: issued here they would sit in front of
+            // the prefetch loads and a counted wait would wait for their write latency)
             pend_ends = mask;
             if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) pend_ends |= 1u << (nvalid - 1);
             pend_p = p0;
             TMARK(10);
         }
-        // prefetch the next tile's e (-> RA): in flight across the barrier
-        if (active_n && !(V & CV_ABL_NO_EPF)) load_e_tile(a.e_frag, tile_n, lane, RA);
-        TMARK(12);
-        if (active_n && !(V & CV_ABL_NO_EPF)) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        TMARK(13);
-        __builtin_amdgcn_s_barrier();
+        // boundary 4: the next tile's e -> RA; its W2 -> buf1 (not behind the last tile: a copy must not outlive the
+        // workgroup).  Younger than the copy of W1: nothing (late) / e (early)
+        if (!early) BOUNDARY(false, 0, if (it + 1 < n_iter) stage(a.w2p, buf1));
         TMARK(11);
-        if (active_n && (V & CV_ABL_NO_EPF)) load_e_tile(a.e_frag, tile_n, lane, RA);
+        if (active_n) load_e_tile(a.e_frag, tile_n, lane, RA);
+        TMARK(12);
+        if (early) BOUNDARY(active_n, 16, if (it + 1 < n_iter) stage(a.w2p, buf1));
+        TMARK(13);
         // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge does
         // not close a segment, that edge too (the run continues in the next chunk as its own piece)
-        if (V & CV_ABL_NO_STORE) pend_ends = 0;
         while (__any(pend_ends != 0)) {
             if (pend_ends != 0) {
                 const int r = __builtin_ctz(pend_ends);
@@ -304,16 +320,16 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             }
         }
         // D[dst] of the next tile (C-in of its phase 2) -> RC, now free; lands during phase 1
-        if (active_n && !(V & CV_ABL_NO_SD)) load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
+        if (active_n) load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
         TMARK(14);
         tile = tile_n; active = active_n; src = src_n; dst = dst_n;
     }
+#undef BOUNDARY
     if (TIME && a.tdbg && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) a.tdbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = tacc[i];
     }
 #undef TMARK
-#undef GEMM_PRIO
 }
 
 template <int V>
@@ -338,8 +354,7 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     if (v < 0) { const char* s = getenv("GAMD_CONV_VARIANT"); v = s ? atoi(s) : CONV_PRODUCTION; }
     switch (v) {
 #define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
-        CASE(0); CASE(1); CASE(2); CASE(8); CASE(16); CASE(33); CASE(65); CASE(129); CASE(257); CASE(513); CASE(993);
-        CASE(32); CASE(64); CASE(128); CASE(256); CASE(512); CASE(992);
+        CASE(0); CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7);
 #undef CASE
         default: break;
     }

@@ -242,6 +242,25 @@ __device__ __forceinline__ void gamd_stage_weight(const float* __restrict__ gw, 
     }
 }
 
+// The same copy issued from inline assembly, i.e. INVISIBLE to hipcc's s_waitcnt insertion.  For a tracked
+// global_load_lds (FLAT encoding, touches both global memory and LDS) the compiler keeps a "pending flat" state that
+// turns the next wait of ANY kind — e.g. the lgkmcnt wait of the first weight ds_read of the phase — into
+// `s_waitcnt vmcnt(0) lgkmcnt(0)`: every wave would sit out the full L2 -> LDS round trip of the copy it has just issued,
+// for the NEXT phase, before its first MFMA.  Callers own the ordering: the data may be read only after an explicit counted
+// `s_waitcnt vmcnt(N)` (N = VMEM ops the wave issued after this copy) and a workgroup barrier.  Compiler-generated vmcnt
+// waits for other loads stay correct (they do not count these eight ops, so they can only wait longer, never shorter).
+template <int NW = 8>
+__device__ __forceinline__ void gamd_stage_weight_raw(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf;
+#pragma unroll
+    for (int k = 0; k < 64 / NW; ++k) {
+        const int chunk = k * NW + wave;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     ::"v"(lane16), "s"(reinterpret_cast<const char*>(gw) + chunk * 1024), "s"(lds0 + chunk * 1024u)
+                     : "memory");
+    }
+}
+
 // Latency-oriented split of a 32-row tile over the 4 waves of a 256-thread workgroup (node.hip, conv_edge_small.hip,
 // wide.hip's node kernel): wave `quarter` computes output features [32 quarter, 32 quarter + 32) of every GEMM from its
 // 16 KiB weight quarter, fetched from L2 in ONE batch of 16 float4 per lane (a GEMM then costs one L2 round trip, not

@@ -14,10 +14,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so")
-SEGMENTS = ["p1 pre (DMA issue, bias)", "p1 gemm+post+S gather issue", "p1 barrier", "p2 pre (DMA issue)",
-            "p2 gemm+post+hn gather issue", "p2 barrier", "p3 pre (DMA, idx loads, bias)", "p3 gemm+post", "p3 barrier",
-            "p4 pre (DMA issue, b4)", "p4 gemm+segment-sum", "p4 s_barrier", "p4 e-prefetch issue", "p4 vmcnt wait",
-            "piece stores + D gather issue"]
+SEGMENTS = ["p1 bias init", "p1 gemm+post", "boundary 1 (late waves: barrier + DMA issue)", "S gather issue",
+            "boundary 1 (early waves) + p2 gemm+post", "boundary 2 (late waves)", "hn gather issue",
+            "boundary 2 (early waves) + idx loads + bias", "p3 gemm+post", "boundary 3 + DMA issue", "p4 gemm+segment-sum",
+            "boundary 4 (late waves)", "e-prefetch issue", "boundary 4 (early waves)", "piece stores + D gather issue"]
 
 
 def child():
