@@ -13,7 +13,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so")
+PROF = os.environ.get("CV_LIB") or os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so")
 SEGMENTS = ["p1 bias init", "p1 gemm+post", "boundary 1 (late waves: barrier + DMA issue)", "S gather issue",
             "boundary 1 (early waves) + p2 gemm+post", "boundary 2 (late waves)", "hn gather issue",
             "boundary 2 (early waves) + idx loads + bias", "p3 gemm+post", "boundary 3 + DMA issue", "p4 gemm+segment-sum",
