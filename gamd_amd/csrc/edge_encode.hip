@@ -110,20 +110,28 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
     // geometry of the first tile; every iteration then prefetches the next tile's indices and positions
     // (a three-deep dependent load chain) behind the current tile's GEMMs
     int E32 = (int)E;
-    auto fetch_idx = [&](int tile, int& src, int& dst) {
+    // Unconditional loads from a clamped index (E >= 1 whenever the loop runs), the validity applied where the value is
+    // used: "r = 0; if (ok) r = load" makes hipcc guard the re-initialisation of r against the previous load into it —
+    // with the stores of e in flight that guard is an s_waitcnt vmcnt(0) at the top of every tile.
+    auto fetch_idx = [&](int tile, int& src, int& dst) -> bool {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
-        src = 0; dst = 0;
-        if (tile < n_tiles && x < E32) { src = a.col[x]; dst = a.erow[x]; }
+        const bool ok = tile < n_tiles && x < E32;
+        const int xc = ok ? x : 0;
+        src = a.col[xc]; dst = a.erow[xc];
+        return ok;
     };
     int src_c, dst_c;
-    fetch_idx(tile_of(0), src_c, dst_c);
+    {
+        const bool ok = fetch_idx(tile_of(0), src_c, dst_c);
+        src_c = ok ? src_c : 0; dst_c = ok ? dst_c : 0;
+    }
     float4 ps = a.pos_s[src_c], pd = a.pos_s[dst_c];
 
     for (int it = 0; it < n_iter; ++it) {
         const int tile = tile_of(it);
         int src_n, dst_n;
-        fetch_idx(tile_of(it + 1), src_n, dst_n);
-        if (tile >= n_tiles) continue;
+        const bool ok_n = fetch_idx(tile_of(it + 1), src_n, dst_n);
+        if (tile >= n_tiles) { asm volatile("" ::"v"(src_n), "v"(dst_n)); continue; }      // (consumed on this path too)
         const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
         const int src = src_c, dst = dst_c;
@@ -153,6 +161,12 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         load_bias_chain(vb2, half, acc);
         gemm128<false>((const f32x4*)w2, lane, X, acc);
         gelu_block<ABL>(acc, X);
+        // next tile's positions (its indices were fetched at the top of this iteration); consumed at the top of the next
+        // iteration.  Issued HERE and waited for just before the stores of e below: with loads and stores both in flight hipcc
+        // can only wait with vmcnt(0), i.e. a wait for these two loads placed behind the stores would sit out the write
+        // latency of the whole 16 KiB tile.
+        src_c = ok_n ? src_n : 0; dst_c = ok_n ? dst_n : 0;
+        ps = a.pos_s[src_c]; pd = a.pos_s[dst_c];
         // ---- GEMM 3 + LayerNorm ----
         load_bias_chain(vb3, half, acc);
         gemm128<false>((const f32x4*)w3, lane, X, acc);
@@ -168,9 +182,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
             }
         }
         // ---- store e fragment: 16 x 1 KiB coalesced ----
-        // next tile's positions (indices arrived long ago); consumed at the top of the next iteration
-        src_c = src_n; dst_c = dst_n;
-        ps = a.pos_s[src_c]; pd = a.pos_s[dst_c];
+        asm volatile("" ::"v"(ps.x), "v"(ps.y), "v"(ps.z), "v"(ps.w), "v"(pd.x), "v"(pd.y), "v"(pd.z), "v"(pd.w));
         f32x4* out = (f32x4*)a.e_frag + (size_t)tile * 16 * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t)

@@ -9,7 +9,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so")
+PROF = os.environ.get("CV_LIB") or os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so")
 
 
 def child():
