@@ -50,21 +50,22 @@ __global__ void k_bin(NbrArgs a) {
     if (i < a.n) d_bin(a, i);
 }
 
-// single-block exclusive scan, any length; out has n+1 entries (out[n] = total).  4 items per thread
-// per pass (4096 per pass), wave shuffles + one LDS hop.
+// single-block exclusive scan, any length; out has n+1 entries (out[n] = total).  4 consecutive items per thread per
+// pass (4 096 per pass), wave shuffles + one LDS hop.
 template <typename F>
 __device__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
+    constexpr int IPT = 4;
     __shared__ int wave_tot[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 4096) {
-        const int i0 = base + tid * 4;
-        int v[4];
+    for (int base = 0; base < n; base += 1024 * IPT) {
+        const int i0 = base + tid * IPT;
+        int v[IPT];
+        int mine = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? load(i0 + k) : 0;
-        const int mine = (v[0] + v[1]) + (v[2] + v[3]);
+        for (int k = 0; k < IPT; ++k) { v[k] = (i0 + k < n) ? load(i0 + k) : 0; mine += v[k]; }
         int x = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -78,7 +79,7 @@ __device__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
         const int carry = carry_s;
         int run = carry + woff + x - mine;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < IPT; ++k) {
             if (i0 + k < n) out[i0 + k] = run;
             run += v[k];
         }
@@ -214,7 +215,79 @@ __global__ void __launch_bounds__(256) k_count(NbrArgs a) {
 
 // row_ptr = exscan(deg); NA = inclusive count of non-empty segments that start off a chunk boundary;
 // publishes E, the piece count and the overflow flag.
+// The same two scans for n <= 16 384 in ONE pass over registers: 16 consecutive rows per thread (four 16-byte loads), row_ptr
+// and the off-boundary flags derived from it never leave the thread between the two scans — the multi-pass form above
+// re-reads row_ptr through L2 and needs 6 passes with 4 workgroup barriers each at n = 10 000 (17 us -> see DESIGN).
+__device__ void d_scan_deg_fast(const NbrArgs& a) {
+    constexpr int IPT = 16;
+    __shared__ int s_tot[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = tid * IPT;
+    int v[IPT];
+    if (i0 + IPT <= a.n) {
+#pragma unroll
+        for (int q = 0; q < IPT / 4; ++q) {
+            const int4 t = *reinterpret_cast<const int4*>(a.deg + i0 + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) v[k] = (i0 + k < a.n) ? a.deg[i0 + k] : 0;
+    }
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) mine += v[k];
+    int x = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) s_tot[0][wv] = x;
+    __syncthreads();
+    int run = x - mine, E_all = 0;
+    for (int w = 0; w < 16; ++w) { const int t = s_tot[0][w]; if (w < wv) run += t; E_all += t; }
+    int f[IPT], mine2 = 0;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int rp = run;
+        if (i0 + k < a.n) a.row_ptr[i0 + k] = rp;
+        f[k] = (a.cand_pass == 0 && i0 + k < a.n && v[k] > 0 && (rp % GAMD_CHUNK) != 0) ? 1 : 0;
+        mine2 += f[k];
+        run += v[k];
+    }
+    if (tid == 0) a.row_ptr[a.n] = E_all;
+    if (a.cand_pass) {                                     // candidate CSR: only its size and overflow matter
+        if (tid == 0) {
+            a.counters[CNT_NCAND] = E_all;
+            a.sticky[STICKY_NCAND] = E_all;
+            if ((long long)E_all > a.e_cap) { a.sticky[STICKY_CAND_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1; }
+            a.sticky[STICKY_REBUILDS] += 1;
+        }
+        return;
+    }
+    int y2 = mine2;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(y2, d, 64); if (lane >= d) y2 += y; }
+    if (lane == 63) s_tot[1][wv] = y2;
+    __syncthreads();
+    int run2 = y2 - mine2, NA_all = 0;
+    for (int w = 0; w < 16; ++w) { const int t = s_tot[1][w]; if (w < wv) run2 += t; NA_all += t; }
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        if (i0 + k < a.n) a.na_excl[i0 + k] = run2;
+        run2 += f[k];
+    }
+    if (tid == 0) {
+        a.na_excl[a.n] = NA_all;
+        a.counters[CNT_E] = E_all;
+        a.counters[CNT_PIECES] = (E_all + GAMD_CHUNK - 1) / GAMD_CHUNK + NA_all;
+        if ((long long)E_all > a.e_cap) {
+            a.counters[CNT_OVERFLOW] = 1; a.sticky[STICKY_EDGE_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1;
+        }
+        a.counters[CNT_TILES] = (E_all + GAMD_TILE - 1) / GAMD_TILE;
+    }
+}
+
 __device__ void d_scan_deg(const NbrArgs& a) {
+    if (a.n <= 16 * 1024) { d_scan_deg_fast(a); return; }
     block_exclusive_scan(a.n, [&](int i) { return a.deg[i]; }, a.row_ptr);
     __syncthreads();
     if (a.cand_pass) {                                     // candidate CSR: only its size and overflow matter

@@ -350,6 +350,37 @@ def test_small_system_fused_md_overflow_freezes_and_resumes():
         assert np.isfinite(b).all() and rel_err(b, a) < 1e-4
 
 
+def test_more_than_16384_atoms_take_the_multi_pass_row_scan():
+    """Up to 16 384 atoms the row scan (row_ptr, piece numbering) is one pass over registers; above that the generic
+    multi-pass scan.  20 000 atoms: the edge set against an independent periodic KD-tree, the CSR invariants, and the forces
+    against the CPU oracle on the same edges (the piece metadata decides which partial sums belong to which atom)."""
+    from scipy.spatial import cKDTree
+    n, rc = 20000, 6.0
+    pos, box = workloads.lj_box(n, seed=77)
+    sd = make_state_dict(ModelConfig(kind="lj"), 1, 5.0, 1.7)
+    p = torch.from_numpy(pos).float()
+    for kw in ({}, dict(neighbor_skin=rc / 6)):
+        eng = _engine(sd, n, box, rc, **kw)
+        out = eng.forward(p).cpu().numpy()
+        edges = eng.debug_edges()
+        row_ptr, col = eng.debug_csr()
+        assert row_ptr[0] == 0 and row_ptr[-1] == edges.shape[1] == eng.counts()[0] and np.all(np.diff(row_ptr) > 0)
+        w = np.mod(p.numpy().astype(np.float64), box)
+        w[w >= box] = 0.0
+        tree = cKDTree(w, boxsize=box)
+        loops = np.tile(np.arange(n), (2, 1))
+
+        def directed(r):
+            pr = tree.query_pairs(r, output_type="ndarray").T
+            return set(map(int, edge_set(np.concatenate([pr, pr[::-1], loops], axis=1))))
+        # fp32 positions on the GPU, fp64 here: pairs within 1e-3 of the cutoff may fall on either side
+        got = set(map(int, edge_set(edges)))
+        inner, outer = directed(rc - 1e-3), directed(rc + 1e-3)
+        assert inner <= got <= outer and len(outer) - len(inner) < 2000
+        assert rel_err(out, orc.forward(sd, p, torch.from_numpy(edges).long(), box).numpy()) < TOL
+        eng.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # argument checks of the MD entry points (they used to skip what gamd_forces_async checks)
 # ---------------------------------------------------------------------------------------------------------------
