@@ -384,10 +384,12 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     };
     int r;
     mark("begin");
-    // small systems with Verlet-skin reuse: ping-pong counter blocks, 4 neighbour launches per call (neighbor.hip)
-    const bool small_skin = !el && h->skin > 0.f && h->n <= 1024;
+    // Verlet-skin reuse: ping-pong counter blocks instead of a memset node per call; n <= 1024: 4 neighbour launches per call
+    // with the integrator halves folded in (neighbor.hip)
+    const bool pingpong = !el && h->skin > 0.f;
+    const bool small_skin = pingpong && h->n <= 1024;
     int* counters_next = nullptr;
-    if (small_skin) {
+    if (pingpong) {
         h->cnt_parity ^= 1;
         h->cur_counters = h->cnt2.as<int>() + h->cnt_parity * CNT_COUNT;
         counters_next = h->cnt2.as<int>() + (1 - h->cnt_parity) * CNT_COUNT;

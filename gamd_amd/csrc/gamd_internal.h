@@ -49,7 +49,7 @@ struct NbrArgs {
     int* chunk_piece;      // [(e_cap+32)/16]
     unsigned* chunk_mask;  // [(e_cap+32)/16]
     int* counters;         // [CNT_COUNT]
-    int* counters_next;    // small-system skin path: the OTHER counter block of the ping-pong pair, cleared by k_skin_check
+    int* counters_next;    // skin path: the OTHER counter block of the ping-pong pair, cleared by k_skin_check / k_step_small
                            // for the next call (no per-call memset node in the stream); null otherwise
     int* sticky;           // [STICKY_COUNT] host-mapped
     // Verlet-skin reuse (graph_utils.py:21-25,36-44: build with cutoff + dr_threshold, rebuild when an atom has moved

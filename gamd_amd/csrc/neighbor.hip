@@ -338,6 +338,9 @@ __device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l) {
 __global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
     GAMD_GATE();
     d_fill(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31);
+    // last kernel of a cell-list build: the cell counters are not read any more (the sweep uses cell_start) and are left
+    // ZERO for the next build, so the skin path needs no memset node per step
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.ncell; k += gridDim.x * blockDim.x) { a.cell_cnt[k] = 0; a.cell_fill[k] = 0; }
 }
 
 // per 16-edge chunk: first piece id and the bit mask of edges that close a destination segment
@@ -394,6 +397,7 @@ __device__ __forceinline__ bool d_skin_check(const NbrArgs& a, int i) {
 
 __global__ void k_skin_check(NbrArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.counters_next && i < CNT_COUNT) a.counters_next[i] = 0;      // ping-pong counter blocks: no memset node
     if (i >= a.n) return;
     if (d_skin_check(a, i)) a.counters[CNT_REBUILD] = 1;
 }
@@ -666,7 +670,7 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
 int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     hipError_t e;
     const int tb = 256, gb = (a.n + tb - 1) / tb, ga = (a.n + 7) / 8;
-    if (a.counters_next) {
+    if (a.counters_next && a.n <= 1024) {
         // small system (n <= 1024): 3 launches and no memset node instead of 13 + 1 (+ 2 integrator launches): counters
         // ping-pong, cell arrays cleared inside the rebuild, integrator halves folded in
         MdArgs md{};
@@ -679,7 +683,9 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
         hipLaunchKernelGGL(k_filter_fill_small, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
         return 0;
     }
-    e = hipMemsetAsync(a.counters, 0, sizeof(int) * (CNT_COUNT + 2 * (size_t)a.ncell_cap), st); if (e) return (int)e;
+    if (fuse) return -22;                                     // integrator halves ride in k_step_small only
+    // counters: ping-pong blocks (k_skin_check clears the other one) or one memset; the cell counters are left zero by k_fill
+    if (!a.counters_next) { e = hipMemsetAsync(a.counters, 0, sizeof(int) * CNT_COUNT, st); if (e) return (int)e; }
     hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
     // candidate rebuild with rc + skin, every kernel gated on the flag k_skin_check has just written
     NbrArgs c = a;
