@@ -387,7 +387,6 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     // Verlet-skin reuse: ping-pong counter blocks instead of a memset node per call; n <= 1024: 4 neighbour launches per call
     // with the integrator halves folded in (neighbor.hip)
     const bool pingpong = !el && h->skin > 0.f;
-    const bool small_skin = pingpong && h->n <= 1024;
     int* counters_next = nullptr;
     if (pingpong) {
         h->cnt_parity ^= 1;
@@ -405,7 +404,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     } else if (h->skin > 0.f) {
         na.ref_pos = h->ref_pos.as<float4>();
         na.force_rebuild = h->cand_valid ? 0 : 1;
-        if (fuse && !small_skin) return fail(-1, "internal: integrator halves can only be fused into the small-system path");
+        if (fuse && !pingpong) return fail(-1, "internal: integrator halves can only be fused into the skin path");
         if ((r = launch_neighbor_skin(na, st, fuse))) return fail(-1, "neighbor (skin) launch failed (%d)", r);
         h->cand_valid = true;
     } else if ((r = launch_neighbor_build(na, st))) return fail(-1, "neighbor build launch failed (%d)", r);
@@ -573,9 +572,9 @@ int clear_devflags(gamd_handle* h) {
 int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
     MdPending& p = h->pending;
     int r;
-    // Small systems (n <= 1024) in skin mode, plain BAOAB: the B of step s-1 and the B A O A of step s ride in the first
-    // kernel of step s's force evaluation (k_step_small): 2 launches less per step; the last B is launched on its own.
-    if (p.kind == 0 && !p.m.use_rigid && h->skin > 0.f && h->n <= 1024) {
+    // Skin mode, plain BAOAB: the B of step s-1 and the B A O A of step s ride in the first kernel of step s's force
+    // evaluation (k_step_small / k_skin_check): 2 launches less per step; the last B is launched on its own.
+    if (p.kind == 0 && !p.m.use_rigid && h->skin > 0.f) {
         for (long long s = s_begin; s < p.n_steps; ++s) {
             p.m.step = p.first_step + (unsigned long long)s;
             p.m.step_index = (int)s;

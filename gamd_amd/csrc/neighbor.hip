@@ -395,9 +395,23 @@ __device__ __forceinline__ bool d_skin_check(const NbrArgs& a, int i) {
     return moved;
 }
 
-__global__ void k_skin_check(NbrArgs a) {
+// do_second / do_first: the B of the previous MD step and the B A O A of this one for atom i first (plain BAOAB, MdFuse) —
+// per-atom work in front of a per-atom check: two launches less per step
+__global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (a.counters_next && i < CNT_COUNT) a.counters_next[i] = 0;      // ping-pong counter blocks: no memset node
+    if (do_second | do_first) {
+        if (md.devflags[DEVFLAG_FROZEN]) {                 // GAMD_MD_GATE of integrate.hip for the fused halves
+            if (i == 0 && md.devflags[DEVFLAG_FROZEN_AT] < 0)
+                md.devflags[DEVFLAG_FROZEN_AT] = do_second ? 2 * (md.step_index - 1) + 1 : 2 * md.step_index;
+        } else if (i < a.n) {
+            if (do_second) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) d_baoab_second_dof(md, 3 * i + d);
+            }
+            if (do_first) d_baoab_first_atom(md, i);
+        }
+    }
     if (i >= a.n) return;
     if (d_skin_check(a, i)) a.counters[CNT_REBUILD] = 1;
 }
@@ -683,10 +697,14 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
         hipLaunchKernelGGL(k_filter_fill_small, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
         return 0;
     }
-    if (fuse) return -22;                                     // integrator halves ride in k_step_small only
     // counters: ping-pong blocks (k_skin_check clears the other one) or one memset; the cell counters are left zero by k_fill
     if (!a.counters_next) { e = hipMemsetAsync(a.counters, 0, sizeof(int) * CNT_COUNT, st); if (e) return (int)e; }
-    hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a); GAMD_CHECK_LAUNCH();
+    {
+        MdArgs md{};
+        if (fuse) md = *fuse->md;
+        hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a, md, fuse ? fuse->do_second : 0, fuse ? fuse->do_first : 0);
+        GAMD_CHECK_LAUNCH();
+    }
     // candidate rebuild with rc + skin, every kernel gated on the flag k_skin_check has just written
     NbrArgs c = a;
     c.gate = a.counters + CNT_REBUILD;

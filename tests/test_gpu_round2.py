@@ -304,12 +304,13 @@ def test_small_system_skin_path_gives_the_exact_edge_set_every_step(n, flavour):
     exact.close(); reuse.close()
 
 
-def test_small_system_fused_md_steps_match_the_unfused_path():
-    """n <= 1024 with skin: B of step s-1 and B A O A of step s run inside the first neighbour kernel of step s.  Same
-    noise stream (seed, step, atom) and the same arithmetic as the stand-alone integrator kernels: against an engine
-    without skin (un-fused launches, exact rebuild) the trajectory agrees to the rounding of the row order, and calling
-    md_run step by step equals one call."""
-    n, rc = 300, 7.5
+@pytest.mark.parametrize("n", [300, 1500])
+def test_fused_md_steps_match_the_unfused_path(n):
+    """Skin mode: B of step s-1 and B A O A of step s run inside the first neighbour kernel of step s (k_step_small up to
+    1024 atoms, k_skin_check above).  Same noise stream (seed, step, atom) and the same arithmetic as the stand-alone
+    integrator kernels: against an engine without skin (un-fused launches, exact rebuild) the trajectory agrees to the
+    rounding of the row order, and calling md_run step by step equals one call."""
+    rc = 7.5
     sd = make_state_dict(ModelConfig(kind="lj"), 2, 5.0, 1.7)
     out = {}
     for tag, kw, chunks in (("unfused", {}, [12]), ("fused", dict(neighbor_skin=rc / 6), [12]),
