@@ -572,9 +572,9 @@ int clear_devflags(gamd_handle* h) {
 int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
     MdPending& p = h->pending;
     int r;
-    // Skin mode, plain BAOAB: the B of step s-1 and the B A O A of step s ride in the first kernel of step s's force
+    // Skin mode, BAOAB (free atoms or rigid water): the B of step s-1 and the B A O A of step s ride in the first kernel of step s's force
     // evaluation (k_step_small / k_skin_check): 2 launches less per step; the last B is launched on its own.
-    if (p.kind == 0 && !p.m.use_rigid && h->skin > 0.f) {
+    if (p.kind == 0 && h->skin > 0.f) {
         for (long long s = s_begin; s < p.n_steps; ++s) {
             p.m.step = p.first_step + (unsigned long long)s;
             p.m.step_index = (int)s;

@@ -40,134 +40,21 @@ __global__ void k_baoab_second(MdArgs a) {
     if (i < 3 * a.n) d_baoab_second_dof(a, i);
 }
 
-// ---- rigid 3-site water ------------------------------------------------------------------------
-// The water drivers integrate rigid molecules: OpenMM applies the constraints where the hacked integrators
-// say addConstrainPositions / addConstrainVelocities (hack_integrator.py:145-164,178,277-280,427-428).  For a
-// 3-site molecule both have closed forms: SETTLE (Miyamoto & Kollman, J. Comput. Chem. 13, 952 (1992)) for the
-// positions and a 3x3 linear solve for the velocities.  One thread owns one molecule (atoms O,H,H).
-struct Vec3 { float x, y, z; };
-__device__ __forceinline__ Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ Vec3 operator*(float s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ float dot(Vec3 a, Vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ Vec3 unit(Vec3 a) { return (1.0f / sqrtf(dot(a, a))) * a; }
+using namespace gamd_md;
 
-// x0: constrained reference geometry; x1: unconstrained new positions -> constrained new positions (in place).
-// Works in coordinates relative to the old oxygen so that fp32 carries the bond lengths, not the box size.
-__device__ __forceinline__ void settle_positions(const Vec3 (&x0)[3], Vec3 (&x1)[3], const RigidWater& g) {
-    const Vec3 b0 = x0[1] - x0[0], c0 = x0[2] - x0[0];
-    const Vec3 A1 = x1[0] - x0[0], B1 = x1[1] - x0[0], C1 = x1[2] - x0[0];
-    const float inv_m = 1.0f / (g.m_o + 2.0f * g.m_h);
-    const Vec3 d0 = inv_m * ((g.m_o * A1) + (g.m_h * (B1 + C1)));
-    const Vec3 a1 = A1 - d0, b1 = B1 - d0, c1 = C1 - d0;
-    Vec3 n0 = cross(b0, c0), n1 = cross(a1, n0), n2 = cross(n0, n1);
-    n0 = unit(n0); n1 = unit(n1); n2 = unit(n2);
-    const float b0x = dot(b0, n1), b0y = dot(b0, n2), c0x = dot(c0, n1), c0y = dot(c0, n2);
-    const float a1z = dot(a1, n0);
-    const float b1x = dot(b1, n1), b1y = dot(b1, n2), b1z = dot(b1, n0);
-    const float c1x = dot(c1, n1), c1y = dot(c1, n2), c1z = dot(c1, n0);
-    const float sinphi = a1z / g.ra, cosphi = sqrtf(1.0f - sinphi * sinphi);
-    const float sinpsi = (b1z - c1z) / (2.0f * g.rc * cosphi), cospsi = sqrtf(1.0f - sinpsi * sinpsi);
-    const float a2y = g.ra * cosphi, a2z = g.ra * sinphi;
-    const float b2x = -g.rc * cospsi, b2y = -g.rb * cosphi - g.rc * sinpsi * sinphi, b2z = -g.rb * sinphi + g.rc * sinpsi * cosphi;
-    const float c2x = g.rc * cospsi, c2y = -g.rb * cosphi + g.rc * sinpsi * sinphi, c2z = -g.rb * sinphi - g.rc * sinpsi * cosphi;
-    const float alpha = b2x * (b0x - c0x) + b0y * b2y + c0y * c2y;
-    const float beta = b2x * (c0y - b0y) + b0x * b2y + c0x * c2y;
-    const float gamma = (b0x * b1y - b1x * b0y) + (c0x * c1y - c1x * c0y);
-    const float a2b2 = alpha * alpha + beta * beta;
-    const float sint = (alpha * gamma - beta * sqrtf(a2b2 - gamma * gamma)) / a2b2, cost = sqrtf(1.0f - sint * sint);
-    const float a3x = -a2y * sint, a3y = a2y * cost;
-    const float b3x = b2x * cost - b2y * sint, b3y = b2x * sint + b2y * cost;
-    const float c3x = c2x * cost - c2y * sint, c3y = c2x * sint + c2y * cost;
-    const Vec3 base = x0[0] + d0;
-    x1[0] = base + ((a3x * n1) + (a3y * n2)) + (a2z * n0);
-    x1[1] = base + ((b3x * n1) + (b3y * n2)) + (b2z * n0);
-    x1[2] = base + ((c3x * n1) + (c3y * n2)) + (c2z * n0);
-}
-
-// remove the relative velocity along the three bonds: v_i += w_i sum_k (+-) g_k r_k with A g = -r_k.u_k
-__device__ __forceinline__ void settle_velocities(const Vec3 (&x)[3], Vec3 (&v)[3], const RigidWater& g) {
-    const float wo = 1.0f / g.m_o, wh = 1.0f / g.m_h;
-    const Vec3 r0 = x[0] - x[1], r1 = x[0] - x[2], r2 = x[1] - x[2];
-    const float y0 = -dot(r0, v[0] - v[1]), y1 = -dot(r1, v[0] - v[2]), y2 = -dot(r2, v[1] - v[2]);
-    const float a00 = (wo + wh) * dot(r0, r0), a01 = wo * dot(r0, r1), a02 = -wh * dot(r0, r2);
-    const float a11 = (wo + wh) * dot(r1, r1), a12 = wh * dot(r1, r2), a22 = 2.0f * wh * dot(r2, r2);
-    // symmetric 3x3 solve by cofactors
-    const float c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
-    const float c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
-    const float inv_det = 1.0f / ((a00 * c00 + a01 * c01) + a02 * c02);
-    const float g0 = ((c00 * y0 + c01 * y1) + c02 * y2) * inv_det;
-    const float g1 = ((c01 * y0 + c11 * y1) + c12 * y2) * inv_det;
-    const float g2 = ((c02 * y0 + c12 * y1) + c22 * y2) * inv_det;
-    v[0] = v[0] + (wo * ((g0 * r0) + (g1 * r1)));
-    v[1] = v[1] + (wh * ((g2 * r2) - (g0 * r0)));
-    v[2] = v[2] - (wh * ((g1 * r1) + (g2 * r2)));
-}
-
-__device__ __forceinline__ void load_mol(const float* p, int m, Vec3 (&o)[3]) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) o[k] = {p[9 * m + 3 * k], p[9 * m + 3 * k + 1], p[9 * m + 3 * k + 2]};
-}
-__device__ __forceinline__ void store_mol(float* p, int m, const Vec3 (&o)[3]) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { p[9 * m + 3 * k] = o[k].x; p[9 * m + 3 * k + 1] = o[k].y; p[9 * m + 3 * k + 2] = o[k].z; }
-}
-// keep the molecule whole: translate all three atoms by the lattice vector that brings the oxygen into the box
-__device__ __forceinline__ void wrap_mol(Vec3 (&x)[3], const float (&box)[3]) {
-    const Vec3 s = {floorf(x[0].x / box[0]) * box[0], floorf(x[0].y / box[1]) * box[1], floorf(x[0].z / box[2]) * box[2]};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) x[k] = x[k] - s;
-}
 
 // HackLangevinIntegrator with constraints, hack_integrator.py:141-165, one molecule per thread
 __global__ void k_baoab_first_rigid(MdArgs a) {
     GAMD_MD_GATE(0);
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (3 * m >= a.n) return;
-    Vec3 x[3], v[3], f[3];
-    load_mol(a.x, m, x); load_mol(a.v, m, v); load_mol(a.f, m, f);
-    const float w[3] = {1.0f / a.rigid.m_o, 1.0f / a.rigid.m_h, 1.0f / a.rigid.m_h};
-    const float hdt = 0.5f * a.dt;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] = v[k] + ((hdt * a.len * w[k]) * f[k]);          // B  :145
-    settle_velocities(x, v, a.rigid);                                                     //    :146
-#pragma unroll
-    for (int stage = 0; stage < 2; ++stage) {
-        Vec3 x1[3], xc[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { x1[k] = x[k] + (hdt * v[k]); xc[k] = x1[k]; }      // A  :149 / :160
-        settle_positions(x, xc, a.rigid);                                                 //    :151 / :162
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { v[k] = v[k] + ((1.0f / hdt) * (xc[k] - x1[k])); x[k] = xc[k]; }   // :152 / :163
-        settle_velocities(x, v, a.rigid);                                                 //    :153 / :164
-        if (stage == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {                                                 // O  :157
-                float xi[3];
-                atom_noise(a.seed, a.step, 3 * m + k, xi);
-                const float bs = a.b_len_kT * sqrtf(w[k]);
-                v[k] = (a.a * v[k]) + Vec3{bs * xi[0], bs * xi[1], bs * xi[2]};
-            }
-            settle_velocities(x, v, a.rigid);                                             //    :158
-        }
-    }
-    wrap_mol(x, a.box);
-    store_mol(a.x, m, x); store_mol(a.v, m, v);
+    if (3 * m < a.n) d_baoab_first_mol(a, m);
 }
 
 // HackHalfVelocityIntegrator with constraints, hack_integrator.py:177-178
 __global__ void k_baoab_second_rigid(MdArgs a) {
     GAMD_MD_GATE(1);
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (3 * m >= a.n) return;
-    Vec3 x[3], v[3], f[3];
-    load_mol(a.x, m, x); load_mol(a.v, m, v); load_mol(a.f, m, f);
-    const float w[3] = {1.0f / a.rigid.m_o, 1.0f / a.rigid.m_h, 1.0f / a.rigid.m_h};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] = v[k] + ((0.5f * a.dt * a.len * w[k]) * f[k]);
-    settle_velocities(x, v, a.rigid);
-    store_mol(a.v, m, v);
+    if (3 * m < a.n) d_baoab_second_mol(a, m);
 }
 
 // ---- Nose-Hoover chain -------------------------------------------------------------------------

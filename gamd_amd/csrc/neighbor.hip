@@ -404,6 +404,11 @@ __global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) 
         if (md.devflags[DEVFLAG_FROZEN]) {                 // GAMD_MD_GATE of integrate.hip for the fused halves
             if (i == 0 && md.devflags[DEVFLAG_FROZEN_AT] < 0)
                 md.devflags[DEVFLAG_FROZEN_AT] = do_second ? 2 * (md.step_index - 1) + 1 : 2 * md.step_index;
+        } else if (md.use_rigid) {                         // thread i owns molecule i (atoms 3 i .. 3 i + 2 = O, H, H)
+            if (3 * i < a.n) {
+                if (do_second) gamd_md::d_baoab_second_mol(md, i);
+                if (do_first) gamd_md::d_baoab_first_mol(md, i);
+            }
         } else if (i < a.n) {
             if (do_second) {
 #pragma unroll
@@ -411,6 +416,11 @@ __global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) 
             }
             if (do_first) d_baoab_first_atom(md, i);
         }
+    }
+    if ((do_second | do_first) && md.use_rigid) {          // the thread that moved the molecule checks its three atoms
+        for (int k = 0; k < 3 && 3 * i + k < a.n; ++k)
+            if (d_skin_check(a, 3 * i + k)) a.counters[CNT_REBUILD] = 1;
+        return;
     }
     if (i >= a.n) return;
     if (d_skin_check(a, i)) a.counters[CNT_REBUILD] = 1;
@@ -429,6 +439,11 @@ __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int d
         if (md.devflags[DEVFLAG_FROZEN]) {                 // GAMD_MD_GATE of integrate.hip for the fused halves
             if (tid == 0 && md.devflags[DEVFLAG_FROZEN_AT] < 0)
                 md.devflags[DEVFLAG_FROZEN_AT] = do_second ? 2 * (md.step_index - 1) + 1 : 2 * md.step_index;
+        } else if (md.use_rigid) {                         // thread t owns molecule t (atoms 3 t .. 3 t + 2 = O, H, H)
+            if (3 * tid < a.n) {
+                if (do_second) gamd_md::d_baoab_second_mol(md, tid);
+                if (do_first) gamd_md::d_baoab_first_mol(md, tid);
+            }
         } else if (tid < a.n) {
             if (do_second) {
 #pragma unroll
@@ -437,7 +452,12 @@ __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int d
             if (do_first) d_baoab_first_atom(md, tid);
         }
     }
-    const bool moved = tid < a.n ? d_skin_check(a, tid) : false;
+    bool moved = false;
+    if ((do_second | do_first) && md.use_rigid) {          // the thread that moved the molecule checks its three atoms
+        for (int k = 0; k < 3 && 3 * tid + k < a.n; ++k) moved |= d_skin_check(a, 3 * tid + k);
+    } else if (tid < a.n) {
+        moved = d_skin_check(a, tid);
+    }
     if (tid < CNT_COUNT) a.counters_next[tid] = 0;
     if (!__syncthreads_or(moved ? 1 : 0)) return;
     if (tid == 0) a.counters[CNT_REBUILD] = 1;

@@ -192,6 +192,45 @@ def test_rigid_water_stays_rigid_over_many_steps():
     eng.close()
 
 
+@pytest.mark.parametrize("n_mol", [125, 512])
+def test_rigid_water_halves_fused_into_the_skin_check_match_the_separate_kernels(n_mol):
+    """Skin mode: the rigid-molecule B / B A O A halves ride in the first neighbour kernel of the step (k_step_small up to
+    1024 atoms, k_skin_check above), one thread per molecule, which then runs the displacement check of its three atoms.
+    Same device functions and noise stream as k_baoab_*_rigid: the run equals the un-fused engine's (no skin) to the
+    rounding of the row order, step-by-step calls equal one call bit for bit, and the molecules stay rigid."""
+    from gamd_amd.engine import GamdForce
+    from gamd_amd import workloads as wl
+    eng0, sd, pos, box, species, bonds, mass, pairs, lengths, v0 = _water_setup(n_mol=n_mol, seed=9)
+    eng0.close()
+    n = 3 * n_mol
+    kw = dict(dt_ps=0.002, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, temperature_k=300.0, gamma_per_ps=25.0, seed=3,
+              species=species, rigid_water=True, r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH)
+    out = {}
+    for tag, ekw, chunks in (("unfused", {}, [8]), ("fused", dict(neighbor_skin=0.7), [8]),
+                             ("fused_split", dict(neighbor_skin=0.7), [1, 3, 4])):
+        eng = GamdForce(sd, n, box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS["tip3p"], **ekw)
+        x = torch.from_numpy(pos).float().cuda()
+        v = torch.from_numpy(v0).float().cuda()
+        f = eng.forward(x, species=species, denormalize=True).clone()
+        done = 0
+        for c in chunks:
+            eng.md_run(x, v, f, c, first_step=done, **kw)
+            done += c
+        out[tag] = (x.cpu().numpy(), v.cpu().numpy(), f.cpu().numpy())
+        eng.close()
+    for a, b in zip(out["fused"], out["fused_split"]):
+        assert np.array_equal(a, b)
+    xu, xf = out["unfused"][0].astype(np.float64), out["fused"][0].astype(np.float64)
+    d = xf - xu
+    d -= box * np.round(d / box)
+    # rounding of the row order (1e-6 of the forces), amplified by 8 steps of a stiff random-weight force field
+    assert np.abs(d).max() < 2e-4                                     # Angstrom
+    assert rel_err(out["fused"][1], out["unfused"][1]) < 5e-4
+    d_err, rv = _bond_errors(xf, out["fused"][1].astype(np.float64), pairs, lengths)
+    assert d_err < 2e-5 and rv < 2e-3 * np.abs(out["fused"][1]).max()
+    assert np.abs(xf - pos).max() > 1e-3                              # it moved
+
+
 def test_rigid_water_nose_hoover_matches_oracle():
     """HackNoseHooverIntegrator / HackHalfNoseHooverIntegrator with constraints (hack_integrator.py:274-280,
     427-430), ndf = 3N - N constraints (:226-235)."""
