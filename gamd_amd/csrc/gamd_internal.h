@@ -5,7 +5,9 @@
 #include <stdint.h>
 #include "gamd_common.h"
 
-enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD = 4, CNT_NCAND = 5, CNT_COUNT = 8 };
+enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD = 4, CNT_NCAND = 5,
+       CNT_CAND_MAX = 6,      // fixed-stride candidate rows: the longest row of the rebuild of this call
+       CNT_COUNT = 8 };
 // host-mapped, never cleared by the per-call memset: overflow must survive later steps of an enqueued MD run
 enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, STICKY_NCAND = 3,
        STICKY_NONFINITE = 4,   // the decoder produced a non-finite force component (NaN / inf positions, or an operand
@@ -63,6 +65,11 @@ struct NbrArgs {
     int* cand_ptr;         // [n+1]
     int* cand_col;         // [cand_cap] sorted index of the candidate neighbour
     long long cand_cap;
+    int cand_stride;       // > 0 (n > 1024): candidate row c is cand_col[c * cand_stride ..][cand_deg[c]] — fixed-width rows as in
+                           // jax-md's idx[N, max_occupancy] (graph_utils.py:21-25): one kernel fills them, no count / scan / fill
+                           // passes.  0 (n <= 1024, k_step_small): CSR rows cand_col[cand_ptr[c] ..][cand_deg[c]]
+    int cells_one_wg;      // candidate rebuild: the four cell-list phases in one single-workgroup launch (rebuilds are rare: one
+                           // gated launch per reuse step instead of four) or as four grid-wide kernels (rebuilds are frequent)
     float rc_build, rc2_build;   // rc + skin
 };
 struct MdArgs;

@@ -244,14 +244,21 @@ __device__ void d_scan_deg_fast(const NbrArgs& a) {
     __syncthreads();
     int run = x - mine, E_all = 0;
     for (int w = 0; w < 16; ++w) { const int t = s_tot[0][w]; if (w < wv) run += t; E_all += t; }
-    int f[IPT], mine2 = 0;
+    int f[IPT], rp[IPT], mine2 = 0;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        const int rp = run;
-        if (i0 + k < a.n) a.row_ptr[i0 + k] = rp;
-        f[k] = (a.cand_pass == 0 && i0 + k < a.n && v[k] > 0 && (rp % GAMD_CHUNK) != 0) ? 1 : 0;
+        rp[k] = run;
+        f[k] = (a.cand_pass == 0 && i0 + k < a.n && v[k] > 0 && (rp[k] % GAMD_CHUNK) != 0) ? 1 : 0;
         mine2 += f[k];
         run += v[k];
+    }
+    if (i0 + IPT <= a.n) {
+#pragma unroll
+        for (int q = 0; q < IPT / 4; ++q)
+            *reinterpret_cast<int4*>(a.row_ptr + i0 + 4 * q) = make_int4(rp[4 * q], rp[4 * q + 1], rp[4 * q + 2], rp[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) if (i0 + k < a.n) a.row_ptr[i0 + k] = rp[k];
     }
     if (tid == 0) a.row_ptr[a.n] = E_all;
     if (a.cand_pass) {                                     // candidate CSR: only its size and overflow matter
@@ -270,10 +277,16 @@ __device__ void d_scan_deg_fast(const NbrArgs& a) {
     __syncthreads();
     int run2 = y2 - mine2, NA_all = 0;
     for (int w = 0; w < 16; ++w) { const int t = s_tot[1][w]; if (w < wv) run2 += t; NA_all += t; }
+    int na[IPT];
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-        if (i0 + k < a.n) a.na_excl[i0 + k] = run2;
-        run2 += f[k];
+    for (int k = 0; k < IPT; ++k) { na[k] = run2; run2 += f[k]; }
+    if (i0 + IPT <= a.n) {
+#pragma unroll
+        for (int q = 0; q < IPT / 4; ++q)
+            *reinterpret_cast<int4*>(a.na_excl + i0 + 4 * q) = make_int4(na[4 * q], na[4 * q + 1], na[4 * q + 2], na[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) if (i0 + k < a.n) a.na_excl[i0 + k] = na[k];
     }
     if (tid == 0) {
         a.na_excl[a.n] = NA_all;
@@ -490,9 +503,16 @@ __device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPt
     const bool live = ctr < a.n;
     const int c = live ? ctr : a.n - 1;
     const float4 pc = a.pos_s[c];
-    long long s = a.cand_ptr[c], e = a.cand_ptr[c + 1];
-    if (e > a.cand_cap) e = a.cand_cap;
-    if (s > e) s = e;
+    long long s, e;
+    if (a.cand_stride > 0) {
+        const int dgc = a.cand_deg[c];
+        s = (long long)c * a.cand_stride;
+        e = s + (dgc < a.cand_stride ? dgc : a.cand_stride);
+    } else {
+        s = a.cand_ptr[c]; e = a.cand_ptr[c + 1];
+        if (e > a.cand_cap) e = a.cand_cap;
+        if (s > e) s = e;
+    }
     long long w = FILL ? (long long)row_ptr[c] : 0;
     int cnt = 0;
     for (long long b0 = s; b0 < e; b0 += 32) {
@@ -525,7 +545,71 @@ __device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPt
 
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
+    if (!FILL && a.cand_stride > 0 && blockIdx.x == 0 && threadIdx.x == 0 && a.counters[CNT_REBUILD]) {
+        // fixed-stride candidate rows were rebuilt in this call (k_cand_fill): publish its size; a row longer than the stride
+        // is an overflow (the list is truncated: freeze, the host regrows to 1.25 x longest row x n and resumes)
+        const int longest = a.counters[CNT_CAND_MAX];
+        a.sticky[STICKY_NCAND] = a.counters[CNT_NCAND];
+        a.sticky[STICKY_REBUILDS] += 1;
+        if (longest > a.cand_stride) {
+            const long long need = (long long)longest * a.n;
+            a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
+            a.sticky[STICKY_CAND_OVERFLOW] = 1;
+            a.devflags[DEVFLAG_FROZEN] = 1;
+        }
+    }
     d_filter<FILL>(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31, a.row_ptr);
+}
+
+// ---- candidate rebuild for n > 1024 in two gated launches ----------------------------------------------------------
+// k_cells_one_wg: bin | scan | fill | sort + gather in ONE 1024-thread workgroup (the phases of k_step_small's rebuild with
+// loops over the atoms / cells; up to 16 384 atoms, the four-kernel sequence above that).  It runs once in 50-100 steps;
+// what counts is that a reuse step pays for two gated launches instead of seven.
+__global__ void __launch_bounds__(1024) k_cells_one_wg(NbrArgs c) {
+    if (c.gate && *c.gate == 0) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < c.n; i += 1024) d_bin(c, i);                      // cell counters are zero on entry (k_cand_fill)
+    __syncthreads();
+    block_exclusive_scan(c.ncell, [&](int i) { return c.cell_cnt[i]; }, c.cell_start);
+    __syncthreads();
+    for (int i = tid; i < c.n; i += 1024) d_fill_cells(c, i);
+    __syncthreads();
+    for (int k = tid >> 6; k < c.ncell; k += 16) d_sort_gather(c, k, tid & 63);
+}
+
+// k_cand_fill: one half-wave per centre atom sweeps its 27 cells once and writes the accepted neighbours straight into the
+// atom's fixed-width row; the row length, the total and the longest row go to cand_deg / counters.  Leaves the cell
+// counters zero for the next rebuild.
+__global__ void __launch_bounds__(256) k_cand_fill(NbrArgs c) {
+    if (c.gate && *c.gate == 0) return;
+    const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
+    const bool live = ctr < c.n;
+    const int cc = live ? ctr : c.n - 1;
+    const long long row0 = (long long)cc * c.cand_stride;
+    int w = 0;
+    sweep(c, cc, l, [&](bool ok, int b) {
+        const unsigned m = half_ballot(ok);
+        if (ok && live) {
+            const int at = w + __popc(m & ((1u << l) - 1u));
+            if (at < c.cand_stride) c.cand_col[row0 + at] = b;
+        }
+        w += __popc(m);
+    });
+    // total and longest row: one pair of global atomics per workgroup, not per atom (same-address atomics serialise)
+    __shared__ int s_tot, s_max;
+    if (threadIdx.x == 0) { s_tot = 0; s_max = 0; }
+    __syncthreads();
+    if (live && l == 0) {
+        c.cand_deg[ctr] = w;
+        atomicAdd(&s_tot, w < c.cand_stride ? w : c.cand_stride);
+        atomicMax(&s_max, w);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&c.counters[CNT_NCAND], s_tot);
+        atomicMax(&c.counters[CNT_CAND_MAX], s_max);
+    }
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < c.ncell; k += gridDim.x * blockDim.x) { c.cell_cnt[k] = 0; c.cell_fill[k] = 0; }
 }
 
 // Small systems (n <= 1024): exact-filter fill, the scan of the degrees and the chunk metadata in ONE launch.  Every
@@ -732,13 +816,21 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     c.rc = a.rc_build; c.rc2 = a.rc2_build;
     c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
     c.self_loop = 0;                                          // loops are appended by the exact filter, not kept as candidates
-    hipLaunchKernelGGL(k_bin, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();          // also stores ref_pos
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_fill_cells, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sort_gather, dim3((a.ncell + 3) / 4), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_count, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_fill, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
+    if (a.cells_one_wg && a.n <= 16 * 1024) {
+        hipLaunchKernelGGL(k_cells_one_wg, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();          // also stores ref_pos
+    } else {
+        hipLaunchKernelGGL(k_bin, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_fill_cells, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_sort_gather, dim3((a.ncell + 3) / 4), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
+    }
+    if (a.cand_stride > 0) {
+        hipLaunchKernelGGL(k_cand_fill, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(k_count, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_fill, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
+    }
     // exact list of this step
     NbrArgs x = a;
     x.ref_pos = nullptr;
