@@ -17,9 +17,10 @@
 // the two waves of a SIMD do NOT interleave their MFMA streams — the older wave owns the matrix pipe
 // until its GEMM is done, then the younger one runs.  A phase therefore costs
 //     (older wave: barrier release -> first MFMA) + 2 GEMMs + (younger wave: last MFMA -> barrier).
-// So: (1) everything a GEMM needs besides its LDS weights is loaded BEFORE the preceding barrier,
-// into whichever of the three 64-register sets is free, and stays in flight across the barrier
-// (raw s_barrier + counted vmcnt: only the weight DMA, issued earlier, must have landed);
+// So: (1) everything a GEMM needs besides its LDS weights is loaded a phase ahead, into whichever of
+// the three 64-register sets is free — by the older waves BEFORE the barrier (the loads stay in
+// flight across it: raw s_barrier + counted vmcnt, only the weight copy must have landed), by the
+// younger waves right AFTER it (see "Gather schedule" below);
 // (2) element-wise post-ops (SiLU, message, segment sum) of output tile tp-1 are issued in the
 // shadow of the MFMAs of tile tp, so only a quarter of them trails the last MFMA.
 //
