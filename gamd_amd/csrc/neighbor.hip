@@ -559,6 +559,37 @@ __global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
         }
     }
     d_filter<FILL>(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31, a.row_ptr);
+    if (FILL && a.cand_stride > 0) {
+        // Chunk metadata (first piece id, mask of the edges that close a destination segment) of the 16-edge chunks that START
+        // in this half-wave's row, one lane per chunk, from the row pointers alone — an edge closes a segment iff it is the
+        // last of its row (k_filter_fill_small's rule; row_ptr / na_excl are complete, the scan ran before): no k_chunk_meta
+        // launch, and no dependence on other workgroups' erow stores.
+        const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
+        long long E = a.counters[CNT_E];
+        if (E > a.e_cap) E = a.e_cap;
+        if (ctr < a.n) {
+            const long long rp = a.row_ptr[ctr], re = a.row_ptr[ctr + 1];          // this row: [rp, re)
+            const int na_incl = a.na_excl[ctr] + ((re > rp && (rp % GAMD_CHUNK) != 0) ? 1 : 0);
+            for (long long c = (rp + GAMD_CHUNK - 1) / GAMD_CHUNK + l; c * GAMD_CHUNK < re && c * GAMD_CHUNK < E; c += 32) {
+                const long long x0 = c * GAMD_CHUNK;
+                a.chunk_piece[c] = (int)c + na_incl;
+                unsigned mask = 0;
+                int at = ctr;
+                long long end = re;                                                  // end of row `at`
+                for (int r = 0; r < GAMD_CHUNK; ++r) {
+                    const long long xe = x0 + r;
+                    if (xe >= E) break;
+                    while (end <= xe) { ++at; end = a.row_ptr[at + 1]; }
+                    if (xe == end - 1 || xe == E - 1) mask |= 1u << r;
+                }
+                a.chunk_mask[c] = mask;
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {          // the second chunk of a last tile that is at most half full
+            const long long n_chunks = 2 * ((E + GAMD_TILE - 1) / GAMD_TILE);
+            if (n_chunks > 0 && (n_chunks - 1) * GAMD_CHUNK >= E) { a.chunk_piece[n_chunks - 1] = 0; a.chunk_mask[n_chunks - 1] = 0; }
+        }
+    }
 }
 
 // ---- candidate rebuild for n > 1024 in two gated launches ----------------------------------------------------------
@@ -837,9 +868,11 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     hipLaunchKernelGGL(k_filter<false>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, x); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter<true>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
-    const long long nchunk_cap = (a.e_cap + GAMD_TILE) / GAMD_CHUNK;
-    hipLaunchKernelGGL(k_chunk_meta, dim3((unsigned)((nchunk_cap + 255) / 256)), dim3(256), 0, st, x);
-    GAMD_CHECK_LAUNCH();
+    if (a.cand_stride <= 0) {                                  // fixed-width mode: the fill pass wrote the chunk metadata
+        const long long nchunk_cap = (a.e_cap + GAMD_TILE) / GAMD_CHUNK;
+        hipLaunchKernelGGL(k_chunk_meta, dim3((unsigned)((nchunk_cap + 255) / 256)), dim3(256), 0, st, x);
+        GAMD_CHECK_LAUNCH();
+    }
     return 0;
 }
 
