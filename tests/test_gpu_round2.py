@@ -351,6 +351,36 @@ def test_small_system_fused_md_overflow_freezes_and_resumes():
         assert np.isfinite(b).all() and rel_err(b, a) < 1e-4
 
 
+@pytest.mark.parametrize("n", [1025, 16384, 16385])
+def test_sizes_at_the_kernel_selection_boundaries(n):
+    """1024 / 1025 atoms: single-workgroup fused path vs the launch sequence with fixed-width candidate rows; 16 384 / 16 385:
+    one-pass vs multi-pass row scan and one-workgroup vs four-kernel cell build.  Skin engine against the rebuild-every-call
+    engine along a short walk with one forced rebuild: same edge set, forces to rounding, and the MD entry point runs."""
+    rng = np.random.default_rng(n)
+    rc = 6.0
+    pos, box = workloads.lj_box(n, seed=5)
+    sd = make_state_dict(ModelConfig(kind="lj"), 2, 5.0, 1.7)
+    exact = _engine(sd, n, box, rc)
+    reuse = _engine(sd, n, box, rc, neighbor_skin=1.0, scaler=SHIPPED_SCALERS["lj"])
+    x = pos.copy()
+    for step in range(6):
+        if step == 3:
+            x[n - 1] += np.array([2.0, 1.0, -2.5])
+        p = torch.from_numpy(x).float()
+        f0, f1 = exact.forward(p).cpu().numpy(), reuse.forward(p).cpu().numpy()
+        assert exact.counts()[0] == reuse.counts()[0], step
+        assert np.array_equal(edge_set(exact.debug_edges()), edge_set(reuse.debug_edges())), step
+        assert rel_err(f1, f0) < TOL, step
+        x = x + rng.normal(0.0, 0.05, x.shape)
+    assert reuse.skin_stats()[0] >= 2
+    xd = torch.from_numpy(x).float().cuda()
+    vd = torch.zeros_like(xd)
+    fd = reuse.forward(xd, denormalize=True).clone()
+    reuse.md_run(xd, vd, fd, 5, temperature_k=100.0, seed=2)
+    assert reuse.last_status == 0 and torch.isfinite(xd).all() and torch.isfinite(fd).all()
+    exact.close(); reuse.close()
+
+
 def test_more_than_16384_atoms_take_the_multi_pass_row_scan():
     """Up to 16 384 atoms the row scan (row_ptr, piece numbering) is one pass over registers; above that the generic
     multi-pass scan.  20 000 atoms: the edge set against an independent periodic KD-tree, the CSR invariants, and the forces
