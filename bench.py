@@ -220,6 +220,7 @@ def timed_run(w, steps, warmup, ctx, dev, ddev):
     w.eng.timing_enable(True)
     t0 = time.perf_counter()
     w.eng.md_run(w.x, w.v, w.f, steps, first_step=warmup, sync=True, **w.md)
+    w.timed_status = int(w.eng.last_status)        # 1: a neighbour buffer overflowed inside the timed run (frozen, regrown, resumed)
     torch.cuda.synchronize(dev)
     ens.barrier(ctx)
     torch.cuda.synchronize(dev)
@@ -373,6 +374,7 @@ def main():
                                       f"{w.eng.skin_stats()[0]} candidate rebuilds in warm-up + timed steps"
                                       if w.uses_skin else "exact cell-list rebuild every step"),
                    "step": "BAOAB half + neighbour build + GNN forces + BAOAB half, on device",
+                   "buffers_regrown_in_timed_run": bool(getattr(w, "timed_status", 0) == 1),
                    "launch": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else
                              ("self-spawned ranks" if ctx.world > 1 else "single process")},
         "ensemble": {"boxes": ctx.world, "collective_on_step_path": False,

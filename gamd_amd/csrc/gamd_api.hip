@@ -170,7 +170,9 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
     h->e_cap = e_cap;
     if (h->skin > 0.f) {
         const double grow = std::pow(((double)h->cfg.cutoff + h->skin) / (double)h->cfg.cutoff, 3.0);
-        const long long want = (long long)((double)e_cap * grow * 1.1) + 1024;
+        // n > 1024: candidate rows have a fixed width (capacity / n), so what must fit is the LONGEST row, not the total:
+        // ~2.5 x the mean row (e_cap is already 1.5 x the density estimate) instead of ~1.65 x
+        const long long want = (long long)((double)e_cap * grow * (h->n > 1024 ? 1.7 : 1.1)) + 1024;
         if (want > h->cand_cap) return alloc_candidates(h, want);
     }
     return 0;

@@ -47,6 +47,15 @@ def test_default_line_has_the_contract_keys():
     assert d["ensemble"]["boxes"] == 1 and len(d["ensemble"]["per_rank"]) == 1
 
 
+def test_long_water_run_does_not_outgrow_its_neighbour_buffers():
+    """1 500 steps of the rigid-water workload: the fixed-width candidate rows (capacity / N per atom) must hold the longest
+    row as the box melts — an overflow is survivable (freeze, regrow, resume) but costs the frozen steps, and the bench
+    line says so."""
+    d = _run("--no-cpu-baseline", "--no-secondary", "--workload", "c3", steps=1500, warmup=10)
+    assert d["config"]["buffers_regrown_in_timed_run"] is False
+    assert "candidate rebuilds" in d["config"]["neighbour_list"]
+
+
 def test_split_fp16_line_is_labelled_as_such():
     d = _run("--no-cpu-baseline", "--no-secondary", "--edge-dtype", "f16x3")
     assert d["dtype"].startswith("f16x3") and d["roofline"]["kernel"] == "k_conv_edge_f16x3"
