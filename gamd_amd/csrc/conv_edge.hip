@@ -112,6 +112,7 @@ enum {
 //     GEMM of waiting in front of them anyway.
 template <int V>
 __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     constexpr bool TIME = (V & CV_TIME) != 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* buf0 = lds;

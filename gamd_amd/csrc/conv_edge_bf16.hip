@@ -14,6 +14,7 @@ namespace {
 constexpr int CONVB_LDS_BYTES = 4 * GAMD_WFRAG_BF16_BYTES + 3 * 128 * 4;
 
 __global__ void __launch_bounds__(512, 2) k_conv_edge_bf16(ConvEdgeArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     const bf16x8* W1 = reinterpret_cast<const bf16x8*>(ldsb);
     const bf16x8* W2 = W1 + 2048;

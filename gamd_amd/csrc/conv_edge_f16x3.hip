@@ -108,6 +108,7 @@ __device__ __forceinline__ void load_e_piece(const float* __restrict__ e_frag, i
 // accumulators and all gathered rows of a tile stay in registers without spilling, and every gather is issued a full
 // GEMM ahead of its use.  (Two waves per SIMD at 256 registers each spill ~100 registers and are slower.)
 __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     constexpr int NW = 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* buf0 = lds;

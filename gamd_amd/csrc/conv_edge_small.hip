@@ -21,6 +21,7 @@ constexpr int XLD = GAMD_XLD;
 // order of wide.hip's phase 2 ((S + D) first, then the GEMM) instead of conv_edge.hip's (D, GEMM, + S).
 template <int EHT, int HT, bool WIDE>
 __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     constexpr int H = 128 * HT;
     __shared__ __attribute__((aligned(16))) float xbuf[32 * XLD];
     const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;

@@ -66,6 +66,7 @@ __device__ __forceinline__ void gelu_block(const f32x16 (&acc)[4], f32x16 (&X)[4
 
 template <int NFEAT, int ABL>
 __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w1 = lds;
     float* w2 = w1 + ENC_W1_FLOATS;
@@ -205,6 +206,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
 // output element as k_edge_encode (including the LayerNorm sums: per 32-feature block, then a fixed tree): bit-identical.
 template <int NFEAT>
 __global__ void __launch_bounds__(256) k_edge_encode_small(EncArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     __shared__ __attribute__((aligned(16))) float xbuf[32 * GAMD_XLD];
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;

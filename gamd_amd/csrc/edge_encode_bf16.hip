@@ -15,6 +15,7 @@ constexpr int ENCB_LDS_BYTES = ENCB_W1_BYTES + 2 * GAMD_WFRAG_BF16_BYTES + (5 * 
 
 template <int NFEAT>
 __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     const bf16x8* W1 = reinterpret_cast<const bf16x8*>(ldsb);
     const bf16x8* W2 = reinterpret_cast<const bf16x8*>(ldsb + ENCB_W1_BYTES);

@@ -15,6 +15,7 @@ constexpr int ENCH_LDS_BYTES = 2 * ENCH_W1_PART * 16 + 2 * 65536 + (5 * 128 + 64
 
 template <int NFEAT>
 __global__ void __launch_bounds__(512, 2) k_edge_encode_f16x3(EncArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
     const f16x8* W1 = reinterpret_cast<const f16x8*>(ldsb);                       // [hi | lo], 2 x 12 KiB
     const f16x8* W2 = W1 + 2 * ENCH_W1_PART;                                      // [hi | lo], 2 x 32 KiB

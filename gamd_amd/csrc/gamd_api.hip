@@ -421,6 +421,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
 
     EncArgs ea{};
     ea.counters = h->cur_counters;
+    ea.devflags = h->devflags.as<int>();
     ea.pos_s = h->pos_s.as<float4>();
     ea.col = h->col.as<int>();
     ea.erow = h->erow.as<int>();
@@ -508,6 +509,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     for (int l = 0; l < h->L; ++l) {
         ConvEdgeArgs ca{};
         ca.counters = h->cur_counters;
+        ca.devflags = h->devflags.as<int>();
         ca.col = h->col.as<int>(); ca.erow = h->erow.as<int>();
         ca.chunk_piece = h->chunk_piece.as<int>(); ca.chunk_mask = h->chunk_mask.as<unsigned>();
         ca.e_frag = h->e_frag.as<float>();

@@ -87,6 +87,7 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
 // ---- edge encoder -----------------------------------------------------------------------------
 struct EncArgs {
     const int* counters;
+    const int* devflags;       // DEVFLAG_FROZEN set: return at once (see ConvEdgeArgs)
     const float4* pos_s;
     const int* col;
     const int* erow;
@@ -121,6 +122,8 @@ int launch_edge_encode_wide(const EncArgs& a, int eht, int n_blocks, hipStream_t
 // ---- conv layer, edge side --------------------------------------------------------------------
 struct ConvEdgeArgs {
     const int* counters;
+    const int* devflags;       // DEVFLAG_FROZEN set (a neighbour buffer overflowed earlier in this enqueued run): return at once —
+                               // the steps enqueued behind a frozen one cost their launches, not their GEMMs
     const int* col;
     const int* erow;
     const int* chunk_piece;

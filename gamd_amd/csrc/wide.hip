@@ -33,6 +33,7 @@ __device__ __forceinline__ void wide_barrier() {
 // ================================================================================================
 template <int NFEAT, int EHT>
 __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     static_assert(EHT == 1 || EHT == 2, "edge embedding width 128 or 256");
     constexpr int EH = 128 * EHT;
     constexpr bool EXPAND = NFEAT >= 44;
@@ -190,6 +191,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
 // ================================================================================================
 template <int EHT, int HT>
 __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     constexpr int NP = EHT + 2 + HT;
     constexpr int H = 128 * HT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
