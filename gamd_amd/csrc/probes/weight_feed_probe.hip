@@ -8,6 +8,7 @@
 //           ahead, no barrier at all (free-running waves), 8 waves per CU
 //   mode 3  the same with 4 waves per CU (one per SIMD)
 //   mode 4  hybrid: W1, W2 resident in LDS (128 KiB, loaded once), W3, W4 straight from L2; no barrier
+//   mode 8  LDS ring fed as in mode 0, but per-slot ready / done counters in LDS instead of workgroup barriers
 // FLOP/s counts 4 x 256 MFMAs per tile.
 #include "../gamd_common.h"
 #include <cstdio>
@@ -177,6 +178,56 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k(const float* __restr
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+    } else if (MODE == 8) {
+        // LDS ring WITHOUT workgroup barriers: per slot a "ready" counter (waves whose share of the copy has landed) and a
+        // "done" counter (waves that have finished reading it).  A wave starts phase k when ready[k & 1] says all eight shares
+        // of that matrix are in; it issues its share of phase k + 1's matrix as soon as done[] says everybody has left that
+        // slot (checked at the phase start and again at every output-tile boundary), and announces it half a GEMM later.
+        // Waves may drift by most of a phase instead of meeting four times per tile.
+        auto slot_ptr = [&](int sl) { return lds + sl * GAMD_WFRAG_FLOATS; };
+        int* cnt = reinterpret_cast<int*>(lds + 2 * GAMD_WFRAG_FLOATS);      // ready[0], ready[1], done[0], done[1]
+        if (tid < 4) cnt[tid] = 0;
+        __syncthreads();
+        auto poll = [&](int idx, int target) {
+            int spins = 0;
+            while (__hip_atomic_load(cnt + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(1);
+        };
+        auto bump = [&](int idx) {
+            if (lane == 0) __hip_atomic_fetch_add(cnt + idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        gamd_stage_weight_raw<8>(Wm(0), slot_ptr(0), wave, lane16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bump(0);
+        const int n_phase = 4 * iters;
+        for (int k = 0; k < n_phase; ++k) {
+            const int slot = k & 1, nslot = slot ^ 1;
+            poll(slot, 8 * ((k >> 1) + 1));                                   // weights of phase k are in
+            // slot nslot was last read in phase k - 1: its ((k - 1) >> 1)-th use
+            const int free_target = k >= 1 ? 8 * (((k - 1) >> 1) + 1) : 0;
+            bool issued = false, told = false;
+            auto try_issue = [&]() {
+                if (!issued && __hip_atomic_load(cnt + 2 + nslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= free_target) {
+                    gamd_stage_weight_raw<8>(Wm(k + 1), slot_ptr(nslot), wave, lane16);
+                    issued = true;
+                }
+            };
+            try_issue();
+            for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.01f;
+            gemm_lds((const f32x4*)slot_ptr(slot), lane, X, acc, [&](int tp, int g) {
+                if (g == 0) {                                                 // output-tile boundary: tp + 1 is starting
+                    if (!issued) try_issue();
+                    else if (!told && tp >= 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bump(nslot); told = true; }
+                }
+                acc[tp][g] = silu_hw(acc[tp][g]);
+            });
+#pragma unroll
+            for (int t = 0; t < 4; ++t) X[t] = acc[t];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bump(2 + slot);                                                   // done with this slot
+            if (!issued) { poll(2 + nslot, free_target); try_issue(); }
+            if (!told) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bump(nslot); }
+        }
     } else if (MODE == 2 || MODE == 3) {
         f32x4 w[D];
 #pragma unroll
@@ -219,7 +270,7 @@ __global__ void __launch_bounds__(THREADS, THREADS / 256) k(const float* __restr
 
 template <int MODE, int D, int threads>
 double run(const float* dW, float* dOut, int iters) {
-    const size_t ldsb = sizeof(float) * 2 * GAMD_WFRAG_FLOATS;
+    const size_t ldsb = sizeof(float) * 2 * GAMD_WFRAG_FLOATS + 64;
     hipFuncSetAttribute((const void*)k<MODE, D, threads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     k<MODE, D, threads><<<256, threads, ldsb>>>(dW, dOut, 2);
@@ -251,6 +302,7 @@ int main() {
         printf("mode4 W1,W2 LDS-resident + W3,W4 from L2 depth 4 (8 waves) : %.1f TF\n", run<4, 4, 512>(dW, dOut, iters));
         printf("mode4 W1,W2 LDS-resident + W3,W4 from L2 depth 8 (4 waves) : %.1f TF\n", run<4, 8, 256>(dW, dOut, iters));
         printf("mode5 LDS ring, 4 waves x 2 tiles each, barrier per GEMM       : %.1f TF\n", run<5, 4, 256>(dW, dOut, iters / 2));
+        printf("mode8 LDS ring, ready/done counters instead of barriers (8 w)  : %.1f TF\n", run<8, 4, 512>(dW, dOut, iters));
         printf("mode7 mode0 + 16 KB streamed + 64 gathers per GEMM (8 w x 1 t) : %.1f TF\n", run<7, 4, 512>(dW, dOut, iters));
         printf("mode6 mode5 + the same traffic per tile (4 waves x 2 tiles)    : %.1f TF\n", run<6, 4, 256>(dW, dOut, iters / 2));
     }
