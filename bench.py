@@ -397,9 +397,10 @@ def main():
         except Exception as exc:                                        # missing / unreadable file: say so, report null
             rl["traffic_note"] = f"no PMC record: {exc}"
         rl["ceiling_note"] = ("gfx950 issues fp32 MFMA and VALU on the same lanes: a dependent v_mfma_f32_32x32x2_f32 chain runs at 64 "
-                              "cycles per instruction and every VALU instruction between MFMAs adds ~4.4 cycles even with two waves "
-                              "per SIMD (csrc/probes/mfma_issue_probe); at ~1.2-1.6 k VALU instructions (3 x SiLU, message, sums) "
-                              "per 1 024 MFMAs this kernel's arithmetic cannot exceed ~0.91 of the matrix peak")
+                              "cycles per instruction and every vector instruction between MFMAs adds its time even with two waves per "
+                              "SIMD: ~4.4 cycles per v_fma-class instruction, ~8.3 per v_exp_f32 / v_rcp_f32 (csrc/probes/"
+                              "mfma_issue_probe); 3 x 64 SiLU + message + sums are ~8.1 k cycles next to 65.5 k of MFMA per tile: "
+                              "this arithmetic cannot exceed ~0.89 of the matrix peak (~0.865 with the launch tail at this size)")
         # SURVEY.md §8d "neighbour gather" figure: L2-served rows, so this is not HBM traffic; stated with its bound
         n_layers = 4
         gather_bytes = n_layers * (n_edges * 1028.0 + w.n_atoms * 1024.0)

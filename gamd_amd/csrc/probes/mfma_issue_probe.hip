@@ -27,7 +27,12 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) 
                 if ((k & 3) == 3) a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, x, a3, 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < VALU; ++j) { v = __builtin_fmaf(v, 1.0001f, 0.25f); asm volatile("" : "+v"(v)); }
+            for (int j = 0; j < (VALU < 100 ? VALU : VALU - 100); ++j) {
+                // VALU >= 100: transcendental instructions (alternating v_exp_f32 / v_rcp_f32) instead of v_fma_f32
+                if (VALU >= 100) v = (j & 1) ? __builtin_amdgcn_rcpf(v) : __builtin_amdgcn_exp2f(v);
+                else v = __builtin_fmaf(v, 1.0001f, 0.25f);
+                asm volatile("" : "+v"(v));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -53,7 +58,7 @@ void run(int threads, const char* name) {
     for (auto c : h) sum += (double)c;
     const double per_wave = sum / h.size() / (iters * 16.0);
     const int waves_per_simd = threads / 256;
-    printf("%-34s waves/SIMD %d  VALU/MFMA %d : %7.2f ticks per MFMA per wave = %7.2f per SIMD slot\n", name, waves_per_simd, VALU,
+    printf("%-34s waves/SIMD %d  VALU/MFMA %3d : %7.2f ticks per MFMA per wave = %7.2f per SIMD slot\n", name, waves_per_simd, VALU,
            per_wave, per_wave / waves_per_simd);
     hipFree(out); hipFree(cyc);
 }
@@ -71,5 +76,9 @@ int main() {
     run<0, 6>(512, "one accumulator + VALU");
     run<0, 12>(512, "one accumulator + VALU");
     run<1, 6>(512, "two accumulators + VALU");
+    run<0, 102>(256, "one accumulator + 2 exp/rcp");
+    run<0, 106>(256, "one accumulator + 6 exp/rcp");
+    run<0, 106>(512, "one accumulator + 6 exp/rcp");
+    run<0, 112>(512, "one accumulator + 12 exp/rcp");
     return 0;
 }
