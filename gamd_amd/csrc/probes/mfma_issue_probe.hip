@@ -13,6 +13,8 @@ template <int MODE, int VALU>
 __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) {
     f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
     float x = threadIdx.x * 1e-3f, w = 1.0f + threadIdx.x * 1e-4f, v = 0.5f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 v2 = {0.5f, 0.25f}, c2 = {1.0001f, 0.9999f};
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < iters; ++i) {
@@ -27,17 +29,19 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int iters) 
                 if ((k & 3) == 3) a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, x, a3, 0, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < (VALU < 100 ? VALU : VALU - 100); ++j) {
-                // VALU >= 100: transcendental instructions (alternating v_exp_f32 / v_rcp_f32) instead of v_fma_f32
-                if (VALU >= 100) v = (j & 1) ? __builtin_amdgcn_rcpf(v) : __builtin_amdgcn_exp2f(v);
-                else v = __builtin_fmaf(v, 1.0001f, 0.25f);
-                asm volatile("" : "+v"(v));
+            for (int j = 0; j < VALU % 100; ++j) {
+                // VALU 1xx: transcendental instructions (alternating v_exp_f32 / v_rcp_f32) instead of v_fma_f32;
+                // VALU 2xx / 3xx: packed v_pk_mul_f32 / v_pk_fma_f32 (two elements per instruction)
+                if (VALU >= 300) { asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(v2) : "v"(c2)); }
+                else if (VALU >= 200) { asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v2) : "v"(c2)); }
+                else if (VALU >= 100) { v = (j & 1) ? __builtin_amdgcn_rcpf(v) : __builtin_amdgcn_exp2f(v); asm volatile("" : "+v"(v)); }
+                else { v = __builtin_fmaf(v, 1.0001f, 0.25f); asm volatile("" : "+v"(v)); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     const long long t1 = __builtin_readcyclecounter();
-    float s = v;
+    float s = v + v2[0] + v2[1];
     for (int i = 0; i < 16; ++i) s += a0[i] + a1[i] + a2[i] + a3[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
@@ -80,5 +84,9 @@ int main() {
     run<0, 106>(256, "one accumulator + 6 exp/rcp");
     run<0, 106>(512, "one accumulator + 6 exp/rcp");
     run<0, 112>(512, "one accumulator + 12 exp/rcp");
+    run<0, 206>(512, "one accumulator + 6 pk_mul");
+    run<0, 212>(512, "one accumulator + 12 pk_mul");
+    run<0, 306>(512, "one accumulator + 6 pk_fma");
+    run<0, 312>(512, "one accumulator + 12 pk_fma");
     return 0;
 }
