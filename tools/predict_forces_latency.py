@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-call latency of the reference-shaped host-buffer boundary, predict_forces(np.float64[N,3]) -> np.float64[N,3]
+(one sync per call, as the reference's OpenMM drivers use it): python tools/predict_forces_latency.py.  GPU box only."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gamd_amd import compat, workloads                                   # noqa: E402
+from gamd_amd.weights import ModelConfig, make_state_dict              # noqa: E402
+
+for n, rc in ((258, 7.5), (10000, 10.2)):
+    pos, box = workloads.lj_box(n, seed=3)
+    m = compat.ParticleNetLightningLJ(None, make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2), num_atoms=n,
+                                      box_size=float(box), cutoff=rc)
+    m.cuda(); m.eval()
+    p = pos.astype(np.float64)
+    for _ in range(20):
+        f = m.predict_forces(p)
+    reps = 300 if n < 1000 else 100
+    t0 = time.perf_counter()
+    for k in range(reps):
+        f = m.predict_forces(p + 1e-4 * (k & 1))
+    dt = (time.perf_counter() - t0) / reps
+    print(f"{n:6d} atoms: predict_forces {dt * 1e3:.3f} ms per call ({f.dtype}, {f.shape})")
