@@ -42,10 +42,18 @@ constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
 // 128x128 GEMM of the chain with a software-pipelined element-wise post-op: while output tile tp is
 // being accumulated (64 MFMAs in 16 groups of 4), post(tp-1, g) finishes element g of the previous,
 // already complete, output tile.  Only tile 3's post-op trails the last MFMA.
-template <bool F2, typename WPtr, typename Post>
-__device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post) {
+// mid() runs once, between output tiles 0 and 1 (64 MFMAs into the GEMM): memory instructions that are due "some time
+// during this phase" (the weight copy for the next phase, piece stores, C-in gathers) are issued there instead of in front
+// of the first MFMA, where they would queue behind the other waves' gathers on the CU's address path and keep the matrix
+// pipe idle after every barrier (CV_INGEMM).
+// BUNCH: the 16 post-op elements of output tile tp - 1 run as ONE block behind the first MFMA group of tile tp (fenced), not
+// one element per MFMA group: a wave that is alone on its SIMD pays for every switch between the matrix and the vector
+// stream (~38 cycles, probes/ws_chain_probe), 16 switches per output tile in the interleaved form, one in this one.
+template <bool F2, bool BUNCH = false, typename WPtr, typename Post, typename Mid>
+__device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post, Mid mid) {
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
+        if (tp == 1) mid();
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -56,6 +64,57 @@ __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)
                     const float x = X[t][q * 4 + j];
                     acc[tp] = F2 ? mfma32(x, w[j], acc[tp]) : mfma32(w[j], x, acc[tp]);
                 }
+                if (!BUNCH) { if (tp > 0) post(tp - 1, t * 4 + q); }
+                else if (tp > 0 && t == 0 && q == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) post(tp - 1, g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    if (BUNCH) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) post(3, g);
+}
+
+// The same GEMM with the weight fragments read from LDS in 8-byte HALVES, each half two MFMAs ahead of its use.  The
+// float4-per-group form above is single-buffered at the 256-VGPR cap (hipcc re-uses the four fragment registers: read,
+// s_waitcnt lgkmcnt(0), 4 MFMAs, next read), i.e. the LDS latency of every fragment is exposed unless the OTHER wave of
+// the SIMD has MFMAs to issue meanwhile — and for about half of every phase it has not (it waits at the barrier, or its
+// GEMM is over).  Here the four registers hold two halves that are refilled as soon as the two MFMAs that use them have
+// issued, so a wave that is alone on its SIMD keeps the pipe full.  The reads are inline assembly (hipcc would merge them
+// back into one ds_read_b128); the waits are tied to the registers they guard, so no MFMA can be scheduled above its wait.
+template <bool F2, typename Post, typename Mid>
+__device__ __forceinline__ void gemm128_post_hf(const float* Wlds, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post, Mid mid) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)Wlds + (unsigned)lane * 16u;
+    f32x2_t lo, hi;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(lo) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(hi) : "v"(addr));
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+        if (tp == 1) mid();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = (tp * 4 + t) * 4 + q;
+                if (g < 63) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(lo)); else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(lo));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float x = X[t][q * 4 + j];
+                    acc[tp] = F2 ? mfma32(x, lo[j], acc[tp]) : mfma32(lo[j], x, acc[tp]);
+                }
+                if (g < 63) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"((g + 1) * 1024));
+                if (g < 63) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(hi)); else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hi));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float x = X[t][q * 4 + 2 + j];
+                    acc[tp] = F2 ? mfma32(x, hi[j], acc[tp]) : mfma32(hi[j], x, acc[tp]);
+                }
+                if (g < 63) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"((g + 1) * 1024 + 8));
                 if (tp > 0) post(tp - 1, t * 4 + q);
             }
         }
@@ -68,10 +127,10 @@ __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)
 // recent VMEM loads) landed, then the workgroup meets.  The N prefetch loads stay in flight.
 // vmcnt retires in order, so "at most N outstanding" proves the older DMA is done only if at least
 // N loads really were issued after it: callers pass 0 on paths that skip the prefetch.
-template <int N>
+template <int N, bool SYNC = true>
 __device__ __forceinline__ void phase_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_s_barrier();
+    if (SYNC) __builtin_amdgcn_s_barrier();
 }
 
 __device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, int tile, int lane, f32x16 (&X)[4]) {
@@ -95,6 +154,12 @@ enum {
     CV_TIME = 1,         // per-segment cycle counters -> a.tdbg
     CV_SYM_GATHER = 2,   // every wave issues its gathers BEFORE the phase barrier (round-1 schedule; see below)
     CV_TRACKED_DMA = 4,  // the weight copy through __builtin_amdgcn_global_load_lds (compiler-tracked: see gamd_stage_weight_raw)
+    CV_INGEMM = 8,       // weight copy / piece stores / D gather issued 64 MFMAs into the GEMM instead of at the phase boundary
+    CV_HALFFRAG = 16,    // weight fragments read in 8-byte halves two MFMAs ahead (gemm128_post_hf)
+    CV_NOBARRIER = 32,   // TIMING ONLY (results invalid): the phase barriers are skipped, waves run free
+    CV_NOPIECES = 64,    // TIMING ONLY: no piece stores
+    CV_ROW0 = 128,       // TIMING ONLY: every S / D / hn gather reads row 0 (cache-hot)
+    CV_BUNCH = 256,      // post-ops of an output tile as one fenced block (gemm128_post<.., BUNCH>)
 };
 #ifndef CONV_PRODUCTION
 #define CONV_PRODUCTION 0
@@ -137,6 +202,9 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     const int n_iter = ((end - first + step - 1) / step + 1) / 2;
     const int wsub = wave & 3, whalf = wave >> 2;
     const bool early = (V & CV_SYM_GATHER) ? true : whalf == 0;       // gathers before (true) / after (false) the barrier
+    constexpr bool INGEMM = (V & CV_INGEMM) != 0;
+    // vmcnt budget of a late wave at a boundary: with the copy issued inside the GEMM nothing younger than it is in flight
+    constexpr int LATE_N = INGEMM ? 0 : 16;
     auto tile_of = [&](int it) {              // this wave's tile in iteration `it`, or n_tiles (inactive)
         const int u = first + (2 * it + whalf) * step;
         return (it < n_iter && u < end) ? u * 4 + wsub : n_tiles;
@@ -155,7 +223,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
 
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
     stage(a.w1p, buf0);
-    stage(a.w2p, buf1);                          // phase 1's copy (inside the loop it is issued at the previous tile's boundary 4)
+    if (!INGEMM) stage(a.w2p, buf1);             // phase 1's copy (inside the loop it is issued at the previous tile's boundary 4)
 
     // three 64-register sets rotate through the roles {GEMM input, GEMM output, prefetched gather}
     f32x16 RA[4], RB[4], RC[4];
@@ -175,9 +243,10 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
+        if (V & CV_ROW0) { src = 0; dst = 0; }
         if (active) {
             load_e_tile(a.e_frag, tile, lane, RA);
-            load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
+            if (!INGEMM) load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
         }
     }
     asm volatile("" ::"v"(src), "v"(dst));      // compiler-visible wait for the index loads (see phase 4)
@@ -209,102 +278,13 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     // both groups run the same gather code into the same registers.
 #define BOUNDARY(COND, N, STAGE_STMT)                               \
     do {                                                            \
-        if (COND) phase_barrier<N>(); else phase_barrier<0>();      \
-        STAGE_STMT;                                                 \
+        if (COND) phase_barrier<N, !(V & CV_NOBARRIER)>(); else phase_barrier<0, !(V & CV_NOBARRIER)>();      \
+        if (!INGEMM) { STAGE_STMT; }                                \
     } while (0)
-
-    for (int it = 0; it < n_iter; ++it) {
-        const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
-        int nvalid = E - x0;
-        nvalid = !active ? 0 : (nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid));
-        // next tile of this wave (indices prefetched during phase 3)
-        const int tile_n = tile_of(it + 1);
-        const bool active_n = tile_n < n_tiles;
-        int src_n = 0, dst_n = 0;
-
-        // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====
-        // (W2 -> buf1 was issued at the previous boundary)
-        if (active) {
-            load_bias_chain(vb1, half, RB);
-            TMARK(0);
-            gemm128_post<false>((const f32x4*)buf0, lane, RA, RB,
-                                [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
-            TMARK(1);
-        }
-        // boundary 1: S[src] -> RA for phase 2's post-op; W3 -> buf0.  Younger than the copy of W2: e, D (late) / D, S (early)
-        if (!early) BOUNDARY(active, 16, stage(a.w3p, buf0));
-        TMARK(2);
-        if (active) gather_S();
-        TMARK(3);
-        if (early) BOUNDARY(active, 16, stage(a.w3p, buf0));
-        // ===== phase 2: RC = SiLU(W2 T1 + D[dst] + S[src])        in RB, S in RA =====
-        if (active) {
-            gemm128_post<false>((const f32x4*)buf1, lane, RB, RC,
-                                [&](int tp, int g) { RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]); });
-            TMARK(4);
-        }
-        // boundary 2: hn[src] -> RA for phase 4; W4 -> buf1.  Younger than the copy of W3: S (late) / hn (early)
-        if (!early) BOUNDARY(active, 16, stage(a.w4p, buf1));
-        TMARK(5);
-        if (active) gather_hn();
-        TMARK(6);
-        if (early) BOUNDARY(active, 16, stage(a.w4p, buf1));
-        // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
-        unsigned mask = 0;
-        int p0 = 0;
-        // small index loads for phase 4 / the next tile go first: done long before the barrier needs vmcnt(0)
-        if (active) {
-            mask = a.chunk_mask[tile * 2 + half];
-            p0 = a.chunk_piece[tile * 2 + half];
-        }
-        if (active_n) {
-            const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
-            if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
-        }
-        if (active) {
-            load_bias_chain(vb3, half, RB);
-            TMARK(7);
-            gemm128_post<false>((const f32x4*)buf0, lane, RC, RB,
-                                [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); });
-            TMARK(8);
-        }
-        // boundary 3 (nothing to gather): everything has landed behind it
-        phase_barrier<0>();
-        // The index loads of phase 3 are complete, but hipcc cannot see a wait written in assembly: it would keep them on
-        // its scoreboard and later flush vmcnt(0) — in front of the piece-store loop, at the next tile's first use of src,
-        // and before it re-initialises src_n.  Naming the registers here makes it emit its wait now, where it costs nothing.
-        asm volatile("" ::"v"(mask), "v"(p0), "v"(src_n), "v"(dst_n));
-        stage(a.w1p, buf0);       // next tile's W1 (harmless on the last iteration: drained at boundary 4)
-        TMARK(9);
-        // ===== phase 4: RC = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
-        if (active) {
-            init_b4();
-            // e_emb for this lane's 16 edges x 4 features, then message + segment sum (nn_module.py:142
-            // u_mul_e -> sum).  In-stream part is branch-free: RC[tp][r] becomes the running sum of the
-            // messages of the current piece (reset after every edge that closes a destination segment).
-            const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
-            gemm128_post<true>((const f32x4*)buf1, lane, RB, RC, [&](int tp, int r) {
-                const float prod = (r < nvalid) ? RA[r >> 2][(r & 3) * 4 + tp] * RC[tp][r] : 0.f;
-                if (r == 0) RC[tp][0] = prod;
-                else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
-            });
-            // piece stores are deferred past the boundary (vmcnt counts stores too: issued here they would sit in front of
-            // the prefetch loads and a counted wait would wait for their write latency)
-            pend_ends = mask;
-            if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) pend_ends |= 1u << (nvalid - 1);
-            pend_p = p0;
-            TMARK(10);
-        }
-        // boundary 4: the next tile's e -> RA; its W2 -> buf1 (not behind the last tile: a copy must not outlive the
-        // workgroup).  Younger than the copy of W1: nothing (late) / e (early)
-        if (!early) BOUNDARY(false, 0, if (it + 1 < n_iter) stage(a.w2p, buf1));
-        TMARK(11);
-        if (active_n) load_e_tile(a.e_frag, tile_n, lane, RA);
-        TMARK(12);
-        if (early) BOUNDARY(active_n, 16, if (it + 1 < n_iter) stage(a.w2p, buf1));
-        TMARK(13);
-        // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge does
-        // not close a segment, that edge too (the run continues in the next chunk as its own piece)
+    // one store per finished piece of the previous tile: closing edges (mask bits) and, if the chunk's last valid edge does
+    // not close a segment, that edge too (the run continues in the next chunk as its own piece)
+    auto piece_stores = [&]() {
+        if (V & CV_NOPIECES) pend_ends = 0;
         while (__any(pend_ends != 0)) {
             if (pend_ends != 0) {
                 const int r = __builtin_ctz(pend_ends);
@@ -321,12 +301,141 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
                 ++pend_p;
             }
         }
-        // D[dst] of the next tile (C-in of its phase 2) -> RC, now free; lands during phase 1
-        if (active_n) load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
+    };
+    auto nomid = []() {};
+    (void)nomid;
+    // INGEMM: what a phase owes the memory system, issued 64 MFMAs into its GEMM (inactive waves still owe their share
+    // of the weight copy: the `else` branches below)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define GEMM(F2, BUF, IN, OUT, ...)                                                              \
+    do {                                                                                         \
+        if (V & CV_HALFFRAG) gemm128_post_hf<F2>(BUF, lane, IN, OUT, __VA_ARGS__);               \
+        else gemm128_post<F2, (V & CV_BUNCH) != 0>((const f32x4*)BUF, lane, IN, OUT, __VA_ARGS__); \
+    } while (0)
+
+    for (int it = 0; it < n_iter; ++it) {
+        const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
+        int nvalid = E - x0;
+        nvalid = !active ? 0 : (nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid));
+        // next tile of this wave (indices prefetched during phase 3)
+        const int tile_n = tile_of(it + 1);
+        const bool active_n = tile_n < n_tiles;
+        int src_n = 0, dst_n = 0;
+
+        // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====
+        // (W2 -> buf1 was issued at the previous boundary)
+        if (active) {
+            load_bias_chain(vb1, half, RB);
+            TMARK(0);
+            GEMM(false, buf0, RA, RB,
+                                [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); },
+                                [&]() {
+                                    if (INGEMM) {       // previous tile's pieces out of RC, then D[dst] (C-in of phase 2) into it, W2 -> buf1
+                                        FENCE();
+                                        piece_stores();
+                                        load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
+                                        stage(a.w2p, buf1);
+                                        FENCE();
+                                    }
+                                });
+            TMARK(1);
+        } else if (INGEMM) {
+            piece_stores();
+            stage(a.w2p, buf1);
+        }
+        // boundary 1: S[src] -> RA for phase 2's post-op; W3 -> buf0.  Younger than the copy of W2: e, D (late) / D, S (early)
+        if (!early) BOUNDARY(active, LATE_N, stage(a.w3p, buf0));
+        TMARK(2);
+        if (active) gather_S();
+        TMARK(3);
+        if (early) BOUNDARY(active, 16, stage(a.w3p, buf0));
+        // ===== phase 2: RC = SiLU(W2 T1 + D[dst] + S[src])        in RB, S in RA =====
+        if (active) {
+            GEMM(false, buf1, RB, RC,
+                                [&](int tp, int g) { RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]); },
+                                [&]() { if (INGEMM) { FENCE(); stage(a.w3p, buf0); FENCE(); } });
+            TMARK(4);
+        } else if (INGEMM) {
+            stage(a.w3p, buf0);
+        }
+        // boundary 2: hn[src] -> RA for phase 4; W4 -> buf1.  Younger than the copy of W3: S (late) / hn (early)
+        if (!early) BOUNDARY(active, LATE_N, stage(a.w4p, buf1));
+        TMARK(5);
+        if (active) gather_hn();
+        TMARK(6);
+        if (early) BOUNDARY(active, 16, stage(a.w4p, buf1));
+        // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
+        unsigned mask = 0;
+        int p0 = 0;
+        // small index loads for phase 4 / the next tile go first: done long before the barrier needs vmcnt(0)
+        if (active) {
+            mask = a.chunk_mask[tile * 2 + half];
+            p0 = a.chunk_piece[tile * 2 + half];
+        }
+        if (active_n) {
+            const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
+            if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
+            if (V & CV_ROW0) { src_n = 0; dst_n = 0; }
+        }
+        if (active) {
+            load_bias_chain(vb3, half, RB);
+            TMARK(7);
+            GEMM(false, buf0, RC, RB,
+                                [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); },
+                                [&]() { if (INGEMM) { FENCE(); stage(a.w4p, buf1); FENCE(); } });
+            TMARK(8);
+        } else if (INGEMM) {
+            stage(a.w4p, buf1);
+        }
+        // boundary 3 (nothing to gather): everything has landed behind it
+        phase_barrier<0, !(V & CV_NOBARRIER)>();
+        // The index loads of phase 3 are complete, but hipcc cannot see a wait written in assembly: it would keep them on
+        // its scoreboard and later flush vmcnt(0) — in front of the piece-store loop, at the next tile's first use of src,
+        // and before it re-initialises src_n.  Naming the registers here makes it emit its wait now, where it costs nothing.
+        asm volatile("" ::"v"(mask), "v"(p0), "v"(src_n), "v"(dst_n));
+        if (!INGEMM) stage(a.w1p, buf0);       // next tile's W1 (harmless on the last iteration: drained at boundary 4)
+        TMARK(9);
+        // ===== phase 4: RC = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
+        if (active) {
+            init_b4();
+            // e_emb for this lane's 16 edges x 4 features, then message + segment sum (nn_module.py:142
+            // u_mul_e -> sum).  In-stream part is branch-free: RC[tp][r] becomes the running sum of the
+            // messages of the current piece (reset after every edge that closes a destination segment).
+            const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
+            GEMM(true, buf1, RB, RC, [&](int tp, int r) {
+                const float prod = (r < nvalid) ? RA[r >> 2][(r & 3) * 4 + tp] * RC[tp][r] : 0.f;
+                if (r == 0) RC[tp][0] = prod;
+                else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
+            }, [&]() { if (INGEMM) { FENCE(); if (it + 1 < n_iter) stage(a.w1p, buf0); FENCE(); } });
+            // piece stores are deferred past the boundary (vmcnt counts stores too: issued here they would sit in front of
+            // the prefetch loads and a counted wait would wait for their write latency)
+            pend_ends = mask;
+            if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) pend_ends |= 1u << (nvalid - 1);
+            pend_p = p0;
+            TMARK(10);
+        } else if (INGEMM) {
+            if (it + 1 < n_iter) stage(a.w1p, buf0);
+        }
+        // boundary 4: the next tile's e -> RA; its W2 -> buf1 (not behind the last tile: a copy must not outlive the
+        // workgroup).  Younger than the copy of W1: nothing (late) / e (early)
+        if (!early) BOUNDARY(false, 0, if (it + 1 < n_iter) stage(a.w2p, buf1));      // (late waves: nothing younger than the copy)
+        TMARK(11);
+        if (active_n) load_e_tile(a.e_frag, tile_n, lane, RA);
+        TMARK(12);
+        if (early) BOUNDARY(active_n, 16, if (it + 1 < n_iter) stage(a.w2p, buf1));
+        TMARK(13);
+        if (!INGEMM) {
+            piece_stores();
+            // D[dst] of the next tile (C-in of its phase 2) -> RC, now free; lands during phase 1
+            if (active_n) load_row_chain(a.D + (size_t)dst_n * GAMD_H, half, RC);
+        }
         TMARK(14);
         tile = tile_n; active = active_n; src = src_n; dst = dst_n;
     }
 #undef BOUNDARY
+#undef FENCE
+#undef GEMM
+    if (INGEMM) piece_stores();            // the last tile's pieces
     if (TIME && a.tdbg && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) a.tdbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = tacc[i];
@@ -356,7 +465,7 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     if (v < 0) { const char* s = getenv("GAMD_CONV_VARIANT"); v = s ? atoi(s) : CONV_PRODUCTION; }
     switch (v) {
 #define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
-        CASE(0); CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7);
+        CASE(0); CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7); CASE(8); CASE(9); CASE(16); CASE(17); CASE(24); CASE(25); CASE(256); CASE(257); CASE(264); CASE(32); CASE(40); CASE(64); CASE(128); CASE(136); CASE(168);
 #undef CASE
         default: break;
     }

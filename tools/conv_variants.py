@@ -50,6 +50,7 @@ def child():
     if rec["variant"] & 1:
         t = eng._dbg(5, (256, 8, 16), np.int64).astype(np.float64)
         tot = t[:, :, :15].sum(-1)
+        rec["per_wave"] = [[float(t[:, wv, i].mean()) for i in range(15)] for wv in range(8)]
         rec["cycles"] = {"per_wave_total": float(tot.mean()),
                          "segments": {nm: [float(t[:, :, i].mean()), float(t[:, :4, i].mean()), float(t[:, 4:, i].mean())]
                                       for i, nm in enumerate(SEGMENTS)}}
@@ -81,6 +82,10 @@ def main():
             for nm, (a, o, y) in c["segments"].items():
                 print(f"    | {nm:24s} | {a / tiles_per_wave:8.0f} | {o / tiles_per_wave:8.0f} | {y / tiles_per_wave:8.0f} |")
             print(f"    | sum | {c['per_wave_total'] / tiles_per_wave:8.0f} |   (ideal 4 x 2 x 256 MFMA x 64 = 131072)")
+            if "--perwave" in sys.argv:
+                print("    per wave (columns = waves 0..7), ticks per tile:")
+                for i, nm in enumerate(SEGMENTS):
+                    print(f"    | {nm[:40]:40s} | " + " | ".join(f"{r['per_wave'][wv][i] / tiles_per_wave:7.0f}" for wv in range(8)) + " |")
     return 0
 
 
