@@ -157,12 +157,14 @@ enum {
     CV_INGEMM = 8,       // weight copy / piece stores / D gather issued 64 MFMAs into the GEMM instead of at the phase boundary
     CV_HALFFRAG = 16,    // weight fragments read in 8-byte halves two MFMAs ahead (gemm128_post_hf)
     CV_NOBARRIER = 32,   // TIMING ONLY (results invalid): the phase barriers are skipped, waves run free
-    CV_NOPIECES = 64,    // TIMING ONLY: no piece stores
     CV_ROW0 = 128,       // TIMING ONLY: every S / D / hn gather reads row 0 (cache-hot)
     CV_BUNCH = 256,      // post-ops of an output tile as one fenced block (gemm128_post<.., BUNCH>)
+    CV_CONTIG_DMA = 512, // weight copy: 8 contiguous KiB per wave, immediate offsets (gamd_stage_weight_raw_contig)
+    CV_HN2 = 1024,       // hn gather with one bpermute index register and scalar-base addressing (gather_hn2)
+    CV_ZROW = 2048,      // padding slots of the last tile gather the all-zero row n instead of being masked per element
 };
 #ifndef CONV_PRODUCTION
-#define CONV_PRODUCTION 0
+#define CONV_PRODUCTION (CV_INGEMM | CV_CONTIG_DMA | CV_HN2 | CV_ZROW)
 #endif
 
 // Gather schedule.  Of the two waves of a SIMD the one with the lower id is served first after a barrier (measured:
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     // L2 -> LDS copy of the next phase's weight matrix
     auto stage = [&](const float* gw, float* buf) {
         if (V & CV_TRACKED_DMA) gamd_stage_weight<8>(gw, buf, wave, lane16);
+        else if (V & CV_CONTIG_DMA) gamd_stage_weight_raw_contig<8>(gw, buf, wave, lane16);
         else gamd_stage_weight_raw<8>(gw, buf, wave, lane16);
     };
 
@@ -243,6 +246,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
+        else if (V & CV_ZROW) { src = a.zero_row; dst = a.zero_row; }
         if (V & CV_ROW0) { src = 0; dst = 0; }
         if (active) {
             load_e_tile(a.e_frag, tile, lane, RA);
@@ -272,6 +276,30 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         }
     };
 
+    // The same gather with ONE index register: ds_bpermute's immediate offset selects the lane (hipcc materialises the 16
+    // lane indices of __shfl as 16 loop-invariant VGPRs), the byte offset src * 512 is what travels, and the load takes the
+    // scalar base + 32-bit offset form (one v_add per edge instead of sign extension + 64-bit shift + 64-bit add).
+    auto gather_hn2 = [&]() {
+        const unsigned soff = (unsigned)src << 9;
+        const unsigned idx0 = 16u * (unsigned)half;                  // bpermute address = 4 * lane: lanes 4 half + ...
+        const unsigned slot16 = 16u * (unsigned)slot;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            unsigned o0, o1, o2, o3;
+            asm volatile("ds_bpermute_b32 %0, %4, %5 offset:%6\n\tds_bpermute_b32 %1, %4, %5 offset:%7\n\t"
+                         "ds_bpermute_b32 %2, %4, %5 offset:%8\n\tds_bpermute_b32 %3, %4, %5 offset:%9\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                         : "v"(idx0), "v"(soff), "n"(4 * (0 + 8 * r4)), "n"(4 * (1 + 8 * r4)), "n"(4 * (2 + 8 * r4)), "n"(4 * (3 + 8 * r4)));
+            const unsigned o[4] = {o0, o1, o2, o3};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 hv = *(const f32x4*)((const char*)a.hn + (o[k] + slot16));
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) RA[r4][k * 4 + tp] = hv[tp];
+            }
+        }
+    };
+
     // Phase boundary: barrier (every wave's share of the weight copy issued one boundary earlier has landed: at most N
     // younger VMEM operations may still be in flight) + the copy for the phase after the next barrier.  Waves that gather
     // early pass it AFTER their gathers, the others BEFORE: the branch is around the barrier, not around the loads, so
@@ -284,7 +312,6 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     // one store per finished piece of the previous tile: closing edges (mask bits) and, if the chunk's last valid edge does
     // not close a segment, that edge too (the run continues in the next chunk as its own piece)
     auto piece_stores = [&]() {
-        if (V & CV_NOPIECES) pend_ends = 0;
         while (__any(pend_ends != 0)) {
             if (pend_ends != 0) {
                 const int r = __builtin_ctz(pend_ends);
@@ -320,7 +347,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // next tile of this wave (indices prefetched during phase 3)
         const int tile_n = tile_of(it + 1);
         const bool active_n = tile_n < n_tiles;
-        int src_n = 0, dst_n = 0;
+        int src_n = (V & CV_ZROW) ? a.zero_row : 0, dst_n = src_n;      // padding slots: the all-zero row (CV_ZROW)
 
         // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====
         // (W2 -> buf1 was issued at the previous boundary)
@@ -361,7 +388,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // boundary 2: hn[src] -> RA for phase 4; W4 -> buf1.  Younger than the copy of W3: S (late) / hn (early)
         if (!early) BOUNDARY(active, LATE_N, stage(a.w4p, buf1));
         TMARK(5);
-        if (active) gather_hn();
+        if (active) { if (V & CV_HN2) gather_hn2(); else gather_hn(); }
         TMARK(6);
         if (early) BOUNDARY(active, 16, stage(a.w4p, buf1));
         // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
@@ -403,9 +430,9 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             // messages of the current piece (reset after every edge that closes a destination segment).
             const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
             GEMM(true, buf1, RB, RC, [&](int tp, int r) {
-                const float prod = (r < nvalid) ? RA[r >> 2][(r & 3) * 4 + tp] * RC[tp][r] : 0.f;
-                if (r == 0) RC[tp][0] = prod;
-                else RC[tp][r] = (((keep_bits >> r) & 1u) ? RC[tp][r - 1] : 0.f) + prod;
+                // padding edges (r >= nvalid, last tile only): masked here, or hn[zero_row] = 0 makes the product an exact zero
+                const float hnv = (V & CV_ZROW) ? RA[r >> 2][(r & 3) * 4 + tp] : ((r < nvalid) ? RA[r >> 2][(r & 3) * 4 + tp] : 0.f);
+                RC[tp][r] = gamd_msg_acc(hnv, RC[tp][r], (r > 0 && ((keep_bits >> r) & 1u)) ? RC[tp][r - 1] : 0.f);
             }, [&]() { if (INGEMM) { FENCE(); if (it + 1 < n_iter) stage(a.w1p, buf0); FENCE(); } });
             // piece stores are deferred past the boundary (vmcnt counts stores too: issued here they would sit in front of
             // the prefetch loads and a counted wait would wait for their write latency)
@@ -465,7 +492,9 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     if (v < 0) { const char* s = getenv("GAMD_CONV_VARIANT"); v = s ? atoi(s) : CONV_PRODUCTION; }
     switch (v) {
 #define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
-        CASE(0); CASE(1); CASE(2); CASE(3); CASE(4); CASE(5); CASE(6); CASE(7); CASE(8); CASE(9); CASE(16); CASE(17); CASE(24); CASE(25); CASE(256); CASE(257); CASE(264); CASE(32); CASE(40); CASE(64); CASE(128); CASE(136); CASE(168);
+        CASE(0); CASE(1); CASE(2); CASE(4); CASE(6); CASE(8); CASE(9); CASE(16); CASE(24); CASE(32); CASE(40); CASE(128);
+        CASE(256); CASE(264); CASE(512); CASE(520); CASE(1544); CASE(3592); CASE(3593); CASE(3608); CASE(3848); CASE(3624);
+        CASE(3720);
 #undef CASE
         default: break;
     }

@@ -116,9 +116,7 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
             gemm_quarter<true>(cur, X, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float prod = (r < nvalid) ? hn_q[ob][r] * acc[r] : 0.f;
-                if (r == 0) acc[0] = prod;
-                else acc[r] = (((keep_bits >> r) & 1u) ? acc[r - 1] : 0.f) + prod;
+                acc[r] = gamd_msg_acc((r < nvalid) ? hn_q[ob][r] : 0.f, acc[r], (r > 0 && ((keep_bits >> r) & 1u)) ? acc[r - 1] : 0.f);
             }
             unsigned ends = ends0;
             int p = p0;

@@ -519,6 +519,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
         ca.partial = h->partial.as<float>();
         ca.e_cap = h->e_cap;
+        ca.zero_row = h->n;
         ca.tdbg = h->tdbg.as<long long>();
         if ((r = tev_begin(l))) return r;                        // kind l: conv-layer edge kernel of layer l
         r = h->wide_conv ? (small_tiles > 0 ? launch_conv_edge_small_wide(ca, h->EHT, h->HT, small_tiles, st)
@@ -679,9 +680,11 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->na_excl.ensure(sizeof(int) * (n + 1), true);
     const size_t nh = n * (size_t)H * sizeof(float), nd = n * 128 * sizeof(float);
     r |= h->hbuf.ensure(nh * (cfg->keep_stages ? (size_t)h->L + 1 : 2), true);
-    r |= h->hn.ensure(nh, true);
-    r |= h->S.ensure(nd, true);
-    r |= h->D.ensure(nd, true);
+    // one extra, all-zero row (index n) behind the node tables the conv-layer edge kernel gathers from: the padding
+    // slots of the last 32-edge tile point at it, so their messages are exact zeros without a per-element mask
+    r |= h->hn.ensure(nh + (size_t)H * sizeof(float), true);
+    r |= h->S.ensure(nd + 128 * sizeof(float), true);
+    r |= h->D.ensure(nd + 128 * sizeof(float), true);
     r |= h->P.ensure(nd, true);
     r |= h->f_norm.ensure(sizeof(float) * 3 * n, true);
     r |= h->f_den.ensure(sizeof(float) * 3 * n, true);

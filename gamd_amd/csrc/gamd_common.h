@@ -151,6 +151,12 @@ __device__ __forceinline__ float gamd_min_image_wrapped(float d, float L, float 
     return t - halfL;
 }
 
+// Message of one edge folded into the running sum of its partial-sum piece (nn_module.py:142, u_mul_e -> sum): a single fused
+// multiply-add, i.e. hn[src] * e_emb is not rounded before it is added (the reference multiplies and adds separately; the
+// two differ by at most half an ulp of the product).  Every fp32 conv-layer edge kernel uses this form, so they stay
+// bit-identical to one another.
+__device__ __forceinline__ float gamd_msg_acc(float hn, float e_emb, float prev) { return __builtin_fmaf(hn, e_emb, prev); }
+
 // bias fragment in chain layout: 16 float4 (one per (t,q)), from a plain [128] vector
 template <typename BPtr>
 __device__ __forceinline__ void load_bias_chain(BPtr b, int half, f32x16 (&acc)[4]) {
@@ -259,6 +265,28 @@ __device__ __forceinline__ void gamd_stage_weight_raw(const float* __restrict__ 
                      ::"v"(lane16), "s"(reinterpret_cast<const char*>(gw) + chunk * 1024), "s"(lds0 + chunk * 1024u)
                      : "memory");
     }
+}
+
+// The same copy with each wave's 64 / NW KiB CONTIGUOUS (chunks wave * 64 / NW ... ) and addressed by the instruction's
+// immediate offset, which advances the global and the LDS side alike: one scalar base pair + one M0 value per four
+// KiB-sized copies instead of one of each per copy.  The per-copy form above keeps 8 x 3 loop-invariant SGPRs per matrix
+// alive, which hipcc spills to VGPR lanes and restores with two v_readlane per copy (~160 per tile in k_conv_edge).
+template <int NW = 8>
+__device__ __forceinline__ void gamd_stage_weight_raw_contig(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
+    static_assert(64 / NW == 8 || 64 / NW == 4, "4 or 8 KiB per wave");
+    int woff = wave * (64 / NW) * 1024;
+    asm volatile("" : "+s"(woff));                      // rebuilt per call (2 scalar adds), never kept across the tile loop
+    const char* g0 = reinterpret_cast<const char*>(gw) + woff;
+    const unsigned l0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf + (unsigned)woff;
+#pragma unroll
+    for (int h = 0; h < 64 / NW / 4; ++h)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %0, %1\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:3072"
+                     ::"v"(lane16), "s"(g0 + h * 4096), "s"(l0 + h * 4096u)
+                     : "memory");
 }
 
 // Latency-oriented split of a 32-row tile over the 4 waves of a 256-thread workgroup (node.hip, conv_edge_small.hip,

@@ -136,6 +136,7 @@ struct ConvEdgeArgs {
     const float* b1; const float* b3; const float* b4;                           // [128]
     float* partial;            // [pieces][128]
     long long e_cap;
+    int zero_row;              // = n: hn / S / D have one extra all-zero row for the padding slots of the last tile
     long long* tdbg;           // profiling builds only: [blocks][8 waves][16] cycle sums, or null
 };
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);

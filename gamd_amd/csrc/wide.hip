@@ -318,9 +318,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
                 for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float prod = (r < nvalid) ? X[tp][r] * U[tp][r] : 0.f;
-                        if (r == 0) U[tp][0] = prod;
-                        else U[tp][r] = (((keep_bits >> r) & 1u) ? U[tp][r - 1] : 0.f) + prod;
+                        U[tp][r] = gamd_msg_acc((r < nvalid) ? X[tp][r] : 0.f, U[tp][r], (r > 0 && ((keep_bits >> r) & 1u)) ? U[tp][r - 1] : 0.f);
                     }
                 unsigned ends = mask;
                 if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends |= 1u << (nvalid - 1);
