@@ -162,6 +162,7 @@ enum {
     CV_CONTIG_DMA = 512, // weight copy: 8 contiguous KiB per wave, immediate offsets (gamd_stage_weight_raw_contig)
     CV_HN2 = 1024,       // hn gather with one bpermute index register and scalar-base addressing (gather_hn2)
     CV_ZROW = 2048,      // padding slots of the last tile gather the all-zero row n instead of being masked per element
+    CV_PIDX = 4096,      // piece stores read the closing edge's registers by scalar index (piece_stores_idx)
 };
 #ifndef CONV_PRODUCTION
 #define CONV_PRODUCTION (CV_INGEMM | CV_CONTIG_DMA | CV_HN2 | CV_ZROW)
@@ -311,7 +312,28 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     } while (0)
     // one store per finished piece of the previous tile: closing edges (mask bits) and, if the chunk's last valid edge does
     // not close a segment, that edge too (the run continues in the next chunk as its own piece)
+    // The lanes of a half share pend_ends, so the register index of a closing edge is one scalar per half: two indexed
+    // register reads + one select per output block instead of a 15-deep select chain (CV_PIDX).
+    auto piece_stores_idx = [&]() {
+        unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)pend_ends, 0), e1 = (unsigned)__builtin_amdgcn_readlane((int)pend_ends, 32);
+        while ((e0 | e1) != 0) {
+            const int r0 = e0 ? __builtin_ctz(e0) : 0, r1 = e1 ? __builtin_ctz(e1) : 0;
+            f32x4 pv;
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const float v0 = RC[tp][r0], v1 = RC[tp][r1];
+                pv[tp] = half ? v1 : v0;
+            }
+            if (half ? (e1 != 0) : (e0 != 0)) {
+                *(f32x4*)(a.partial + (size_t)pend_p * GAMD_H + 4 * slot) = pv;
+                ++pend_p;
+            }
+            e0 &= e0 - 1; e1 &= e1 - 1;
+        }
+        pend_ends = 0;
+    };
     auto piece_stores = [&]() {
+        if (V & CV_PIDX) { piece_stores_idx(); return; }
         while (__any(pend_ends != 0)) {
             if (pend_ends != 0) {
                 const int r = __builtin_ctz(pend_ends);
@@ -494,7 +516,7 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
 #define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
         CASE(0); CASE(1); CASE(2); CASE(4); CASE(6); CASE(8); CASE(9); CASE(16); CASE(24); CASE(32); CASE(40); CASE(128);
         CASE(256); CASE(264); CASE(512); CASE(520); CASE(1544); CASE(3592); CASE(3593); CASE(3608); CASE(3848); CASE(3624);
-        CASE(3720);
+        CASE(3720); CASE(7688); CASE(7689);
 #undef CASE
         default: break;
     }
