@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of a tools/gpu_profile_round.sh run (gpurun_out/<tag>/) into profiles/ under the round's names.
-# Usage: bash tools/collect_profiles.sh r02b r02_final
+# Usage: bash tools/collect_profiles.sh r03a r03_a   (raw logs go to profiles/<round>_raw/)
 set -eu
 src=gpurun_out/$1; dst=profiles; name=$2
 hdr='`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --steps 50 --warmup 5 --workload <w>` (tools/gpu_profile_round.sh)'
@@ -9,6 +9,7 @@ for w in c2 c5; do cp $src/pmc_$w.md $dst/${name}_pmc_$w.md; done
 tail -1 $src/bench_default.json > $dst/${name}_bench_default.json
 tail -1 $src/bench_f16x3.json > $dst/${name}_bench_f16x3.json
 cp $src/pmc_conv_edge.json $dst/pmc_conv_edge.json
-mkdir -p $dst/r02_raw
-cp $src/conv_variants_sched.log $dst/r02_raw/conv_variants_final_sched.log
-cp $src/conv_variants_cycles.log $dst/r02_raw/conv_variants_final_cycles.log
+raw=$dst/${name%%_*}_raw
+mkdir -p $raw
+cp $src/conv_variants_sched.log $raw/${name}_conv_variants_sched.log
+cp $src/conv_variants_cycles.log $raw/${name}_conv_variants_cycles.log

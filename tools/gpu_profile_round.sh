@@ -21,8 +21,8 @@ for w in c2 c5; do
 done
 python3 tools/profile_summary.py pmcjson $out/pmc_fetch_c2 $out/pmc_write_c2 k_conv_edge $out/pmc_conv_edge.json > /dev/null
 # conv-layer kernel: scheduling variants A/B and the s_memtime marks (profiling build)
-python3 tools/conv_variants.py 0 2 4 6 > $out/conv_variants_sched.log 2>&1
-python3 tools/conv_variants.py 1 --cycles > $out/conv_variants_cycles.log 2>&1
+python3 tools/conv_variants.py 3592 0 8 520 1544 3848 > $out/conv_variants_sched.log 2>&1
+python3 tools/conv_variants.py 3593 --cycles > $out/conv_variants_cycles.log 2>&1
 # keep the merge-back small: only the summaries and the per-kernel stats csv
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*agent_info.csv" -delete
 ls -la $out | head -50
