@@ -13,16 +13,21 @@
 // global_load_lds into a two-slot ring, one matrix ahead of the GEMM that consumes it; one
 // workgroup barrier per GEMM phase.
 //
-// What the schedule is built around (measured with s_memtime, profiles/r01_conv_edge_cycles.md):
-// the two waves of a SIMD do NOT interleave their MFMA streams — the older wave owns the matrix pipe
-// until its GEMM is done, then the younger one runs.  A phase therefore costs
-//     (older wave: barrier release -> first MFMA) + 2 GEMMs + (younger wave: last MFMA -> barrier).
-// So: (1) everything a GEMM needs besides its LDS weights is loaded a phase ahead, into whichever of
-// the three 64-register sets is free — by the older waves BEFORE the barrier (the loads stay in
-// flight across it: raw s_barrier + counted vmcnt, only the weight copy must have landed), by the
-// younger waves right AFTER it (see "Gather schedule" below);
-// (2) element-wise post-ops (SiLU, message, segment sum) of output tile tp-1 are issued in the
-// shadow of the MFMAs of tile tp, so only a quarter of them trails the last MFMA.
+// What the schedule is built around (profiles/r01_conv_edge_cycles.md, r02_ / r03_conv_edge_experiments.md):
+// the two waves of a SIMD serialise their MFMA streams — whoever gets the matrix pipe first after a barrier keeps it
+// until its GEMM is done, then the other one runs.  A phase therefore costs 2 GEMMs + whatever sits between the barrier
+// and the first MFMA.  So:
+// (1) everything a GEMM needs besides its LDS weights is loaded a phase ahead, into whichever of the three 64-register
+// sets is free — by waves 0-3 BEFORE the barrier (the loads stay in flight across it: raw s_barrier + counted vmcnt),
+// by waves 4-7 right AFTER it (see "Gather schedule" below);
+// (2) nothing but the accumulator initialisation stands between a barrier and the first MFMA: the weight copy for the
+// next phase, the piece stores of the previous tile and the D[dst] gather are issued 64 MFMAs INTO the GEMM (mid()
+// hook).  In front of the GEMM they queued behind the other waves' gathers on the CU's address path, and the 8 x 3
+// loop-invariant SGPRs of the per-copy addresses were restored from VGPR lanes (two v_readlane per copy) on that
+// critical stretch; the copy now takes one base pair + immediate offsets (gamd_stage_weight_raw_contig);
+// (3) element-wise post-ops (SiLU, message, segment sum) of output tile tp-1 are issued between the MFMA groups of tile
+// tp.  fp32 MFMA and VALU share the SIMD's lanes, so this hides latency, not work: the kernel without any post-op runs
+// at 0.87-0.89 of the matrix peak, with them at 0.81 (timing ablations in r03_conv_edge_experiments.md).
 //
 // The last GEMM runs in the F2 orientation so each lane ends up with 16 edges x 4 features: the
 // multiply by hn[src] and the segment sum are in-lane, and every maximal run of edges (same
@@ -49,6 +54,25 @@ constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
 // BUNCH: the 16 post-op elements of output tile tp - 1 run as ONE block behind the first MFMA group of tile tp (fenced), not
 // one element per MFMA group: a wave that is alone on its SIMD pays for every switch between the matrix and the vector
 // stream (~38 cycles, probes/ws_chain_probe), 16 switches per output tile in the interleaved form, one in this one.
+// SiLU of a whole 16-register output block on PAIRS of elements: the multiply by -log2(e), the "+ 1" and the final product
+// as packed instructions with the constants in registers (hipcc keeps them scalar because v_pk_* cannot take a literal);
+// per element the same IEEE operations as gamd_silu_hw, so the bits do not change.  add: S[src] block of phase 2, or null.
+__device__ __forceinline__ void silu_block16(f32x16& v, const f32x16* add, float c_neg_log2e, float c_one) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 c = {c_neg_log2e, c_neg_log2e}, one = {c_one, c_one};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f2 x = {v[2 * k], v[2 * k + 1]};
+        if (add) { const f2 s2 = {(*add)[2 * k], (*add)[2 * k + 1]}; x = x + s2; }
+        f2 y = x * c;
+        y[0] = __builtin_amdgcn_exp2f(y[0]); y[1] = __builtin_amdgcn_exp2f(y[1]);
+        y = y + one;
+        y[0] = __builtin_amdgcn_rcpf(y[0]); y[1] = __builtin_amdgcn_rcpf(y[1]);
+        x = x * y;
+        v[2 * k] = x[0]; v[2 * k + 1] = x[1];
+    }
+}
+
 template <bool F2, bool BUNCH = false, typename WPtr, typename Post, typename Mid>
 __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post, Mid mid) {
 #pragma unroll
@@ -67,32 +91,28 @@ __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)
                 if (!BUNCH) { if (tp > 0) post(tp - 1, t * 4 + q); }
                 else if (tp > 0 && t == 0 && q == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) post(tp - 1, g);
+                    post(tp - 1, -1);                                   // g = -1: the whole block
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     }
-    if (BUNCH) __builtin_amdgcn_sched_barrier(0);
+    if (BUNCH) { __builtin_amdgcn_sched_barrier(0); post(3, -1); return; }
 #pragma unroll
     for (int g = 0; g < 16; ++g) post(3, g);
 }
 
-// The same GEMM with the weight fragments read from LDS in 8-byte HALVES, each half two MFMAs ahead of its use.  The
-// float4-per-group form above is single-buffered at the 256-VGPR cap (hipcc re-uses the four fragment registers: read,
-// s_waitcnt lgkmcnt(0), 4 MFMAs, next read), i.e. the LDS latency of every fragment is exposed unless the OTHER wave of
-// the SIMD has MFMAs to issue meanwhile — and for about half of every phase it has not (it waits at the barrier, or its
-// GEMM is over).  Here the four registers hold two halves that are refilled as soon as the two MFMAs that use them have
-// issued, so a wave that is alone on its SIMD keeps the pipe full.  The reads are inline assembly (hipcc would merge them
-// back into one ds_read_b128); the waits are tied to the registers they guard, so no MFMA can be scheduled above its wait.
-template <bool F2, typename Post, typename Mid>
-__device__ __forceinline__ void gemm128_post_hf(const float* Wlds, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post, Mid mid) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// The same GEMM with an explicit ring of D fragment buffers (4 registers each): the read of fragment g + D is issued as soon
+// as the four MFMAs of fragment g have issued, so every read has D - 1 full groups (256 cycles each) to land (hipcc's own
+// schedule re-uses one or two buffers: read, s_waitcnt lgkmcnt(0), 4 MFMAs).  Measured neutral in the full kernel (CV_PF3,
+// profiles/r03_conv_edge_experiments.md): the LDS latency is already covered by the other wave of the SIMD.  The reads are
+// inline assembly and the waits are tied to the registers they guard, so no MFMA can be scheduled above its wait.
+template <bool F2, int D, typename Post, typename Mid>
+__device__ __forceinline__ void gemm128_post_pf(const float* Wlds, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post, Mid mid) {
     const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)Wlds + (unsigned)lane * 16u;
-    f32x2_t lo, hi;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(lo) : "v"(addr));
-    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(hi) : "v"(addr));
+    f32x4 w[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[d]) : "v"(addr), "n"(d * 1024));
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
         if (tp == 1) mid();
@@ -101,20 +121,16 @@ __device__ __forceinline__ void gemm128_post_hf(const float* Wlds, int lane, con
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int g = (tp * 4 + t) * 4 + q;
-                if (g < 63) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(lo)); else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(lo));
+                f32x4& cur = w[g % D];
+                // reads return in order: at most min(D - 1, 63 - g) younger ones may still be in flight
+                if (63 - g >= D - 1) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur) : "n"(D - 1));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 4; ++j) {
                     const float x = X[t][q * 4 + j];
-                    acc[tp] = F2 ? mfma32(x, lo[j], acc[tp]) : mfma32(lo[j], x, acc[tp]);
+                    acc[tp] = F2 ? mfma32(x, cur[j], acc[tp]) : mfma32(cur[j], x, acc[tp]);
                 }
-                if (g < 63) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"((g + 1) * 1024));
-                if (g < 63) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(hi)); else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hi));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float x = X[t][q * 4 + 2 + j];
-                    acc[tp] = F2 ? mfma32(x, hi[j], acc[tp]) : mfma32(hi[j], x, acc[tp]);
-                }
-                if (g < 63) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"((g + 1) * 1024 + 8));
+                if (g + D < 64) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(cur) : "v"(addr), "n"((g + D) * 1024));
                 if (tp > 0) post(tp - 1, t * 4 + q);
             }
         }
@@ -155,14 +171,17 @@ enum {
     CV_SYM_GATHER = 2,   // every wave issues its gathers BEFORE the phase barrier (round-1 schedule; see below)
     CV_TRACKED_DMA = 4,  // the weight copy through __builtin_amdgcn_global_load_lds (compiler-tracked: see gamd_stage_weight_raw)
     CV_INGEMM = 8,       // weight copy / piece stores / D gather issued 64 MFMAs into the GEMM instead of at the phase boundary
-    CV_HALFFRAG = 16,    // weight fragments read in 8-byte halves two MFMAs ahead (gemm128_post_hf)
     CV_NOBARRIER = 32,   // TIMING ONLY (results invalid): the phase barriers are skipped, waves run free
     CV_ROW0 = 128,       // TIMING ONLY: every S / D / hn gather reads row 0 (cache-hot)
     CV_BUNCH = 256,      // post-ops of an output tile as one fenced block (gemm128_post<.., BUNCH>)
     CV_CONTIG_DMA = 512, // weight copy: 8 contiguous KiB per wave, immediate offsets (gamd_stage_weight_raw_contig)
     CV_HN2 = 1024,       // hn gather with one bpermute index register and scalar-base addressing (gather_hn2)
     CV_ZROW = 2048,      // padding slots of the last tile gather the all-zero row n instead of being masked per element
-    CV_PIDX = 4096,      // piece stores read the closing edge's registers by scalar index (piece_stores_idx)
+    CV_NOPOST = 8192,    // TIMING ONLY: no element-wise post-ops at all (SiLU, S add, message / segment sum skipped)
+    CV_NOGATHER = 16384, // TIMING ONLY: no S / D / hn gathers and no e prefetch (registers keep stale values)
+    CV_PF3 = 32768,      // weight fragments through an explicit ring of three buffers (gemm128_post_pf<3>)
+    CV_NODMA = 65536,    // TIMING ONLY: no weight copies after the prologue
+    CV_NOBIAS = 131072,  // TIMING ONLY: accumulators not initialised
 };
 #ifndef CONV_PRODUCTION
 #define CONV_PRODUCTION (CV_INGEMM | CV_CONTIG_DMA | CV_HN2 | CV_ZROW)
@@ -206,6 +225,8 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     const int wsub = wave & 3, whalf = wave >> 2;
     const bool early = (V & CV_SYM_GATHER) ? true : whalf == 0;       // gathers before (true) / after (false) the barrier
     constexpr bool INGEMM = (V & CV_INGEMM) != 0;
+    float c_nl2e = -1.4426950408889634f, c_one = 1.0f;          // SiLU constants in registers (silu_block16)
+    asm volatile("" : "+v"(c_nl2e), "+v"(c_one));
     // vmcnt budget of a late wave at a boundary: with the copy issued inside the GEMM nothing younger than it is in flight
     constexpr int LATE_N = INGEMM ? 0 : 16;
     auto tile_of = [&](int it) {              // this wave's tile in iteration `it`, or n_tiles (inactive)
@@ -213,7 +234,9 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         return (it < n_iter && u < end) ? u * 4 + wsub : n_tiles;
     };
     // L2 -> LDS copy of the next phase's weight matrix
+    bool dma_on = true;
     auto stage = [&](const float* gw, float* buf) {
+        if ((V & CV_NODMA) && !dma_on) return;
         if (V & CV_TRACKED_DMA) gamd_stage_weight<8>(gw, buf, wave, lane16);
         else if (V & CV_CONTIG_DMA) gamd_stage_weight_raw_contig<8>(gw, buf, wave, lane16);
         else gamd_stage_weight_raw<8>(gw, buf, wave, lane16);
@@ -312,28 +335,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     } while (0)
     // one store per finished piece of the previous tile: closing edges (mask bits) and, if the chunk's last valid edge does
     // not close a segment, that edge too (the run continues in the next chunk as its own piece)
-    // The lanes of a half share pend_ends, so the register index of a closing edge is one scalar per half: two indexed
-    // register reads + one select per output block instead of a 15-deep select chain (CV_PIDX).
-    auto piece_stores_idx = [&]() {
-        unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)pend_ends, 0), e1 = (unsigned)__builtin_amdgcn_readlane((int)pend_ends, 32);
-        while ((e0 | e1) != 0) {
-            const int r0 = e0 ? __builtin_ctz(e0) : 0, r1 = e1 ? __builtin_ctz(e1) : 0;
-            f32x4 pv;
-#pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                const float v0 = RC[tp][r0], v1 = RC[tp][r1];
-                pv[tp] = half ? v1 : v0;
-            }
-            if (half ? (e1 != 0) : (e0 != 0)) {
-                *(f32x4*)(a.partial + (size_t)pend_p * GAMD_H + 4 * slot) = pv;
-                ++pend_p;
-            }
-            e0 &= e0 - 1; e1 &= e1 - 1;
-        }
-        pend_ends = 0;
-    };
     auto piece_stores = [&]() {
-        if (V & CV_PIDX) { piece_stores_idx(); return; }
         while (__any(pend_ends != 0)) {
             if (pend_ends != 0) {
                 const int r = __builtin_ctz(pend_ends);
@@ -358,10 +360,11 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 #define GEMM(F2, BUF, IN, OUT, ...)                                                              \
     do {                                                                                         \
-        if (V & CV_HALFFRAG) gemm128_post_hf<F2>(BUF, lane, IN, OUT, __VA_ARGS__);               \
+        if (V & CV_PF3) gemm128_post_pf<F2, 3>(BUF, lane, IN, OUT, __VA_ARGS__);                 \
         else gemm128_post<F2, (V & CV_BUNCH) != 0>((const f32x4*)BUF, lane, IN, OUT, __VA_ARGS__); \
     } while (0)
 
+    if (V & CV_NODMA) dma_on = false;
     for (int it = 0; it < n_iter; ++it) {
         const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
         int nvalid = E - x0;
@@ -374,15 +377,18 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // ===== phase 1: RB = SiLU(W1 e + b1)        in RA = e (prefetched), RC = D[dst] (prefetched) =====
         // (W2 -> buf1 was issued at the previous boundary)
         if (active) {
-            load_bias_chain(vb1, half, RB);
+            if (!(V & CV_NOBIAS)) load_bias_chain(vb1, half, RB);
             TMARK(0);
             GEMM(false, buf0, RA, RB,
-                                [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); },
+                                [&](int tp, int g) {
+                                    if (V & CV_NOPOST) return;
+                                    if (g < 0) silu_block16(RB[tp], nullptr, c_nl2e, c_one); else RB[tp][g] = gamd_silu_hw(RB[tp][g]);
+                                },
                                 [&]() {
                                     if (INGEMM) {       // previous tile's pieces out of RC, then D[dst] (C-in of phase 2) into it, W2 -> buf1
                                         FENCE();
                                         piece_stores();
-                                        load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
+                                        if (!(V & CV_NOGATHER)) load_row_chain(a.D + (size_t)dst * GAMD_H, half, RC);
                                         stage(a.w2p, buf1);
                                         FENCE();
                                     }
@@ -395,13 +401,16 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // boundary 1: S[src] -> RA for phase 2's post-op; W3 -> buf0.  Younger than the copy of W2: e, D (late) / D, S (early)
         if (!early) BOUNDARY(active, LATE_N, stage(a.w3p, buf0));
         TMARK(2);
-        if (active) gather_S();
+        if (active && !(V & CV_NOGATHER)) gather_S();
         TMARK(3);
         if (early) BOUNDARY(active, 16, stage(a.w3p, buf0));
         // ===== phase 2: RC = SiLU(W2 T1 + D[dst] + S[src])        in RB, S in RA =====
         if (active) {
             GEMM(false, buf1, RB, RC,
-                                [&](int tp, int g) { RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]); },
+                                [&](int tp, int g) {
+                                    if (V & CV_NOPOST) return;
+                                    if (g < 0) silu_block16(RC[tp], &RA[tp], c_nl2e, c_one); else RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]);
+                                },
                                 [&]() { if (INGEMM) { FENCE(); stage(a.w3p, buf0); FENCE(); } });
             TMARK(4);
         } else if (INGEMM) {
@@ -410,7 +419,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // boundary 2: hn[src] -> RA for phase 4; W4 -> buf1.  Younger than the copy of W3: S (late) / hn (early)
         if (!early) BOUNDARY(active, LATE_N, stage(a.w4p, buf1));
         TMARK(5);
-        if (active) { if (V & CV_HN2) gather_hn2(); else gather_hn(); }
+        if (active && !(V & CV_NOGATHER)) { if (V & CV_HN2) gather_hn2(); else gather_hn(); }
         TMARK(6);
         if (early) BOUNDARY(active, 16, stage(a.w4p, buf1));
         // ===== phase 3: RB = SiLU(W3 T3 + b3)        in RC =====
@@ -427,10 +436,13 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             if (V & CV_ROW0) { src_n = 0; dst_n = 0; }
         }
         if (active) {
-            load_bias_chain(vb3, half, RB);
+            if (!(V & CV_NOBIAS)) load_bias_chain(vb3, half, RB);
             TMARK(7);
             GEMM(false, buf0, RC, RB,
-                                [&](int tp, int g) { RB[tp][g] = gamd_silu_hw(RB[tp][g]); },
+                                [&](int tp, int g) {
+                                    if (V & CV_NOPOST) return;
+                                    if (g < 0) silu_block16(RB[tp], nullptr, c_nl2e, c_one); else RB[tp][g] = gamd_silu_hw(RB[tp][g]);
+                                },
                                 [&]() { if (INGEMM) { FENCE(); stage(a.w4p, buf1); FENCE(); } });
             TMARK(8);
         } else if (INGEMM) {
@@ -446,15 +458,18 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         TMARK(9);
         // ===== phase 4: RC = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
         if (active) {
-            init_b4();
+            if (!(V & CV_NOBIAS)) init_b4();
             // e_emb for this lane's 16 edges x 4 features, then message + segment sum (nn_module.py:142
             // u_mul_e -> sum).  In-stream part is branch-free: RC[tp][r] becomes the running sum of the
             // messages of the current piece (reset after every edge that closes a destination segment).
             const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
-            GEMM(true, buf1, RB, RC, [&](int tp, int r) {
+            GEMM(true, buf1, RB, RC, [&](int tp, int rr) {
+              if (V & CV_NOPOST) return;
+              _Pragma("unroll") for (int r = (rr < 0 ? 0 : rr); r < (rr < 0 ? 16 : rr + 1); ++r) {
                 // padding edges (r >= nvalid, last tile only): masked here, or hn[zero_row] = 0 makes the product an exact zero
                 const float hnv = (V & CV_ZROW) ? RA[r >> 2][(r & 3) * 4 + tp] : ((r < nvalid) ? RA[r >> 2][(r & 3) * 4 + tp] : 0.f);
                 RC[tp][r] = gamd_msg_acc(hnv, RC[tp][r], (r > 0 && ((keep_bits >> r) & 1u)) ? RC[tp][r - 1] : 0.f);
+              }
             }, [&]() { if (INGEMM) { FENCE(); if (it + 1 < n_iter) stage(a.w1p, buf0); FENCE(); } });
             // piece stores are deferred past the boundary (vmcnt counts stores too: issued here they would sit in front of
             // the prefetch loads and a counted wait would wait for their write latency)
@@ -469,7 +484,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // workgroup).  Younger than the copy of W1: nothing (late) / e (early)
         if (!early) BOUNDARY(false, 0, if (it + 1 < n_iter) stage(a.w2p, buf1));      // (late waves: nothing younger than the copy)
         TMARK(11);
-        if (active_n) load_e_tile(a.e_frag, tile_n, lane, RA);
+        if (active_n && !(V & CV_NOGATHER)) load_e_tile(a.e_frag, tile_n, lane, RA);
         TMARK(12);
         if (early) BOUNDARY(active_n, 16, if (it + 1 < n_iter) stage(a.w2p, buf1));
         TMARK(13);
@@ -514,9 +529,9 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     if (v < 0) { const char* s = getenv("GAMD_CONV_VARIANT"); v = s ? atoi(s) : CONV_PRODUCTION; }
     switch (v) {
 #define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
-        CASE(0); CASE(1); CASE(2); CASE(4); CASE(6); CASE(8); CASE(9); CASE(16); CASE(24); CASE(32); CASE(40); CASE(128);
-        CASE(256); CASE(264); CASE(512); CASE(520); CASE(1544); CASE(3592); CASE(3593); CASE(3608); CASE(3848); CASE(3624);
-        CASE(3720); CASE(7688); CASE(7689);
+        // (CONV_PRODUCTION = 3592; | 1 = cycle marks)
+        CASE(0); CASE(1); CASE(2); CASE(4); CASE(6); CASE(8); CASE(520); CASE(1544); CASE(3592); CASE(3593); CASE(3624); CASE(3720);
+        CASE(3848); CASE(11784); CASE(19976); CASE(28168); CASE(36360); CASE(60936); CASE(126472); CASE(192008); CASE(257544);
 #undef CASE
         default: break;
     }
