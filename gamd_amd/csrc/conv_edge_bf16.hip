@@ -53,8 +53,9 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_bf16(ConvEdgeArgs a) {
         asm volatile("" ::: "memory");               // keep loop-invariant LDS reads (bias, weights) inside the loop
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
-        const int src = valid ? a.col[x] : 0;
-        const int dst = valid ? a.erow[x] : 0;
+        // padding slots of the last tile gather the all-zero row n of hn / S / D: their messages are exact zeros
+        const int src = valid ? a.col[x] : a.zero_row;
+        const int dst = valid ? a.erow[x] : a.zero_row;
 
         bf16x8 P[4][2];
         f32x16 RA[4], RB[4], RC[4];
@@ -80,13 +81,26 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_bf16(ConvEdgeArgs a) {
         const int x0 = tile * GAMD_TILE + 16 * half;
         int nvalid = E - x0;
         nvalid = nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid);
+        // (W4's output rows are packed permuted, gamd_finalize_weights: lane = features 4 slot .. 4 slot + 3, one 16-byte load
+        // per edge, landing in RA[r >> 2][4 (r & 3) + tp]; one bpermute index register + immediate lane offsets, scalar base +
+        // 32-bit offset addressing: conv_edge.hip's gather_hn2)
+        {
+            const unsigned soff = (unsigned)src << 9, idx0 = 16u * (unsigned)half, slot16 = 16u * (unsigned)slot;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rho = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int s = __shfl(src, rho, 64);
-            const float* hrow = a.hn + (size_t)s * GAMD_H + slot;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                unsigned o0, o1, o2, o3;
+                asm volatile("ds_bpermute_b32 %0, %4, %5 offset:%6\n\tds_bpermute_b32 %1, %4, %5 offset:%7\n\t"
+                             "ds_bpermute_b32 %2, %4, %5 offset:%8\n\tds_bpermute_b32 %3, %4, %5 offset:%9\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+                             : "v"(idx0), "v"(soff), "n"(4 * (0 + 8 * r4)), "n"(4 * (1 + 8 * r4)), "n"(4 * (2 + 8 * r4)), "n"(4 * (3 + 8 * r4)));
+                const unsigned o[4] = {o0, o1, o2, o3};
 #pragma unroll
-            for (int tp = 0; tp < 4; ++tp) RA[tp][r] = hrow[32 * tp];
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 hv = *(const f32x4*)((const char*)a.hn + (o[k] + slot16));
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) RA[r4][k * 4 + tp] = hv[tp];
+                }
+            }
         }
         gemm128_bf16<false>(W2, lane, P, RB);
 #pragma unroll
@@ -116,24 +130,23 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_bf16(ConvEdgeArgs a) {
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float prod = (r < nvalid) ? RA[tp][r] * RB[tp][r] : 0.f;
-                if (r == 0) RB[tp][0] = prod;
-                else RB[tp][r] = (((keep_bits >> r) & 1u) ? RB[tp][r - 1] : 0.f) + prod;
-            }
+            for (int r = 0; r < 16; ++r)
+                RB[tp][r] = gamd_msg_acc(RA[r >> 2][(r & 3) * 4 + tp], RB[tp][r], (r > 0 && ((keep_bits >> r) & 1u)) ? RB[tp][r - 1] : 0.f);
         unsigned ends = mask;
         if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends |= 1u << (nvalid - 1);
         while (__any(ends != 0)) {
             if (ends != 0) {
                 const int r = __builtin_ctz(ends);
                 ends &= ends - 1;
+                f32x4 pv;
 #pragma unroll
                 for (int tp = 0; tp < 4; ++tp) {
                     float v = RB[tp][0];
 #pragma unroll
                     for (int k = 1; k < 16; ++k) v = (r == k) ? RB[tp][k] : v;
-                    a.partial[(size_t)p * GAMD_H + 32 * tp + slot] = v;
+                    pv[tp] = v;
                 }
+                *(f32x4*)(a.partial + (size_t)p * GAMD_H + 4 * slot) = pv;
                 ++p;
             }
         }

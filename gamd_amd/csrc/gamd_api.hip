@@ -813,8 +813,24 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             return -2;
         Off& o = lo[l];
         HostTensor b4_perm;
+        // 128-wide fp32 and bf16 kernels (conv_edge.hip, conv_edge_small.hip, conv_edge_bf16.hip): output row 32 q + s of the
+        // packed W4 is feature 4 s + q, so a lane of the last GEMM's F2 output holds four CONSECUTIVE features of each edge —
+        // hn[src] is gathered and the pieces are stored 16 bytes at a time.  b4 is stored in the same order.
+        HostTensor w4_perm;
+        auto permute_w4 = [&]() {
+            w4_perm = *t3w;
+            b4_perm = *t3b;
+            for (int q = 0; q < 4; ++q)
+                for (int s = 0; s < 32; ++s) {
+                    std::copy(t3w->data.begin() + (size_t)(4 * s + q) * 128, t3w->data.begin() + (size_t)(4 * s + q + 1) * 128,
+                              w4_perm.data.begin() + (size_t)(32 * q + s) * 128);
+                    b4_perm.data[32 * q + s] = t3b->data[4 * s + q];
+                }
+            t3b = &b4_perm;
+        };
         if (bf16_edges) {
-            o.w1p = put_edge_bf16(ea0w); o.w2p = put_edge_bf16(ea2w); o.w3p = put_edge_bf16(t1w); o.w4p = put_edge_bf16(t3w);
+            permute_w4();
+            o.w1p = put_edge_bf16(ea0w); o.w2p = put_edge_bf16(ea2w); o.w3p = put_edge_bf16(t1w); o.w4p = put_edge_bf16(&w4_perm);
         } else if (f16x3_edges) {
             o.w1p = put_edge_f16x3(ea0w); o.w2p = put_edge_f16x3(ea2w); o.w3p = put_edge_f16x3(t1w); o.w4p = put_edge_f16x3(t3w);
         } else {
@@ -825,19 +841,8 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             if (h->wide_conv) {
                 o.w4p = put_blocks(t3w, (int)HT, 1);
             } else {
-                // 128-wide kernels (conv_edge.hip, conv_edge_small.hip): output row 32 q + s of the packed W4 is feature
-                // 4 s + q, so a lane of the last GEMM's F2 output holds four CONSECUTIVE features of each edge — hn[src]
-                // is gathered and the pieces are stored 16 bytes at a time.  b4 is stored in the same order.
-                HostTensor wp = *t3w;
-                b4_perm = *t3b;
-                for (int q = 0; q < 4; ++q)
-                    for (int s = 0; s < 32; ++s) {
-                        std::copy(t3w->data.begin() + (size_t)(4 * s + q) * 128, t3w->data.begin() + (size_t)(4 * s + q + 1) * 128,
-                                  wp.data.begin() + (size_t)(32 * q + s) * 128);
-                        b4_perm.data[32 * q + s] = t3b->data[4 * s + q];
-                    }
-                o.w4p = put_blocks(&wp, 1, 1);
-                t3b = &b4_perm;
+                permute_w4();
+                o.w4p = put_blocks(&w4_perm, 1, 1);
             }
         }
         o.b1 = put_vec(ea0b); o.b3 = put_vec(t1b); o.b4 = put_vec(t3b);
