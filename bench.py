@@ -396,11 +396,12 @@ def main():
                                       f"({rec.get('kernel_source_sha256_16')} != {kernel_source_hash()}): not reported")
         except Exception as exc:                                        # missing / unreadable file: say so, report null
             rl["traffic_note"] = f"no PMC record: {exc}"
-        rl["ceiling_note"] = ("gfx950 issues fp32 MFMA and VALU on the same lanes: a dependent v_mfma_f32_32x32x2_f32 chain runs at 64 "
-                              "cycles per instruction and every vector instruction between MFMAs adds its time even with two waves per "
-                              "SIMD: ~4.4 cycles per v_fma-class instruction, ~8.3 per v_exp_f32 / v_rcp_f32 (csrc/probes/"
-                              "mfma_issue_probe); 3 x 64 SiLU + message + sums are ~8.1 k cycles next to 65.5 k of MFMA per tile: "
-                              "this arithmetic cannot exceed ~0.89 of the matrix peak (~0.865 with the launch tail at this size)")
+        rl["ceiling_note"] = ("gfx950 issues fp32 MFMA and VALU on the same lanes (simple VALU 4 cycles, v_exp_f32 / v_rcp_f32 8, next to "
+                              "64 per v_mfma_f32_32x32x2_f32). Timing ablations of this kernel at this size (profiles/"
+                              "r03_conv_edge_experiments.md): the GEMM chain alone (LDS-fed MFMAs, barriers, piece stores) 0.90 of the "
+                              "matrix peak, of which 3 % is the launch tail (9.69 tiles per wave -> 10 rounds); the element-wise "
+                              "post-ops (3 x 64 SiLU, S add, message / segment sum per 32-edge tile) cost 5-7 %, weight copies 1 %, "
+                              "accumulator initialisation 0.8 %; gathers, barrier skew and LDS latency nothing")
         # SURVEY.md §8d "neighbour gather" figure: L2-served rows, so this is not HBM traffic; stated with its bound
         n_layers = 4
         gather_bytes = n_layers * (n_edges * 1028.0 + w.n_atoms * 1024.0)

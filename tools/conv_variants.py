@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of k_conv_edge variants (profiling build, libgamd_hip_prof.so) on the C2 workload.
 
-    python tools/conv_variants.py 0 1 2 8 16 32 ...
+    python tools/conv_variants.py 3592 0 520 1544 ...      (3592 = production, bit masks in conv_edge.hip)
 
 Every variant runs in its own process (the variant is latched per process by GAMD_CONV_VARIANT).  Prints one line per
 variant: average conv-layer time (HIP events around the launch, as bench.py does), TFLOP/s of the 131 072 FLOP/edge
