@@ -44,19 +44,10 @@ namespace {
 
 constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
 
-// 128x128 GEMM of the chain with a software-pipelined element-wise post-op: while output tile tp is
-// being accumulated (64 MFMAs in 16 groups of 4), post(tp-1, g) finishes element g of the previous,
-// already complete, output tile.  Only tile 3's post-op trails the last MFMA.
-// mid() runs once, between output tiles 0 and 1 (64 MFMAs into the GEMM): memory instructions that are due "some time
-// during this phase" (the weight copy for the next phase, piece stores, C-in gathers) are issued there instead of in front
-// of the first MFMA, where they would queue behind the other waves' gathers on the CU's address path and keep the matrix
-// pipe idle after every barrier (CV_INGEMM).
-// BUNCH: the 16 post-op elements of output tile tp - 1 run as ONE block behind the first MFMA group of tile tp (fenced), not
-// one element per MFMA group: a wave that is alone on its SIMD pays for every switch between the matrix and the vector
-// stream (~38 cycles, probes/ws_chain_probe), 16 switches per output tile in the interleaved form, one in this one.
 // SiLU of a whole 16-register output block on PAIRS of elements: the multiply by -log2(e), the "+ 1" and the final product
 // as packed instructions with the constants in registers (hipcc keeps them scalar because v_pk_* cannot take a literal);
 // per element the same IEEE operations as gamd_silu_hw, so the bits do not change.  add: S[src] block of phase 2, or null.
+// Used by the CV_BUNCH variant only (measured slower than the interleaved scalar form, r03_conv_edge_experiments.md §3).
 __device__ __forceinline__ void silu_block16(f32x16& v, const f32x16* add, float c_neg_log2e, float c_one) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 c = {c_neg_log2e, c_neg_log2e}, one = {c_one, c_one};
@@ -73,6 +64,15 @@ __device__ __forceinline__ void silu_block16(f32x16& v, const f32x16* add, float
     }
 }
 
+// 128x128 GEMM of the chain with a software-pipelined element-wise post-op: while output tile tp is being accumulated (64
+// MFMAs in 16 groups of 4), post(tp-1, g) finishes element g of the previous, already complete, output tile.  Only tile 3's
+// post-op trails the last MFMA.
+// mid() runs once, between output tiles 0 and 1 (64 MFMAs into the GEMM): memory instructions that are due "some time
+// during this phase" (the weight copy for the next phase, piece stores, C-in gathers) are issued there instead of in front
+// of the first MFMA, where they would queue behind the other waves' gathers on the CU's address path and keep the matrix
+// pipe idle after every barrier (CV_INGEMM).
+// BUNCH (variant): the 16 post-op elements of output tile tp - 1 run as ONE fenced block behind the first MFMA group of tile
+// tp (post(tp - 1, -1)) instead of one element per MFMA group.
 template <bool F2, bool BUNCH = false, typename WPtr, typename Post, typename Mid>
 __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post, Mid mid) {
 #pragma unroll
@@ -189,14 +189,13 @@ enum {
 
 // Gather schedule.  Of the two waves of a SIMD the one with the lower id is served first after a barrier (measured:
 // waves 0-3 wait ~18 000 ticks at the barrier behind their own GEMM, waves 4-7 wait as long in front of theirs).  A gather
-// (32 distinct rows per instruction) or a streaming prefetch occupies the CU's address path for thousands of cycles, and the
-// weight copy of the next phase — which every wave must get issued before its first MFMA — queues behind whatever was
-// issued last.  So:
+// (32 distinct rows per instruction) or a streaming prefetch occupies the CU's address path for thousands of cycles, and
+// whatever a wave issues next queues behind it.  So:
 //   * waves 0-3 issue the gathers for the next phase right after their GEMM, BEFORE the barrier: the address path is idle
 //     then (waves 4-7 are in their GEMM) and the loads are long done when the barrier opens;
-//   * waves 4-7 reach the barrier last; gathers issued there would sit in the queue in front of everybody's weight copy.
-//     They issue them AFTER the barrier and after their own weight copy, at the start of the phase, where they have a whole
-//     GEMM of waiting in front of them anyway.
+//   * waves 4-7 reach the barrier last; gathers issued there would sit in the queue in front of the next phase.  They issue
+//     them AFTER the barrier, at the start of the phase, where they have a whole GEMM of waiting in front of them anyway;
+//   * the weight copy of the phase after next is issued by every wave 64 MFMAs into its GEMM (CV_INGEMM), behind the gathers.
 template <int V>
 __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
