@@ -481,6 +481,9 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     auto hptr = [&](int l) { return h->hbuf.as<float>() + (h->cfg.keep_stages ? (size_t)l * nh : (size_t)(l & 1) * nh); };
 
     NodeArgs no{};
+#ifdef GAMD_PROFILING
+    { static const bool node_time = getenv("GAMD_NODE_TIME") != nullptr; if (node_time) no.tdbg = h->tdbg.as<long long>(); }
+#endif
     no.counters = h->cur_counters;
     no.devflags = h->devflags.as<int>();
     no.sticky = h->sticky_dev;

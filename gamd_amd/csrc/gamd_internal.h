@@ -187,6 +187,7 @@ struct NodeArgs {
                                // conv kernel's row-layout gather is one 16-byte load per edge (conv_edge_f16x3.hip)
     float* forces_norm;        // [n][3] normalised network output, ORIGINAL atom order (mode 2)
     float* forces;             // [n][3] denormalised fp32 (device MD loop), original order, or null
+    long long* tdbg;           // profiling builds only (GAMD_NODE_TIME=1): [workgroup][wave][16] s_memtime marks of the mode-1 launches
 };
 int launch_node(const NodeArgs& a, hipStream_t st);
 // generic widths (wide.hip): h / hn / partial rows and node_emb, enc_w, enc_b, ln_*, bphi are H = 128 ht wide;
