@@ -633,6 +633,9 @@ const char* gamd_last_error(void) { return g_err; }
 int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     if (!cfg || !out) return fail(-22, "null argument");
     if (cfg->n_atoms <= 0) return fail(-22, "n_atoms must be positive");
+    // node-table rows are addressed with 32-bit byte offsets (row * 512 B, scalar base + offset loads) in the conv-layer edge
+    // kernels: 2^23 - 1 rows including the zero row (a 288 GB device holds ~5e6 atoms of this model)
+    if (cfg->n_atoms >= (1 << 23) - 1) return fail(-22, "n_atoms = %d: at most %d atoms per box", cfg->n_atoms, (1 << 23) - 2);
     if (cfg->n_layers <= 0 || cfg->n_layers > 16) return fail(-22, "n_layers out of range");
     if (!(cfg->cutoff > 0.f)) return fail(-22, "cutoff must be positive");
     if (cfg->edge_dtype != GAMD_EDGE_F32 && cfg->edge_dtype != GAMD_EDGE_BF16 && cfg->edge_dtype != GAMD_EDGE_F16X3)
