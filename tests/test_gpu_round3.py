@@ -94,3 +94,12 @@ def test_water_with_bonds_both_kernels_and_bf16_padding(dtype, tol):
         assert np.array_equal(out, again)
         err = rel_err(out, g["out_norm"])
         assert 1e-6 < err < tol, err
+
+
+def test_atom_count_beyond_the_32_bit_row_offsets_is_refused():
+    """The conv-layer edge kernels address node-table rows with 32-bit byte offsets (row * 512 B): gamd_create refuses a box
+    that would overflow them instead of gathering from wrapped addresses."""
+    from gamd_amd._lib import GamdError
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    with pytest.raises(GamdError, match="at most"):
+        _engine(sd, (1 << 23) - 1, 1.0e4, 10.2)
