@@ -44,14 +44,15 @@ class _ModelLevel:
     """`self.pnet_model` of the reference wrappers: the nn.Module called as ``model([pos], [edge_idx])``
     (SimpleMDNetNew.forward, nn_module.py:672-685) or ``model([pos], feat, [edge_idx])``
     (WaterMDNetNew.forward, :545-558) or ``model([pos], feat, [box_size], cutoff)`` (WaterMDDynamicBoxNet.forward,
-    :391-407, which searches neighbours itself).  Single-graph (inference) form only; returns the NORMALISED output."""
+    :391-407, which searches neighbours itself).  Returns the NORMALISED output; lists with several graphs are evaluated
+    graph by graph (see _batched)."""
 
     def __init__(self, owner):
         self._owner = owner
 
     def __call__(self, pos_lst, *rest):
         if len(pos_lst) != 1:
-            raise NotImplementedError("batched graphs (len(pos_lst) > 1) are the training path (dgl.batch)")
+            return self._batched(pos_lst, *rest)
         if len(rest) == 1:
             feat, edge_lst = None, rest[0]
         elif len(rest) == 2:
@@ -66,6 +67,37 @@ class _ModelLevel:
             raise TypeError("expected ([pos], [edge_idx]), ([pos], feat, [edge_idx]) or ([pos], feat, [box], cutoff)")
         species = None if feat is None else _node_feature(feat)
         return self._owner._get_engine().forward_edges(pos_lst[0], edge_lst[0], species=species)
+
+    def _batched(self, pos_lst, *rest):
+        """``len(pos_lst) > 1``: the reference builds one graph per entry and runs the network on their disjoint union
+        (build_graph_batches + dgl.batch, nn_module.py:655-661, :520-527; edge indices are local to each graph, `feat`
+        is the concatenation of the per-graph node features) and returns the outputs concatenated in order.  Without
+        batch statistics (LayerNorm only in every shipped configuration) that is the per-graph result, graph by
+        graph; every graph must have the atom count the engine was built for."""
+        if len(pos_lst) == 0:
+            raise ValueError("empty pos_lst")
+        eng = self._owner._get_engine()
+        sizes = [int(np.asarray(p.shape)[0]) if not isinstance(p, torch.Tensor) else int(p.shape[0]) for p in pos_lst]
+        if any(n != eng.n for n in sizes):
+            raise ValueError(f"every graph of a batch must have {eng.n} atoms (the engine's size), got {sizes}")
+        feat = rest[0] if len(rest) >= 2 else None
+        feats = [None] * len(pos_lst)
+        if feat is not None:
+            f = _node_feature(feat)
+            if f.shape[0] != sum(sizes):
+                raise ValueError(f"feat has {f.shape[0]} rows for {sum(sizes)} atoms")
+            feats = list(torch.split(f, sizes))
+        outs = []
+        for i, pos in enumerate(pos_lst):
+            if len(rest) == 1:
+                outs.append(self([pos], [rest[0][i]]))
+            elif len(rest) == 2:
+                outs.append(self([pos], feats[i], [rest[1][i]]))
+            elif len(rest) == 3:
+                outs.append(self([pos], feats[i], [rest[1][i]], rest[2]))
+            else:
+                raise TypeError("expected (pos_lst, edge_lst), (pos_lst, feat, edge_lst) or (pos_lst, feat, box_lst, cutoff)")
+        return torch.cat(outs, dim=0)
 
     forward = __call__
 

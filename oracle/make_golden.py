@@ -151,12 +151,54 @@ def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, l
     print(f"{name}: N={n} E={edge_idx.shape[1]}")
 
 
+def run_batched_lj(nn_module, name, cfg, seed, pos_list, box, cutoff, lmean, lstd):
+    """The model-level call with SEVERAL graphs, SimpleMDNetNew.forward(pos_lst, edge_idx_lst) with len(pos_lst) > 1:
+    build_graph_batches + dgl.batch (nn_module.py:655-661, :676-679), output [sum N, 3] in list order.  Edge indices are
+    local to each graph.  Pins gamd_amd.compat._ModelLevel._batched."""
+    torch.manual_seed(1234)
+    sd = make_state_dict(cfg, seed, lmean, lstd)
+    m = nn_module.SimpleMDNetNew(encoding_size=cfg.encoding_size, out_feats=3, box_size=box, hidden_dim=cfg.hidden_dim,
+                                 conv_layer=cfg.conv_layer, edge_embedding_dim=cfg.edge_embedding_dim, drop_edge=False,
+                                 use_layer_norm=True)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    pos_w, edges = [], []
+    for pos in pos_list:
+        pos64 = np.asarray(pos, dtype=np.float64)
+        posw = torch.from_numpy(np.mod(pos64, np.array(box))).float()
+        e = jaxmd_edge_set(posw, box, cutoff)
+        assert margin_to_cutoff(posw, box, cutoff) > 2e-5
+        pos_w.append(posw)
+        edges.append(e)
+    with torch.no_grad():
+        out = m(pos_w, edges).numpy()
+        singles = [m([p], [e]).numpy() for p, e in zip(pos_w, edges)]
+    # dgl.batch of independent graphs == the graphs one by one (no batch statistics in the shipped configuration)
+    assert np.abs(out - np.concatenate(singles)).max() <= 2e-6 * np.abs(out).max()
+    rec = dict(box=np.float64(box), cutoff=np.float64(cutoff), seed=np.int64(seed), length_mean=np.float64(lmean),
+               length_std=np.float64(lstd), out_norm=out, n_graphs=np.int64(len(pos_list)),
+               cfg=np.array([cfg.kind, str(cfg.encoding_size), str(cfg.hidden_dim), str(cfg.edge_embedding_dim),
+                             str(cfg.conv_layer), str(int(cfg.use_bond))]))
+    for i, (p, e) in enumerate(zip(pos_w, edges)):
+        rec[f"pos{i}"] = p.numpy()
+        rec[f"edge_idx{i}"] = e.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(f"{name}: graphs={len(pos_list)} N={[p.shape[0] for p in pos_w]} E={[e.shape[1] for e in edges]} |out|max={np.abs(out).max():.4g}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     nn_module, md_module = ref_stubs.import_reference(REF)
     lj_pos = np.load(os.path.join(REF, "code/LJ/init_pos.npy"))          # [258,3] f32, in [0, 27.22]
     w_pos = np.load(os.path.join(REF, "code/water/init_pos.npy"))        # [774,3] f64, centred
     full = dict(encoding_size=128, hidden_dim=128, edge_embedding_dim=128, conv_layer=4)
+
+    # model-level call with two graphs (`--only-batch` writes just this one)
+    rngb = np.random.default_rng(11)
+    run_batched_lj(nn_module, "lj258_batch2_seed0", ModelConfig(kind="lj", **full), 0,
+                   [lj_pos, lj_pos.astype(np.float64) + rngb.normal(0, 0.3, lj_pos.shape)], 27.27, 7.5, 5.3, 1.6)
+    if "--only-batch" in sys.argv:
+        return
 
     # The other reading of `fluid_graph.add_self_loop()` (result discarded, nn_module.py:650-652, :364): an IN-PLACE
     # add_self_loop as in DGL < 0.5.  The reference module is executed with a stub graph that mutates itself; these

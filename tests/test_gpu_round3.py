@@ -103,3 +103,37 @@ def test_atom_count_beyond_the_32_bit_row_offsets_is_refused():
     sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
     with pytest.raises(GamdError, match="at most"):
         _engine(sd, (1 << 23) - 1, 1.0e4, 10.2)
+
+
+def test_model_level_call_with_several_graphs():
+    """pnet_model(pos_lst, edge_idx_lst) with len(pos_lst) > 1 (the reference batches the graphs with dgl.batch,
+    nn_module.py:655-661): against the reference's own output for two graphs, and for the water wrapper (feat = the
+    concatenated node features) against the graphs evaluated one by one."""
+    import os
+    from helpers import GOLDEN
+    from gamd_amd.compat import ParticleNetLightningLJ, ParticleNetLightningWater
+    g = dict(np.load(os.path.join(GOLDEN, "lj258_batch2_seed0.npz"), allow_pickle=False))
+    kind, H, D, Eh, L, bond = [str(x) for x in g["cfg"]][:6]
+    cfg = ModelConfig(kind=kind, encoding_size=int(H), hidden_dim=int(D), edge_embedding_dim=int(Eh), conv_layer=int(L))
+    sd = make_state_dict(cfg, int(g["seed"]), float(g["length_mean"]), float(g["length_std"]))
+    m = ParticleNetLightningLJ(state_dict=sd, num_atoms=258, box_size=float(g["box"]), cutoff=float(g["cutoff"]))
+    pos_lst = [torch.from_numpy(g[f"pos{i}"]).cuda() for i in range(2)]
+    edge_lst = [torch.from_numpy(g[f"edge_idx{i}"]).long().cuda() for i in range(2)]
+    out = m.pnet_model(pos_lst, edge_lst)
+    assert tuple(out.shape) == (516, 3)
+    assert rel_err(out.cpu().numpy(), g["out_norm"]) < TOL
+    with pytest.raises(ValueError, match="atoms"):
+        m.pnet_model([pos_lst[0], pos_lst[1][:100]], edge_lst)
+    # water: feat rows are split by graph
+    gw, cfgw, sdw = load_golden("tip3p774_seed3")
+    box = float(gw["box"])
+    posw = torch.from_numpy(np.mod(gw["pos"], box)).float().cuda()
+    e = torch.from_numpy(gw["edge_idx"]).long().cuda()
+    feat = torch.from_numpy(gw["node_feat"]).cuda()
+    mw = ParticleNetLightningWater(state_dict=sdw)
+    one = mw.pnet_model([posw], feat, [e])
+    two = mw.pnet_model([posw, posw], torch.cat([feat, feat]), [e, e])
+    assert tuple(two.shape) == (2 * posw.shape[0], 3)
+    assert np.array_equal(two[: posw.shape[0]].cpu().numpy(), one.cpu().numpy())
+    assert np.array_equal(two[posw.shape[0]:].cpu().numpy(), one.cpu().numpy())
+    assert rel_err(one.cpu().numpy(), gw["out_norm"]) < TOL

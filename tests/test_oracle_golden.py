@@ -118,3 +118,18 @@ def test_self_loop_mode_append_dynamic_box():
                                   self_loop_mode="append_zero_feature_loops").numpy()
     assert rel_err(out, g["out_norm"]) < 5e-6
     assert rel_err(g["out_norm"], g0["out_norm"]) > 1e-3
+
+
+def test_batched_model_call_golden_is_the_graphs_one_by_one():
+    """The reference's model-level call with two graphs (build_graph_batches + dgl.batch, nn_module.py:655-661,676-679):
+    the golden output equals the oracle applied to each graph separately, concatenated in list order."""
+    g = dict(np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "lj258_batch2_seed0.npz"), allow_pickle=False))
+    from gamd_amd.weights import ModelConfig, make_state_dict
+    kind, H, D, Eh, L, bond = [str(x) for x in g["cfg"]][:6]
+    cfg = ModelConfig(kind=kind, encoding_size=int(H), hidden_dim=int(D), edge_embedding_dim=int(Eh), conv_layer=int(L))
+    sd = make_state_dict(cfg, int(g["seed"]), float(g["length_mean"]), float(g["length_std"]))
+    outs = []
+    for i in range(int(g["n_graphs"])):
+        outs.append(orc.forward(sd, torch.from_numpy(g[f"pos{i}"]), torch.from_numpy(g[f"edge_idx{i}"]).long(), float(g["box"])).numpy())
+    assert np.concatenate(outs).shape == g["out_norm"].shape
+    assert rel_err(np.concatenate(outs), g["out_norm"]) < 5e-6
