@@ -380,7 +380,34 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
 
     f32x16 X[HT][4];
     f32x16 mine[HT];
-    WQ wq;
+    // Weight quarters travel one block-GEMM ahead: step s of the kernel's GEMM sequence (phi_edge kb | phi ob | S kb | D kb |
+    // P kb, or the decoder's kb) runs from buffer s & 1 while the quarter of step s + 1 is fetched from L2 into the other
+    // one — also across the exchanges and the LayerNorm between the stages.  (Fetched right in front of its GEMM, as in
+    // rounds 1-2, every one of the 5 HT block GEMMs sat out an L2 round trip: 39 us per launch on the 774-atom system.)
+    WQ wqa, wqb;
+    constexpr size_t BLK = GAMD_WFRAG_FLOATS;
+    auto wptr = [&](int st) -> const float* {               // weight block of step st (st >= 2 HT: pre(l) or decoder)
+        if (st < HT) return a.post.wpep + (size_t)st * BLK;
+        if (st < 2 * HT) return a.post.wphip + (size_t)(st - HT) * BLK;
+        const int i = st - 2 * HT;
+        if (a.mode == 2) return i < HT ? a.dec_w1p + (size_t)i * BLK : nullptr;
+        if (i < HT) return a.pre.wsp + (size_t)i * BLK;
+        if (i < 2 * HT) return a.pre.wdp + (size_t)(i - HT) * BLK;
+        return i < 3 * HT ? a.pre.wpdp + (size_t)(i - 2 * HT) * BLK : nullptr;
+    };
+    // step st: fetch step st + 1's quarter, then the 64 MFMAs of this one
+    auto step = [&](int st, const f32x16 (&Xb)[4], f32x16& acc) {
+        WQ& cur = (st & 1) ? wqb : wqa;
+        WQ& nxt = (st & 1) ? wqa : wqb;
+        const float* np_ = wptr(st + 1);
+        asm volatile("" ::: "memory");
+        if (np_) wq_load(np_, quarter, lane, nxt);
+        asm volatile("" ::: "memory");
+        wq_gemm(cur, Xb, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (a.mode == 0) wq_load(wptr(2 * HT), quarter, lane, wqa);      // (2 HT is even: buffer a)
+    else wq_load(wptr(0), quarter, lane, wqa);
 
     if (a.mode == 0) {
 #pragma unroll
@@ -428,10 +455,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         }
         exchange_blocks<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = agg
 #pragma unroll
-        for (int kb = 0; kb < HT; ++kb) {                                     // phi_edge: H -> 128
-            wq_load(a.post.wpep + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
-            wq_gemm(wq, X[kb], acc);
-        }
+        for (int kb = 0; kb < HT; ++kb) step(kb, X[kb], acc);                 // phi_edge: H -> 128
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = gamd_silu_hw(acc[r]);
         f32x16 one[1] = {acc};
@@ -440,8 +464,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
 #pragma unroll
         for (int ob = 0; ob < HT; ++ob) {                                     // phi: 128 -> H, residual
             mine[ob] = load_slice(a.post.bphi + 128 * ob, quarter, half);
-            wq_load(a.post.wphip + (size_t)ob * GAMD_WFRAG_FLOATS, quarter, lane, wq);
-            wq_gemm(wq, X1[0], mine[ob]);
+            step(HT + ob, X1[0], mine[ob]);
             mine[ob] += h_res[ob];
             if (valid) store_slice(a.h_out + rowH + 128 * ob, quarter, half, mine[ob]);
         }
@@ -478,35 +501,23 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         exchange_blocks<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = hn
         f32x16 acc = load_slice(a.pre.bS, quarter, half);
 #pragma unroll
-        for (int kb = 0; kb < HT; ++kb) {
-            wq_load(a.pre.wsp + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
-            wq_gemm(wq, X[kb], acc);
-        }
+        for (int kb = 0; kb < HT; ++kb) step(2 * HT + kb, X[kb], acc);
         if (valid) store_slice(a.S_out + rowD, quarter, half, acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < HT; ++kb) {
-            wq_load(a.pre.wdp + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
-            wq_gemm(wq, X[kb], acc);
-        }
+        for (int kb = 0; kb < HT; ++kb) step(3 * HT + kb, X[kb], acc);
         if (valid) store_slice(a.D_out + rowD, quarter, half, acc);
         acc = load_slice(a.pre.bP, quarter, half);
 #pragma unroll
-        for (int kb = 0; kb < HT; ++kb) {
-            wq_load(a.pre.wpdp + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
-            wq_gemm(wq, X[kb], acc);
-        }
+        for (int kb = 0; kb < HT; ++kb) step(4 * HT + kb, X[kb], acc);
         if (valid) store_slice(a.P_out + rowD, quarter, half, acc);
     } else {
         // ---- decoder: Lin(H,128) GELU Lin(128,3); denormalise ------------------------------------
         exchange_blocks<HT, XLDW>(xbuf, quarter, slot, half, mine, X);          // X = h'
         f32x16 acc = load_slice(a.dec_b1, quarter, half);
 #pragma unroll
-        for (int kb = 0; kb < HT; ++kb) {
-            wq_load(a.dec_w1p + (size_t)kb * GAMD_WFRAG_FLOATS, quarter, lane, wq);
-            wq_gemm(wq, X[kb], acc);
-        }
+        for (int kb = 0; kb < HT; ++kb) step(2 * HT + kb, X[kb], acc);
         float o[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
