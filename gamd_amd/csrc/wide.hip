@@ -212,15 +212,18 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
 
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; }
     if (tid < H) vb4[tid] = a.b4[tid];
-    gamd_stage_weight<8>(a.w1p, lds, wave, lane16);
+    gamd_stage_weight_raw_contig<8>(a.w1p, lds, wave, lane16);
     wide_barrier();
 
     unsigned g = 0;                    // running phase counter: block g % NP sits in slot g & 1
     int blk = 0;
-    // start the DMA of the next block into the other slot, hand back this phase's slot
+    // start the DMA of the next block into the other slot, hand back this phase's slot.  The copy is issued from inline
+    // assembly: a compiler-tracked global_load_lds turns the wait of this phase's first weight read into vmcnt(0), i.e. every
+    // phase would sit out the copy it has just issued for the NEXT one (conv_edge.hip); its landing is guaranteed by the
+    // vmcnt(0) of wide_barrier at the end of the phase.
     auto begin_phase = [&]() -> const f32x4* {
         const int nb = (blk + 1 == NP) ? 0 : blk + 1;
-        gamd_stage_weight<8>(a.w1p + (size_t)nb * GAMD_WFRAG_FLOATS, lds + ((g + 1) & 1u) * GAMD_WFRAG_FLOATS, wave, lane16);
+        gamd_stage_weight_raw_contig<8>(a.w1p + (size_t)nb * GAMD_WFRAG_FLOATS, lds + ((g + 1) & 1u) * GAMD_WFRAG_FLOATS, wave, lane16);
         return (const f32x4*)(lds + (g & 1u) * GAMD_WFRAG_FLOATS);
     };
     auto end_phase = [&]() { wide_barrier(); ++g; blk = (blk + 1 == NP) ? 0 : blk + 1; };
