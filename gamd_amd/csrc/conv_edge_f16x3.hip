@@ -65,12 +65,20 @@ __device__ __forceinline__ void gemm128_f16x3_post(const f16x8* W, int lane, con
 template <int NW>
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16, int k) {
     // (inline assembly: a compiler-tracked global_load_lds turns the next wait of any kind into vmcnt(0) lgkmcnt(0), see
-    // gamd_stage_weight_raw in gamd_common.h; the landing is guaranteed by the counted vmcnt of phase_barrier)
-    const int chunk = k * NW + wave;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 ::"v"(lane16), "s"(reinterpret_cast<const char*>(gw) + chunk * 1024), "s"(lds0 + chunk * 1024u)
-                 : "memory");
+    // gamd_stage_weight_raw in gamd_common.h; the landing is guaranteed by the counted vmcnt of phase_barrier.)  A wave's
+    // 64 / NW KiB are contiguous and addressed by the instruction's immediate offset (which advances the global and the LDS
+    // side alike): base pair + M0 are rebuilt per call from one opaque scalar instead of living in 16 x 3 loop-invariant,
+    // spilled SGPRs per matrix.
+    int woff = wave * (64 / NW) * 1024 + (k >> 2) * 4096;
+    asm volatile("" : "+s"(woff));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf + (unsigned)woff;
+    const char* g0 = reinterpret_cast<const char*>(gw) + woff;
+    switch (k & 3) {
+        case 0: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory"); break;
+        case 1: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory"); break;
+        case 2: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory"); break;
+        default: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory"); break;
+    }
 }
 
 // piece i (0..15) of load_row_chain / load_e_tile, so that a gather can be spread over the K steps of a GEMM
@@ -137,7 +145,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
     };
 
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
-    gamd_stage_weight_raw<NW>(a.w1p, buf0, wave, lane16);
+    gamd_stage_weight_raw_contig<NW>(a.w1p, buf0, wave, lane16);
 
     // 64-register sets: two operand sets PA / PB alternate as GEMM input / output (the post-op of a phase writes its
     // activation directly as the split operands of the next phase); RA = S[src], RC = D[dst] -> accumulators of
@@ -184,11 +192,11 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
                 else { load_row_piece(srow, half, RA, i - 16); load_row_piece(drow, half, RC, i - 16); }
             });
         } else {
-            gamd_stage_weight_raw<NW>(a.w2p, buf1, wave, lane16);
+            gamd_stage_weight_raw_contig<NW>(a.w2p, buf1, wave, lane16);
         }
         if (active) phase_barrier<32>(); else phase_barrier<0>();     // S/D gathers (issued after the DMA) stay in flight
         // ===== phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]) =====
-        if (!active) gamd_stage_weight_raw<NW>(a.w3p, buf0, wave, lane16);
+        if (!active) gamd_stage_weight_raw_contig<NW>(a.w3p, buf0, wave, lane16);
         if (active) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) RC[t] += RA[t];
@@ -207,7 +215,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         }
         if (active) phase_barrier<16>(); else phase_barrier<0>();     // hn gathers stay in flight
         // ===== phase 3: T4 = SiLU(W3 T3 + b3) =====
-        if (!active) gamd_stage_weight_raw<NW>(a.w4p, buf1, wave, lane16);
+        if (!active) gamd_stage_weight_raw_contig<NW>(a.w4p, buf1, wave, lane16);
         if (active_n) {
             const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
             if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
@@ -220,7 +228,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         }
         phase_barrier<0>();
         // ===== phase 4: e_emb = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
-        if (!active) gamd_stage_weight_raw<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
+        if (!active) gamd_stage_weight_raw_contig<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
         if (active) {
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {

@@ -273,7 +273,7 @@ __device__ __forceinline__ void gamd_stage_weight_raw(const float* __restrict__ 
 // alive, which hipcc spills to VGPR lanes and restores with two v_readlane per copy (~160 per tile in k_conv_edge).
 template <int NW = 8>
 __device__ __forceinline__ void gamd_stage_weight_raw_contig(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16) {
-    static_assert(64 / NW == 8 || 64 / NW == 4, "4 or 8 KiB per wave");
+    static_assert((64 / NW) % 4 == 0, "whole groups of four KiB-sized copies per wave");
     int woff = wave * (64 / NW) * 1024;
     asm volatile("" : "+s"(woff));                      // rebuilt per call (2 scalar adds), never kept across the tile loop
     const char* g0 = reinterpret_cast<const char*>(gw) + woff;
