@@ -78,6 +78,11 @@ def parse_args():
 # N > 1 without torchrun: this process only spawns and relays; it never initialises a GPU
 # ---------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args) -> int:
+    """Start one child per rank, relay rank 0's result line, and never hang: every child is polled; as soon as one exits
+    non-zero (or the whole run exceeds GAMD_BENCH_TIMEOUT_S, default 1800) the others — which would otherwise sit in a
+    collective until the process-group timeout — are terminated (exact PIDs of our own children; fresh processes, none
+    of them is ever re-exec'd) and this process exits non-zero."""
+    import tempfile
     import torch                                   # device_count() does not initialise the GPU on this stack
     share = os.environ.get("GAMD_BENCH_SHARE_GPU", "0") == "1"
     ndev = torch.cuda.device_count()
@@ -89,30 +94,28 @@ def spawn_ranks(args) -> int:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    import signal
+    from gamd_amd.ensemble import supervise_ranks
+    # a SIGTERM to this launcher (a driver's timeout) must not orphan the ranks: turn it into an exception so that
+    # supervise_ranks' cleanup runs
+    signal.signal(signal.SIGTERM, lambda *_: sys.exit(143))
+    procs, out0 = [], tempfile.TemporaryFile(mode="w+")      # a file, not a pipe: rank 0 can never block on a full pipe
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = ""
-    rc = 0
-    try:
-        out0, _ = procs[0].communicate()
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
-    finally:
-        for p in procs:                            # exact PIDs of our own children only
-            if p.poll() is None:
-                p.kill()
-    if rc != 0:
-        print(f"bench.py: a rank exited with status {rc}", file=sys.stderr)
-        return rc or 1
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    failed = supervise_ranks(procs, timeout_s=float(os.environ.get("GAMD_BENCH_TIMEOUT_S", "1800")))
+    if failed is not None:
+        r, c = failed
+        print(f"bench.py: {'the run timed out' if r < 0 else f'rank {r} exited with status {c}'}; "
+              f"the remaining ranks were terminated", file=sys.stderr)
+        return c if c > 0 else 1
     # rank 0's stdout carries the result line; anything else a library printed there (gloo announces its peers on
     # stdout) goes to stderr so that this process still prints exactly ONE line
-    lines = [l for l in out0.splitlines() if l.strip()]
+    out0.seek(0)
+    lines = [l for l in out0.read().splitlines() if l.strip()]
     result = [l for l in lines if l.lstrip().startswith('{"metric"')]
     for l in lines:
         if l not in result:
@@ -343,17 +346,24 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     if not share and torch.cuda.device_count() <= local:
         raise SystemExit(f"bench.py: rank with LOCAL_RANK={local} has no device ({torch.cuda.device_count()} visible)")
-    ctx = ens.init_ensemble(backend, device_index=0 if share else None)
+    ctx = ens.init_ensemble(backend, device_index=0 if share else None,
+                            timeout_s=float(os.environ.get("GAMD_BENCH_PG_TIMEOUT_S", "120")))
     dev = 0 if share else (ctx.local_rank if ctx.distributed else 0)
     torch.cuda.set_device(dev)
     ddev = f"cuda:{dev}" if (ctx.distributed and backend == "nccl") else "cpu"
+    host_threads = ens.pin_host_threads(ctx) if ctx.distributed else torch.get_num_threads()
+    # fault injection for tests/test_gpu_bench_contract.py: this rank dies after the rendezvous, before the first barrier
+    if os.environ.get("GAMD_BENCH_FAIL_RANK", "") == str(ctx.rank) and ctx.distributed:
+        print(f"bench.py: rank {ctx.rank} failing on purpose (GAMD_BENCH_FAIL_RANK)", file=sys.stderr)
+        os._exit(3)
 
     skin = args.skin if args.workload != "dft" else 0.0          # md_module.get_neighbor searches from scratch every call
     w = build_workload(args.workload, ctx, dev, skin, args.edge_dtype)
     dt, dt_max, conv_ms, conv_n = timed_run(w, args.steps, args.warmup, ctx, dev, ddev)
     n_edges = w.eng.counts()[0]
     summary = ens.gather_summary({"seconds": dt, "edges": float(n_edges), "fsum": float(w.f.abs().sum().item()),
-                                  "box_seed": float(ens.box_seed(1234, ctx)),
+                                  "box_seed": float(ens.box_seed(1234, ctx)), "host_threads": float(host_threads),
+                                  **ens.device_identity(dev),
                                   "finite": float(torch.isfinite(w.x).all().item() and torch.isfinite(w.f).all().item())},
                                  ctx, device=ddev)
     if ctx.rank != 0:
@@ -378,8 +388,11 @@ def main():
                    "launch": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else
                              ("self-spawned ranks" if ctx.world > 1 else "single process")},
         "ensemble": {"boxes": ctx.world, "collective_on_step_path": False,
+                     "distinct_devices": len({ens.pci_string(s) for s in summary}),
                      "per_rank": [{"rank": r, "box_seed": int(s["box_seed"]), "seconds": s["seconds"], "edges": int(s["edges"]),
-                                   "force_abs_sum": s["fsum"]} for r, s in enumerate(summary)]},
+                                   "force_abs_sum": s["fsum"], "device": int(s["device"]), "pci_bus_id": ens.pci_string(s),
+                                   "group_world_size": int(s["group_world_size"]), "host_threads": int(s["host_threads"])}
+                                  for r, s in enumerate(summary)]},
         "roofline": roofline_block(w, n_edges, conv_ms, conv_n),
     }
     rl = line["roofline"]

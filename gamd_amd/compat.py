@@ -76,6 +76,13 @@ class _ModelLevel:
         graph; every graph must have the atom count the engine was built for."""
         if len(pos_lst) == 0:
             raise ValueError("empty pos_lst")
+        if len(rest) not in (1, 2, 3):
+            raise TypeError("expected (pos_lst, edge_lst), (pos_lst, feat, edge_lst) or (pos_lst, feat, box_lst, cutoff)")
+        # the per-graph list must be as long as pos_lst (a longer one would be truncated silently, a shorter one would
+        # surface as a bare IndexError)
+        name, lst = {1: ("edge_lst", rest[0]), 2: ("edge_lst", rest[-1]), 3: ("box_size_lst", rest[1])}[len(rest)]
+        if len(lst) != len(pos_lst):
+            raise ValueError(f"{name} has {len(lst)} entries for {len(pos_lst)} graphs in pos_lst")
         eng = self._owner._get_engine()
         sizes = [int(np.asarray(p.shape)[0]) if not isinstance(p, torch.Tensor) else int(p.shape[0]) for p in pos_lst]
         if any(n != eng.n for n in sizes):
@@ -123,9 +130,10 @@ class _ForceFieldBase:
             self.load_training_stats(scaler_ckpt)
 
     # -- construction / loading (test_langevin.py:74-77) --------------------------------------
-    def load_from_checkpoint(self, path: str, args=None, **kw):
-        """Instance-style call used by the drivers: ParticleNetLightning(args).load_from_checkpoint(PATH, args=args)."""
-        self._sd = load_checkpoint(path)
+    def load_from_checkpoint(self, path: str, args=None, allow_pickle: bool = False, **kw):
+        """Instance-style call used by the drivers: ParticleNetLightning(args).load_from_checkpoint(PATH, args=args).
+        ``allow_pickle``: see weights.load_checkpoint (restricted unpickler unless opted out)."""
+        self._sd = load_checkpoint(path, allow_pickle=allow_pickle)
         self._engine = None
         return self
 

@@ -74,10 +74,10 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ gw, float*
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf + (unsigned)woff;
     const char* g0 = reinterpret_cast<const char*>(gw) + woff;
     switch (k & 3) {
-        case 0: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory"); break;
-        case 1: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory"); break;
-        case 2: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory"); break;
-        default: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory"); break;
+        case 0: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
+        case 1: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
+        case 2: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
+        default: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
     }
 }
 
@@ -162,6 +162,9 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
         if (active) load_e_tile(a.e_frag, tile, lane, PA);
     }
+    // the W1 copy above is issued from inline assembly: hipcc does not count it, so the wait for it is explicit (without it a
+    // wave could read chunks of buf0 that another wave's copy has not filled yet on a cold first tile)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned pend_ends = 0;           // piece stores of the tile just finished (issued after its last barrier)
     int pend_p = 0;
@@ -237,7 +240,10 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
                 for (int r = 0; r < 16; ++r) RC[tp][r] = b;
             }
             // message + segment sum (nn_module.py:142 u_mul_e -> sum), branch-free: RC[tp][r] becomes the running sum
-            // of the messages of the current piece (reset after every edge that closes a destination segment)
+            // of the messages of the current piece (reset after every edge that closes a destination segment).  This kernel
+            // is EXEMPT from gamd_msg_acc (gamd_common.h): it keeps the reference's multiply-then-add (two roundings) and a
+            // per-element nvalid mask instead of the zero-row padding; the f32 / bf16 / wide / small kernels fuse the two.
+            // Both forms are within the 1e-5 goldens; only the fp32 kernels are required to be bit-identical to one another.
             const unsigned keep_bits = ~(mask << 1);          // bit r set: edge r continues edge r-1's piece
             gemm128_f16x3_post<true>((const f16x8*)buf1, lane, PB, RC, [&](int tp, int r0) {
 #pragma unroll

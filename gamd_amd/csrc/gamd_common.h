@@ -263,7 +263,7 @@ __device__ __forceinline__ void gamd_stage_weight_raw(const float* __restrict__ 
         const int chunk = k * NW + wave;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      ::"v"(lane16), "s"(reinterpret_cast<const char*>(gw) + chunk * 1024), "s"(lds0 + chunk * 1024u)
-                     : "memory");
+                     : "memory", "m0");
     }
 }
 
@@ -286,7 +286,7 @@ __device__ __forceinline__ void gamd_stage_weight_raw_contig(const float* __rest
                      "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
                      "global_load_lds_dwordx4 %0, %1 offset:3072"
                      ::"v"(lane16), "s"(g0 + h * 4096), "s"(l0 + h * 4096u)
-                     : "memory");
+                     : "memory", "m0");
 }
 
 // Latency-oriented split of a 32-row tile over the 4 waves of a 256-thread workgroup (node.hip, conv_edge_small.hip,

@@ -125,13 +125,13 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
     const size_t row = (size_t)atom * GAMD_H;
 
 #ifdef GAMD_PROFILING
-    long long tm[16];
-    int tmi = 0;
-#define NMARK() do { if (a.tdbg && tmi < 16) tm[tmi++] = (long long)__builtin_readcyclecounter(); } while (0)
+    long long tm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // compile-time mark indices: tm[] stays in registers (a run-time index sends it to scratch or movrel and skews the marks)
+#define NMARK(I) do { if (a.tdbg) tm[I] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
-#define NMARK() do { } while (0)
+#define NMARK(I) do { } while (0)
 #endif
-    NMARK();                                                      // 0: start
+    NMARK(0);                                                      // 0: start
     f32x4 XB[8];          // full activation rows (chain16 layout)
     f32x4 mine[2];        // this wave's 32 output features
     WHalf wn;             // the weight half that the next 32 MFMAs need (fetched one half ahead)
@@ -173,26 +173,26 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
             for (int k = 0; k < 8; ++k)
                 if (k0 + k < np) { mine[0] += pc[k][0]; mine[1] += pc[k][1]; }
         }
-        NMARK();                                                  // 1: pieces summed
+        NMARK(1);                                                  // 1: pieces summed
         asm volatile("" ::: "memory");                            // the weight fetch stays behind the piece loads (registers)
         load_whalf(a.post.wpep, w, lane, 0, wn);                  // in flight during the exchange
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = agg
-        NMARK();                                                  // 2: exchange 1
+        NMARK(2);                                                  // 2: exchange 1
         mine[0] = p_in[0]; mine[1] = p_in[1];
         gemm16<true>(a.post.wpep, a.post.wphip, wn, XB, mine, w, lane);
-        NMARK();                                                  // 3: GEMM phi_edge
+        NMARK(3);                                                  // 3: GEMM phi_edge
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[o][r] = gamd_silu_hw(mine[o][r]);
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = SiLU(P + phi_edge(agg))
-        NMARK();                                                  // 4: SiLU + exchange 2
+        NMARK(4);                                                  // 4: SiLU + exchange 2
         load16(a.post.bphi, w, g, mine);
         load16(a.h_in + row, w, g, h_res);                        // residual: lands during the GEMM
         gemm16<true>(a.post.wphip, a.mode != 2 ? a.pre.wsp : a.dec_w1p, wn, XB, mine, w, lane);
         mine[0] += h_res[0]; mine[1] += h_res[1];                 // residual
         if (valid) store16(a.h_out + row, w, g, mine);
-        NMARK();                                                  // 5: GEMM phi + residual
+        NMARK(5);                                                  // 5: GEMM phi + residual
     }
 
     if (a.mode != 2) {
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         }
         if (valid && !a.hn_perm) store16(a.hn_out + row, w, g, mine);
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = hn
-        NMARK();                                                  // 6: LayerNorm + exchange 3
+        NMARK(6);                                                  // 6: LayerNorm + exchange 3
         if (a.hn_perm) {
             // feature-permuted copy for the row-layout gather of conv_edge_f16x3.hip, written from the assembled rows
             // in the exchange buffer: position 4 c + j holds feature 32 j + c, one coalesced 16-byte store per (atom, c)
@@ -243,20 +243,20 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         load16(a.pre.bS, w, g, mine);
         gemm16<true>(a.pre.wsp, a.pre.wdp, wn, XB, mine, w, lane);
         if (valid) store16(a.S_out + row, w, g, mine);
-        NMARK();                                                  // 7: GEMM S
+        NMARK(7);                                                  // 7: GEMM S
         mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         mine[1] = mine[0];
         gemm16<true>(a.pre.wdp, a.pre.wpdp, wn, XB, mine, w, lane);
         if (valid) store16(a.D_out + row, w, g, mine);
-        NMARK();                                                  // 8: GEMM D
+        NMARK(8);                                                  // 8: GEMM D
         load16(a.pre.bP, w, g, mine);
         gemm16<false>(a.pre.wpdp, nullptr, wn, XB, mine, w, lane);
         if (valid) store16(a.P_out + row, w, g, mine);
-        NMARK();                                                  // 9: GEMM P
+        NMARK(9);                                                  // 9: GEMM P
 #ifdef GAMD_PROFILING
         if (a.tdbg && a.mode == 1 && lane == 0 && blockIdx.x < 512) {
             long long* o = a.tdbg + ((size_t)blockIdx.x * 4 + w) * 16;
-            for (int i = 0; i < 16; ++i) o[i] = i < tmi ? tm[i] : 0;
+            for (int i = 0; i < 16; ++i) o[i] = tm[i];
         }
 #endif
     } else {
@@ -297,6 +297,8 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         }
     }
 }
+
+#undef NMARK
 
 }  // namespace
 

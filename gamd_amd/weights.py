@@ -167,10 +167,27 @@ def strip_prefix(sd: Dict[str, torch.Tensor], prefix: str = "pnet_model.") -> "O
     return out
 
 
-def load_checkpoint(path: str) -> "OrderedDict[str, torch.Tensor]":
+def load_checkpoint(path: str, allow_pickle: bool = False) -> "OrderedDict[str, torch.Tensor]":
     """Load either a plain state_dict (build_model, train_network_lj.py:85-87) or a
-    Lightning checkpoint (``ckpt['state_dict']``, keys prefixed ``pnet_model.``)."""
-    obj = torch.load(path, map_location="cpu", weights_only=False)
+    Lightning checkpoint (``ckpt['state_dict']``, keys prefixed ``pnet_model.``).
+
+    The file is read with torch's restricted unpickler (``weights_only=True``: tensors, containers and the
+    argparse / SimpleNamespace hyper-parameter objects a Lightning checkpoint of the reference carries, nothing
+    executable).  The reference itself calls the unrestricted ``torch.load`` (train_network_lj.py:85-87); a
+    checkpoint that needs it must be opted into with ``allow_pickle=True`` — unpickling runs arbitrary code
+    from the file, so only do that for files you trust."""
+    import argparse
+    import types
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace, types.SimpleNamespace, OrderedDict]):
+            obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as exc:                          # pickle.UnpicklingError and friends
+        if not allow_pickle:
+            raise RuntimeError(
+                f"{path}: not loadable with torch.load(weights_only=True) ({type(exc).__name__}: {exc}). "
+                "If you trust the file, pass allow_pickle=True (load_checkpoint / load_from_checkpoint): the full "
+                "unpickler executes code stored in the checkpoint.") from exc
+        obj = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(obj, dict) and "state_dict" in obj:
         obj = obj["state_dict"]
     sd = strip_prefix(obj)

@@ -81,6 +81,75 @@ def test_gpus_2_spawns_two_ranks_by_itself():
     assert "cpu_baseline" not in d and "secondary" not in d
 
 
+def test_gpus_2_line_names_each_ranks_device():
+    """per_rank carries the device ordinal, the PCI bus id and the size of the process group each rank saw: on an 8-GPU node
+    'N ranks on N distinct GPUs' is readable from the line (here both ranks share device 0 on purpose)."""
+    d = _run("--gpus", "2", "--no-cpu-baseline", "--no-secondary", steps=2, warmup=1,
+             env={"GAMD_BENCH_SHARE_GPU": "1", "GAMD_BENCH_BACKEND": "gloo"})
+    ranks = d["ensemble"]["per_rank"]
+    assert all(r["group_world_size"] == 2 and r["device"] == 0 and r["host_threads"] >= 1 for r in ranks)
+    assert all(len(r["pci_bus_id"].split(":")) == 3 for r in ranks) and ranks[0]["pci_bus_id"] == ranks[1]["pci_bus_id"]
+    assert d["ensemble"]["distinct_devices"] == 1
+
+
+def test_a_failing_rank_ends_the_run_quickly_and_leaves_no_orphan():
+    """Rank 1 dies after the rendezvous (GAMD_BENCH_FAIL_RANK): the launcher must stop rank 0 — which would otherwise wait
+    in the first barrier until the process-group timeout — exit non-zero well within a minute and leave no process behind."""
+    import time
+    import uuid
+    import psutil
+    mark = uuid.uuid4().hex
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(GAMD_BENCH_SHARE_GPU="1", GAMD_BENCH_BACKEND="gloo", GAMD_BENCH_FAIL_RANK="1", GAMD_TEST_MARK=mark)
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2000", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+    dt = time.monotonic() - t0
+    assert p.returncode != 0 and p.stdout.strip() == "", (p.returncode, p.stdout[-500:])
+    assert "rank 1 exited with status 3" in p.stderr or "rank 0 exited" in p.stderr, p.stderr[-1000:]
+    assert dt < 60, dt
+    left = []
+    for q in psutil.process_iter(["pid"]):
+        try:
+            if q.environ().get("GAMD_TEST_MARK") == mark:
+                left.append(q.pid)
+        except (psutil.Error, OSError):
+            pass
+    assert left == [], left
+
+
+RCCL_WS1 = r"""
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="%d")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch
+import torch.distributed as dist
+from gamd_amd import ensemble as ens
+ctx = ens.init_ensemble("nccl", force_group=True, timeout_s=120)       # device_id=cuda:0 -> eager RCCL communicator
+assert ctx.distributed and ctx.backend == "nccl" and dist.get_backend() == "nccl"
+ens.barrier(ctx)                                                        # dist.barrier(device_ids=[0])
+assert ens.max_over_ranks(2.5, ctx, device="cuda:0") == 2.5            # all_reduce(MAX) on a CUDA tensor
+ident = ens.device_identity(0)
+summ = ens.gather_summary({"seconds": 1.25, "edges": 634930.0, **ident}, ctx, device="cuda:0")   # all_gather_into_tensor
+assert len(summ) == 1 and summ[0]["seconds"] == 1.25 and summ[0]["edges"] == 634930.0
+assert summ[0]["group_world_size"] == 1.0 and summ[0]["pci_bus"] >= 0
+print("PCI", ens.pci_string(summ[0]))
+ens.shutdown(ctx)
+print("RCCL_WS1_OK")
+"""
+
+
+def test_rccl_branch_at_world_size_1():
+    """The branch an 8-GPU run takes (backend "nccl" = RCCL, device_id, barrier(device_ids), all_reduce(MAX) and
+    all_gather_into_tensor on CUDA tensors), executed on this one-GPU box with a process group of size 1."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-c", RCCL_WS1 % (ROOT, port)], capture_output=True, text=True, timeout=600, env=e)
+    assert p.returncode == 0 and "RCCL_WS1_OK" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
 def test_gpus_2_without_a_second_device_fails_loudly():
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GAMD_BENCH_SHARE_GPU")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
