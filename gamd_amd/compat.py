@@ -80,7 +80,7 @@ class _ModelLevel:
             raise TypeError("expected (pos_lst, edge_lst), (pos_lst, feat, edge_lst) or (pos_lst, feat, box_lst, cutoff)")
         # the per-graph list must be as long as pos_lst (a longer one would be truncated silently, a shorter one would
         # surface as a bare IndexError)
-        name, lst = {1: ("edge_lst", rest[0]), 2: ("edge_lst", rest[-1]), 3: ("box_size_lst", rest[1])}[len(rest)]
+        name, lst = ("box_size_lst", rest[1]) if len(rest) == 3 else ("edge_lst", rest[-1])
         if len(lst) != len(pos_lst):
             raise ValueError(f"{name} has {len(lst)} entries for {len(pos_lst)} graphs in pos_lst")
         eng = self._owner._get_engine()

@@ -62,6 +62,8 @@ __device__ __forceinline__ void gemm128_f16x3_post(const f16x8* W, int lane, con
 
 // one 1 KiB piece (k = 0 .. 64/NW - 1 for this wave) of the same copy, to be issued between MFMAs: with one wave per
 // SIMD the ~100 cycles each LDS-DMA instruction takes to issue are otherwise dead time of the matrix pipe
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // "m0" on the clobber lists: see gamd_common.h
 template <int NW>
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16, int k) {
     // (inline assembly: a compiler-tracked global_load_lds turns the next wait of any kind into vmcnt(0) lgkmcnt(0), see
@@ -80,6 +82,8 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ gw, float*
         default: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
     }
 }
+
+#pragma clang diagnostic pop
 
 // piece i (0..15) of load_row_chain / load_e_tile, so that a gather can be spread over the K steps of a GEMM
 __device__ __forceinline__ void load_row_piece(const float* __restrict__ row, int half, f32x16 (&X)[4], int i) {

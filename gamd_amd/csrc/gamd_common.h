@@ -248,6 +248,12 @@ __device__ __forceinline__ void gamd_stage_weight(const float* __restrict__ gw, 
     }
 }
 
+// M0 (the LDS address of an LDS-DMA) is written inside the inline assembly below and named in its clobber list, so that
+// hipcc never assumes a value it put into M0 itself (for a tracked global_load_lds or a relative-indexed access) survives
+// the statement; clang warns that M0 is a reserved register on this target — that is exactly why it is listed.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+
 // The same copy issued from inline assembly, i.e. INVISIBLE to hipcc's s_waitcnt insertion.  For a tracked
 // global_load_lds (FLAT encoding, touches both global memory and LDS) the compiler keeps a "pending flat" state that
 // turns the next wait of ANY kind — e.g. the lgkmcnt wait of the first weight ds_read of the phase — into
@@ -288,6 +294,8 @@ __device__ __forceinline__ void gamd_stage_weight_raw_contig(const float* __rest
                      ::"v"(lane16), "s"(g0 + h * 4096), "s"(l0 + h * 4096u)
                      : "memory", "m0");
 }
+
+#pragma clang diagnostic pop
 
 // Latency-oriented split of a 32-row tile over the 4 waves of a 256-thread workgroup (node.hip, conv_edge_small.hip,
 // wide.hip's node kernel): wave `quarter` computes output features [32 quarter, 32 quarter + 32) of every GEMM from its

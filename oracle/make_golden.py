@@ -53,7 +53,7 @@ def margin_to_cutoff(pos32, box, cutoff):
 
 
 def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=None,
-                  bond=None, lmean=4.0, lstd=1.5, keep_h=True, edge_stride=1, inplace_self_loop=False):
+                  bond=None, lmean=4.0, lstd=1.5, keep_h=True, edge_stride=1, inplace_self_loop=False, h_stride=1):
     torch.manual_seed(1234)
     ref_stubs.INPLACE_SELF_LOOP = bool(inplace_self_loop)
     sd = make_state_dict(cfg, seed, lmean, lstd)
@@ -108,11 +108,13 @@ def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=Non
                margin=np.float64(margin),
                cfg=np.array([cfg.kind, str(cfg.encoding_size), str(cfg.hidden_dim),
                              str(cfg.edge_embedding_dim), str(cfg.conv_layer), str(int(cfg.use_bond))]))
+    if h_stride > 1:
+        rec["h_stride"] = np.int64(h_stride)
     if inplace_self_loop:
         rec["self_loop_inplace"] = np.int64(1)
     if keep_h:
         # h_0 .. h_L — enough to localise a diff to one layer
-        rec["h_layers"] = np.stack([h.numpy() for h in hs])
+        rec["h_layers"] = np.stack([h.numpy()[::h_stride] for h in hs])
     if feat is not None:
         rec["node_feat"] = feat.numpy()
     if bond is not None:
@@ -192,6 +194,23 @@ def main():
     lj_pos = np.load(os.path.join(REF, "code/LJ/init_pos.npy"))          # [258,3] f32, in [0, 27.22]
     w_pos = np.load(os.path.join(REF, "code/water/init_pos.npy"))        # [774,3] f64, centred
     full = dict(encoding_size=128, hidden_dim=128, edge_embedding_dim=128, conv_layer=4)
+
+    # The trainers' DEFAULT widths (LJ/train_network_lj.py:394-396, water/train_network_tip3p.py:404-406: encoding_size 256,
+    # hidden_dim 128, edge_embedding_dim 256) on the fixed-box models: jax-md neighbour flavour (self edges), bond feature,
+    # 4 layers — the configuration the generic-width kernels (wide.hip) serve outside the dynamic-box flavour.
+    # `--only-wide` writes just these two.
+    wide = dict(encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=4)
+    if "--only-wide" in sys.argv or len(sys.argv) == 1:
+        run_fixed_box(nn_module, "lj258_w256_seed9", ModelConfig(kind="lj", **wide), 9, lj_pos, 27.27, 7.5,
+                      SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, edge_stride=61, h_stride=3)
+        nw = w_pos.shape[0]
+        featw = torch.zeros(nw, 1)
+        featw[::3] = 1.0
+        run_fixed_box(nn_module, "tip3p774_w256_seed10", ModelConfig(kind="water", use_bond=True, **wide), 10,
+                      w_pos, 20.0, 4.2, SHIPPED_SCALERS["tip3p"], feat=featw, bond=water_bond(nw),
+                      lmean=2.9, lstd=1.1, edge_stride=211, h_stride=9)
+    if "--only-wide" in sys.argv:
+        return
 
     # model-level call with two graphs (`--only-batch` writes just this one)
     rngb = np.random.default_rng(11)

@@ -1,0 +1,222 @@
+"""Round-4 parity tests (all through the C ABI):
+
+* exact edge-SET equality with the oracle's blocked O(N^2) search at the FULL sizes of BASELINE configs 2, 3, 5 (both
+  readings), in exact mode and in Verlet-skin mode on the positions an on-device MD run of >= 200 steps ends at — the
+  oracle is no longer fed the GPU's own edge list there;
+* a per-atom error statistic (median / p99 of |df_i| / |f_i|) next to the max-norm bar;
+* the generic-width kernels (wide.hip) on the fixed-box models with the trainers' DEFAULT widths 256 / 128 / 256
+  (LJ/train_network_lj.py:394-396): jax-md flavour (self edges), bond feature, skin reuse, a short md_run — against
+  outputs of the reference's own modules (tests/golden/*_w256_*).
+"""
+import numpy as np
+import pytest
+import torch
+
+import gamd_oracle as orc
+from helpers import load_golden, rel_err, edge_set, per_atom_err, edge_set_diff_near_cutoff
+from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS
+from gamd_amd import workloads
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+P99_TOL = 1e-5          # per-atom |df_i| / |f_i|, 99th percentile, fp32 and split-fp16 paths
+NEAR_CUTOFF = 1e-4      # pairs this close to the cutoff may flip between two fp32 searches; nothing else may differ
+
+
+def _engine(*a, **kw):
+    from gamd_amd.engine import GamdForce
+    return GamdForce(*a, **kw)
+
+
+def _workload(name):
+    """(state_dict, pos, box, cutoff, species, bonds, scaler, md kwargs, edge dtype) of a BASELINE config, as bench.py builds it."""
+    if name == "c2":
+        pos, box = workloads.lj_box(10000)
+        return (make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2), pos, box, 3.0 * workloads.LJ_SIGMA, None, None,
+                SHIPPED_SCALERS["lj"], dict(dt_ps=0.002, mass_amu=39.9), "f32")
+    nmol, dens, scal, seed, dtype = {"c3": (1390, 258.0, "tip3p", 2345, "f32"), "c5": (2000, 251.0, "tip4p", 3456, "bf16"),
+                                     "c5b": (2667, 251.0, "tip4p", 3456, "bf16")}[name]
+    pos, box, species, bonds = workloads.water_box(nmol, mol_per_20A3=dens, seed=seed, jitter=0.0, wrap=False)
+    md = dict(dt_ps=0.0005, mass_amu=workloads.MASS_O, mass_h_amu=workloads.MASS_H, rigid_water=True,
+              r_oh=workloads.TIP3P_R_OH, r_hh=workloads.TIP3P_R_HH)
+    return (make_state_dict(ModelConfig(kind="water", use_bond=True), 3, 2.9, 1.1), pos, box, 4.2, species, bonds,
+            SHIPPED_SCALERS[scal], md, dtype)
+
+
+def _assert_same_edge_set(eng, x_host, box, rc, n, what):
+    """GPU CSR vs the oracle's own search on the same (wrapped, fp32) positions."""
+    xw = torch.remainder(torch.from_numpy(np.asarray(x_host)).float(), float(box))
+    ref = orc.neighbor_edges(xw, box, rc, "jaxmd").numpy()
+    got = eng.debug_edges()
+    pairs, dist = edge_set_diff_near_cutoff(got, ref, xw.numpy(), box, rc, n)
+    assert len(pairs) <= 8 and (len(pairs) == 0 or dist.max() < NEAR_CUTOFF), \
+        f"{what}: {len(pairs)} directed pairs differ, the farthest {dist.max() if len(pairs) else 0:.3e} from the cutoff"
+    # no duplicates, every atom has its self edge (jax-md flavour, mask_self=False)
+    assert len(np.unique(edge_set(got))) == got.shape[1]
+    assert int((got[0] == got[1]).sum()) == n
+    return got.shape[1], len(pairs)
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c5", "c5b"])
+def test_full_size_edge_sets_equal_the_oracles_own_search(name):
+    """Exact mode at the start positions, then skin mode (cutoff / 6, the reference's dr_threshold) after 240 MD steps on
+    the device (several candidate rebuilds and many reuse steps), compared at the positions the run ends at."""
+    sd, pos, box, rc, species, bonds, scaler, md, dtype = _workload(name)
+    n = pos.shape[0]
+    eng = _engine(sd, n, box, rc, bond=bonds, scaler=scaler, edge_dtype=dtype)
+    p = torch.from_numpy(pos).float()
+    eng.forward(p, species=species)
+    e0, d0 = _assert_same_edge_set(eng, pos, box, rc, n, f"{name} exact mode")
+    eng.close()
+
+    eng = _engine(sd, n, box, rc, bond=bonds, scaler=scaler, edge_dtype=dtype, neighbor_skin=rc / 6.0)
+    x = p.cuda()
+    v = torch.from_numpy(workloads.maxwell_boltzmann(n, mass_amu=md["mass_amu"], temperature_k=300.0, seed=5)).float().cuda()
+    f = eng.forward(x, species=species, denormalize=True)
+    eng.md_run(x, v, f, 240, temperature_k=300.0, gamma_per_ps=5.0, seed=3, species=species, **md)
+    assert torch.isfinite(x).all() and torch.isfinite(f).all()
+    rebuilds = eng.skin_stats()[0]
+    assert rebuilds >= 2, rebuilds                  # the list really was reused AND rebuilt on the way
+    xh = x.cpu().numpy()
+    moved = np.abs(xh - pos - float(box) * np.round((xh - pos) / float(box))).max()
+    assert moved > 0.2                              # atoms left their start positions
+    e1, d1 = _assert_same_edge_set(eng, xh, box, rc, n, f"{name} skin mode after 240 steps ({rebuilds} rebuilds)")
+    # the exact rebuild at the same positions gives the same set (and the same count) as the skin path
+    eng2 = _engine(sd, n, box, rc, bond=bonds, scaler=scaler, edge_dtype=dtype)
+    eng2.forward(x, species=species)
+    assert np.array_equal(edge_set(eng2.debug_edges()), edge_set(eng.debug_edges()))
+    eng.close(); eng2.close()
+
+
+@pytest.mark.parametrize("name,edge_dtype", [("c2", "f32"), ("c2", "f16x3"), ("c3", "f32"), ("c3", "f16x3")])
+def test_full_size_forces_per_atom_error(name, edge_dtype):
+    """The oracle on its OWN edge list (not the GPU's) at the full size; max-norm bar and the per-atom statistic."""
+    sd, pos, box, rc, species, bonds, scaler, md, _ = _workload(name)
+    n = pos.shape[0]
+    eng = _engine(sd, n, box, rc, bond=bonds, scaler=scaler, edge_dtype=edge_dtype)
+    p = torch.from_numpy(pos).float()
+    out = eng.forward(p, species=species).cpu().numpy()
+    pw = torch.remainder(p, float(box))
+    edges = orc.neighbor_edges(pw, box, rc, "jaxmd")
+    assert edges.shape[1] == eng.counts()[0]
+    feat = None if species is None else torch.from_numpy(species.astype(np.float32)).view(-1, 1)
+    ref = orc.forward(sd, pw, edges, box, feat=feat, bond=bonds).numpy()
+    med, p99, worst, cnt = per_atom_err(out, ref)
+    print(f"{name} {edge_dtype}: max-norm {rel_err(out, ref):.2e}; per atom median {med:.2e} p99 {p99:.2e} max {worst:.2e} "
+          f"over {cnt} of {n} atoms")
+    assert rel_err(out, ref) < TOL
+    assert cnt > 0.9 * n and p99 < P99_TOL, (med, p99, worst, cnt)
+    eng.close()
+
+
+# ---- generic-width kernels on the fixed-box models (trainer-default widths) ---------------------------------------
+WIDE = ["lj258_w256_seed9", "tip3p774_w256_seed10"]
+
+
+def _wide_case(name, **kw):
+    g, cfg, sd = load_golden(name)
+    assert (cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim) == (256, 128, 256)
+    box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+    bond = g["bond"] if "bond" in g else None
+    species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
+    eng = _engine(sd, n, box, rc, bond=bond, scaler=(g["scaler_mean"], g["scaler_var"]), **kw)
+    return g, cfg, sd, eng, box, rc, n, bond, species
+
+
+@pytest.mark.parametrize("name", WIDE)
+def test_wide_fixed_box_goldens_stage_by_stage(name):
+    g, cfg, sd, eng, box, rc, n, bond, species = _wide_case(name, keep_stages=True)
+    posw = np.mod(g["pos"], box).astype(np.float32)
+    out = eng.forward(torch.from_numpy(posw), species=species).cpu().numpy()
+    edges = eng.debug_edges()
+    assert np.array_equal(edge_set(edges), edge_set(g["edge_idx"]))
+    assert int((edges[0] == edges[1]).sum()) == n                     # jax-md flavour: self edges
+    s = int(g["edge_stride"])
+    gkey = g["edge_idx"][0].astype(np.int64) * n + g["edge_idx"][1]
+    pos_of = {k: i for i, k in enumerate(edges[0] * n + edges[1])}
+    rows = np.array([pos_of[k] for k in gkey[::s]])
+    nf = g["feat_rows"].shape[1]
+    assert nf == (45 if bond is not None else 44)
+    assert rel_err(eng.debug_feat(nf)[rows], g["feat_rows"]) < TOL
+    assert rel_err(eng.debug_e()[rows], g["e_rows"]) < TOL
+    hs = int(g["h_stride"])
+    for l in range(g["h_layers"].shape[0]):
+        assert rel_err(eng.debug_h(l)[::hs], g["h_layers"][l]) < TOL, f"h_{l}"
+    assert rel_err(out, g["out_norm"]) < TOL
+    med, p99, worst, cnt = per_atom_err(out, g["out_norm"])
+    assert p99 < P99_TOL, (med, p99, worst)
+    den = eng.forward(torch.from_numpy(posw), species=species, denormalize=True).cpu().numpy()
+    assert rel_err(den, g["forces"]) < TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("name", WIDE)
+def test_wide_fixed_box_skin_reuse_and_md_run(name):
+    """Skin mode: the golden forces again, then along a random walk the edge SET equals the exact rebuild's at every step;
+    then a short deterministic MD run (T = 0) against the oracle integrator driven by oracle forces."""
+    g, cfg, sd, eng, box, rc, n, bond, species = _wide_case(name, neighbor_skin=rc / 6.0)
+    exact = _engine(sd, n, box, rc, bond=bond, scaler=(g["scaler_mean"], g["scaler_var"]))
+    posw = np.mod(g["pos"], box)
+    assert rel_err(eng.forward(torch.from_numpy(posw).float(), species=species).cpu().numpy(), g["out_norm"]) < TOL
+    rng = np.random.default_rng(2)
+    x = posw.copy()
+    for step in range(12):
+        x = x + rng.normal(0, 0.12, x.shape)
+        a = eng.forward(torch.from_numpy(x).float(), species=species).cpu().numpy()
+        b = exact.forward(torch.from_numpy(x).float(), species=species).cpu().numpy()
+        assert np.array_equal(edge_set(eng.debug_edges()), edge_set(exact.debug_edges())), step
+        assert rel_err(a, b) < TOL
+    assert 1 <= eng.skin_stats()[0] < 12                                # reused at least once, rebuilt at least once
+    exact.close()
+    # md_run, free atoms (the LJ case) / unconstrained per-species masses (the water case): T = 0 -> no noise
+    mean, var = g["scaler_mean"], g["scaler_var"]
+    feat = torch.from_numpy(g["node_feat"]) if "node_feat" in g else None
+    mass = (np.where(species, workloads.MASS_O, workloads.MASS_H).reshape(-1, 1) if species is not None else 39.9)
+    xg = torch.from_numpy(posw).float().cuda()
+    vg = torch.from_numpy(np.random.default_rng(1).normal(0, 1.0, (n, 3))).float().cuda()
+    fg = eng.forward(xg, species=species, denormalize=True).clone()
+    xr, vr, fr = xg.cpu().double().numpy(), vg.cpu().double().numpy(), fg.cpu().double().numpy()
+    dt, gamma, steps = 0.001, 25.0, 3
+    kw = dict(mass_amu=workloads.MASS_O, mass_h_amu=workloads.MASS_H, species=species) if species is not None else dict(mass_amu=39.9)
+    eng.md_run(xg, vg, fg, steps, dt_ps=dt, temperature_k=0.0, gamma_per_ps=gamma, **kw)
+    a = np.exp(-gamma * dt)
+    for _ in range(steps):
+        xr, vr = orc.baoab_first_half(xr, vr, fr, 10.0 / mass, dt, a, 0.0, 0.0)
+        xr = np.mod(xr, box)
+        fr = orc.predict_forces(sd, xr, box, rc, var=var, mean=mean, feat=feat, bond=bond)
+        vr = orc.baoab_second_half(vr, fr, 10.0 / mass, dt)
+    assert rel_err(xg.cpu().numpy(), xr) < 1e-5
+    assert rel_err(vg.cpu().numpy(), vr) < 1e-4
+    assert rel_err(fg.cpu().numpy(), fr) < 1e-4
+    eng.close()
+
+
+def test_wide_kernels_match_the_128_wide_ones_with_self_edges_and_bonds():
+    """kernel_select = FORCE_GENERIC_WIDTH on the 128-wide TIP3P golden: wide.hip with the jax-md flavour and the bond
+    feature reproduces the reference golden too (and the specialised kernels to fp32 rounding)."""
+    from gamd_amd.engine import KSEL_FORCE_GENERIC_WIDTH
+    g, cfg, sd = load_golden("tip3p774_seed3")
+    box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+    species = g["node_feat"].reshape(-1) != 0
+    posw = torch.from_numpy(np.mod(g["pos"], box)).float()
+    outs = []
+    for ksel in (0, KSEL_FORCE_GENERIC_WIDTH):
+        eng = _engine(sd, n, box, rc, bond=g["bond"], kernel_select=ksel, neighbor_skin=rc / 6.0)
+        outs.append(eng.forward(posw, species=species).cpu().numpy())
+        eng.close()
+    assert rel_err(outs[1], g["out_norm"]) < TOL and rel_err(outs[1], outs[0]) < TOL
+
+
+def test_f16x3_first_call_on_a_cold_device_matches_f32():
+    """the split-fp16 kernel's prologue must wait for its own W1 copy.  The very first launch of a fresh
+    engine (cold L2 for the weight image) is compared with the fp32 path, and the run is repeated bit for bit."""
+    sd, pos, box, rc, species, bonds, scaler, md, _ = _workload("c2")
+    p = torch.from_numpy(pos).float()
+    e16 = _engine(sd, 10000, box, rc, scaler=scaler, edge_dtype="f16x3")
+    first = e16.forward(p).cpu().numpy().copy()                         # first call of this engine
+    again = e16.forward(p).cpu().numpy().copy()
+    e32 = _engine(sd, 10000, box, rc, scaler=scaler)
+    ref = e32.forward(p).cpu().numpy()
+    assert np.array_equal(first, again)
+    assert rel_err(first, ref) < TOL
+    e16.close(); e32.close()

@@ -49,6 +49,44 @@ def test_lightning_checkpoint_and_scaler(tmp_path):
     assert abs(SHIPPED_SCALERS["lj"][1][0] - 1010.00278026) < 1e-6
 
 
+class _Payload:                                     # stands for arbitrary code a pickle can run on load
+    def __reduce__(self):
+        return (os.getenv, ("GAMD_PICKLE_CANARY",))
+
+
+def test_checkpoints_are_read_with_the_restricted_unpickler(tmp_path):
+    """weights_only=True first: a Lightning checkpoint of the reference (tensors + an argparse Namespace of hyper
+    parameters) loads; one that needs the full unpickler is refused unless the caller opts in with allow_pickle=True."""
+    import argparse
+    from types import SimpleNamespace
+    sd = make_state_dict(ModelConfig(), 2)
+    ck = {"state_dict": {"pnet_model." + k: v for k, v in sd.items()}, "epoch": 30, "global_step": 12345,
+          "hparams_name": "args", "hyper_parameters": {"args": argparse.Namespace(encoding_size=128, lr=3e-4, loss="mae")},
+          "extra": SimpleNamespace(a=1)}
+    torch.save(ck, tmp_path / "lightning.ckpt")
+    assert set(load_checkpoint(str(tmp_path / "lightning.ckpt"))) == set(sd)
+    bad = dict(ck, callbacks=_Payload())
+    torch.save(bad, tmp_path / "needs_pickle.ckpt")
+    with pytest.raises(RuntimeError, match="allow_pickle=True"):
+        load_checkpoint(str(tmp_path / "needs_pickle.ckpt"))
+    got = load_checkpoint(str(tmp_path / "needs_pickle.ckpt"), allow_pickle=True)
+    assert torch.equal(got["node_emb"], sd["node_emb"])
+
+
+def test_batched_model_call_checks_its_list_lengths():
+    """compat._ModelLevel._batched: the per-graph list must match pos_lst (checked before any GPU work)."""
+    from gamd_amd.compat import ParticleNetLightningLJ
+    m = ParticleNetLightningLJ(state_dict=make_state_dict(ModelConfig(), 0), num_atoms=8)
+    pos = [torch.zeros(8, 3), torch.zeros(8, 3)]
+    e = torch.zeros(2, 4, dtype=torch.long)
+    with pytest.raises(ValueError, match="edge_lst has 3 entries for 2 graphs"):
+        m.pnet_model(pos, [e, e, e])
+    with pytest.raises(ValueError, match="edge_lst has 1 entries for 2 graphs"):
+        m.pnet_model(pos, [e])
+    with pytest.raises(TypeError):
+        m.pnet_model(pos, 1, 2, 3, 4)
+
+
 def test_workloads_shapes_and_density():
     pos, box = workloads.lj_box(10000)
     assert pos.shape == (10000, 3) and abs(box - 92.29) < 0.01

@@ -7,7 +7,8 @@ import torch
 import gamd_oracle as orc
 from helpers import load_golden, rel_err, edge_set
 
-FIXED = ["lj258_seed0", "lj258_pert_seed1", "lj64_h32", "tip3p774_seed3"]
+# the *_w256_* cases: the trainers' default widths 256 / 128 / 256 (LJ/train_network_lj.py:394-396) on the fixed-box models
+FIXED = ["lj258_seed0", "lj258_pert_seed1", "lj64_h32", "tip3p774_seed3", "lj258_w256_seed9", "tip3p774_w256_seed10"]
 
 
 @pytest.mark.parametrize("name", FIXED)
@@ -25,8 +26,9 @@ def test_forward_matches_reference(name):
     assert rel_err(st["feat"].numpy()[::s], g["feat_rows"]) < 1e-6
     assert rel_err(st["e"].numpy()[::s], g["e_rows"]) < 5e-6
     if "h_layers" in g:
+        hs = int(g["h_stride"]) if "h_stride" in g else 1
         for l, h in enumerate(st["h"]):
-            assert rel_err(h.numpy(), g["h_layers"][l]) < 5e-6, f"layer {l}"
+            assert rel_err(h.numpy()[::hs], g["h_layers"][l]) < 5e-6, f"layer {l}"
     assert rel_err(out, g["out_norm"]) < 5e-6
     forces = orc.denormalize(out, g["scaler_var"], g["scaler_mean"])
     assert forces.dtype == np.float64
