@@ -21,7 +21,7 @@ class GamdConfig(C.Structure):
                 ("keep_stages", C.c_int32), ("edge_dtype", C.c_int32),
                 ("encoding_size", C.c_int32), ("edge_embedding_dim", C.c_int32), ("hidden_dim", C.c_int32),
                 ("no_expand_edge", C.c_int32), ("neighbor_skin", C.c_float), ("self_loop_mode", C.c_int32),
-                ("kernel_select", C.c_int32), ("small_tile_limit", C.c_int32)]
+                ("kernel_select", C.c_int32), ("small_tile_limit", C.c_int32), ("n_boxes", C.c_int32)]
 
 
 # common tail of both integrator parameter blocks (masses per species, length unit, rigid water)

@@ -71,9 +71,10 @@ class _ModelLevel:
     def _batched(self, pos_lst, *rest):
         """``len(pos_lst) > 1``: the reference builds one graph per entry and runs the network on their disjoint union
         (build_graph_batches + dgl.batch, nn_module.py:655-661, :520-527; edge indices are local to each graph, `feat`
-        is the concatenation of the per-graph node features) and returns the outputs concatenated in order.  Without
-        batch statistics (LayerNorm only in every shipped configuration) that is the per-graph result, graph by
-        graph; every graph must have the atom count the engine was built for."""
+        is the concatenation of the per-graph node features) and returns the outputs concatenated in order.  Here the
+        graphs are the boxes of ONE batched engine (GamdForce(n_boxes=len(pos_lst))): a single set of launches, results
+        bit-identical to the graphs evaluated one by one.  Every graph must have the atom count the wrapper was built
+        for."""
         if len(pos_lst) == 0:
             raise ValueError("empty pos_lst")
         if len(rest) not in (1, 2, 3):
@@ -83,28 +84,29 @@ class _ModelLevel:
         name, lst = ("box_size_lst", rest[1]) if len(rest) == 3 else ("edge_lst", rest[-1])
         if len(lst) != len(pos_lst):
             raise ValueError(f"{name} has {len(lst)} entries for {len(pos_lst)} graphs in pos_lst")
-        eng = self._owner._get_engine()
-        sizes = [int(np.asarray(p.shape)[0]) if not isinstance(p, torch.Tensor) else int(p.shape[0]) for p in pos_lst]
-        if any(n != eng.n for n in sizes):
-            raise ValueError(f"every graph of a batch must have {eng.n} atoms (the engine's size), got {sizes}")
-        feat = rest[0] if len(rest) >= 2 else None
-        feats = [None] * len(pos_lst)
-        if feat is not None:
-            f = _node_feature(feat)
-            if f.shape[0] != sum(sizes):
-                raise ValueError(f"feat has {f.shape[0]} rows for {sum(sizes)} atoms")
-            feats = list(torch.split(f, sizes))
-        outs = []
-        for i, pos in enumerate(pos_lst):
-            if len(rest) == 1:
-                outs.append(self([pos], [rest[0][i]]))
-            elif len(rest) == 2:
-                outs.append(self([pos], feats[i], [rest[1][i]]))
-            elif len(rest) == 3:
-                outs.append(self([pos], feats[i], [rest[1][i]], rest[2]))
-            else:
-                raise TypeError("expected (pos_lst, edge_lst), (pos_lst, feat, edge_lst) or (pos_lst, feat, box_lst, cutoff)")
-        return torch.cat(outs, dim=0)
+        n, nb = self._owner.num_atoms, len(pos_lst)
+        sizes = [int(p.shape[0]) for p in pos_lst]
+        if any(k != n for k in sizes):
+            raise ValueError(f"every graph of a batch must have {n} atoms (the wrapper's size), got {sizes}")
+        eng = self._owner._get_engine(n_boxes=nb)
+        dev = eng.device
+        pos = torch.cat([(torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)) if isinstance(p, np.ndarray) else p)
+                         .to(device=dev, dtype=torch.float32) for p in pos_lst], dim=0)
+        species = None
+        if len(rest) >= 2:
+            species = _node_feature(rest[0])
+            if species.shape[0] != n * nb:
+                raise ValueError(f"feat has {species.shape[0]} rows for {n * nb} atoms")
+        if len(rest) == 3:
+            cutoff = rest[2]
+            if abs(float(cutoff) - eng.cutoff) > 1e-6 * eng.cutoff:
+                raise ValueError(f"cutoff {cutoff} differs from the one the engine was built with ({eng.cutoff})")
+            boxes = np.stack([np.broadcast_to(np.asarray(b, dtype=np.float32).reshape(-1), (3,)) for b in rest[1]])
+            return eng.forward(pos, box=boxes, species=species)
+        # dgl.batch: graph i's node ids are shifted by the number of nodes in front of it
+        edges = torch.cat([(torch.from_numpy(e) if isinstance(e, np.ndarray) else e).to(device=dev, dtype=torch.int64) + i * n
+                           for i, e in enumerate(lst)], dim=1)
+        return eng.forward_edges(pos, edges, species=species)
 
     forward = __call__
 
@@ -124,7 +126,7 @@ class _ForceFieldBase:
         self.training_mean = np.array([0.])          # LJ/train_network_lj.py:105-106
         self.training_var = np.array([1.])
         self._sd = state_dict
-        self._engine: Optional[GamdForce] = None
+        self._engines = {}                           # n_boxes -> GamdForce (1: the driver path; B: model-level batches)
         self.pnet_model = _ModelLevel(self)        # attribute name of the reference (train_network_lj.py:95)
         if scaler_ckpt is not None:
             self.load_training_stats(scaler_ckpt)
@@ -134,19 +136,28 @@ class _ForceFieldBase:
         """Instance-style call used by the drivers: ParticleNetLightning(args).load_from_checkpoint(PATH, args=args).
         ``allow_pickle``: see weights.load_checkpoint (restricted unpickler unless opted out)."""
         self._sd = load_checkpoint(path, allow_pickle=allow_pickle)
-        self._engine = None
+        self._drop_engines()
         return self
 
     def load_state_dict(self, sd):
         self._sd = {k: v.detach().float().cpu() for k, v in sd.items()}
-        self._engine = None
+        self._drop_engines()
         return self
+
+    def _drop_engines(self):
+        for e in self._engines.values():
+            e.close()
+        self._engines = {}
+
+    @property
+    def _engine(self) -> Optional[GamdForce]:
+        return self._engines.get(1)
 
     def load_training_stats(self, scaler_ckpt):
         if scaler_ckpt is not None:
             self.training_mean, self.training_var = load_scaler(scaler_ckpt)
-            if self._engine is not None:
-                self._engine.set_scaler(self.training_mean, self.training_var)
+            for e in self._engines.values():
+                e.set_scaler(self.training_mean, self.training_var)
 
     def cuda(self, device=None):
         return self
@@ -154,15 +165,18 @@ class _ForceFieldBase:
     def eval(self):
         return self
 
-    def _get_engine(self) -> GamdForce:
-        if self._engine is None:
+    def _get_engine(self, n_boxes: int = 1) -> GamdForce:
+        """n_boxes = 1: the engine behind predict_forces / single-graph model calls; n_boxes = B: the batched engine a
+        model-level call with B graphs runs on (built on first use, kept)."""
+        if n_boxes not in self._engines:
             if self._sd is None:
                 raise RuntimeError("no weights loaded: call load_from_checkpoint / load_state_dict first")
-            self._engine = GamdForce(self._sd, self.num_atoms, self.box_size, self.cutoff, bond=self.bond,
-                                     scaler=(self.training_mean, self.training_var), device=self.device_index,
-                                     nbr_flavour=self._nbr_flavour, neighbor_skin=self._skin,
-                                     edge_dtype=self.edge_dtype, self_loop_mode=self.self_loop_mode)
-        return self._engine
+            self._engines[n_boxes] = GamdForce(
+                self._sd, self.num_atoms, self.box_size, self.cutoff, bond=self.bond,
+                scaler=(self.training_mean, self.training_var), device=self.device_index,
+                nbr_flavour=self._nbr_flavour, neighbor_skin=self._skin if n_boxes == 1 else 0.0,
+                edge_dtype=self.edge_dtype, self_loop_mode=self.self_loop_mode, n_boxes=n_boxes)
+        return self._engines[n_boxes]
 
     def denormalize(self, normalized_force, var, mean):
         return normalized_force * np.sqrt(var) + mean         # LJ/train_network_lj.py:128-131

@@ -25,9 +25,10 @@ template <int NFEAT, int ABL, typename CPtr>
 __device__ __forceinline__ void edge_features(const EncArgs& a, CPtr cen, int src, int dst, const float4& ps, const float4& pd,
                                               int half, float (&F)[24]) {
     // nn_module.py:615-624
-    const float rx = gamd_min_image_wrapped(ps.x - pd.x, a.box[0], a.half[0]);
-    const float ry = gamd_min_image_wrapped(ps.y - pd.y, a.box[1], a.half[1]);
-    const float rz = gamd_min_image_wrapped(ps.z - pd.z, a.box[2], a.half[2]);
+    const BoxDims B = gamd_edge_box(a, dst);
+    const float rx = gamd_min_image_wrapped(ps.x - pd.x, B.bx, B.hx);
+    const float ry = gamd_min_image_wrapped(ps.y - pd.y, B.by, B.hy);
+    const float rz = gamd_min_image_wrapped(ps.z - pd.z, B.bz, B.hz);
     const float nrm = sqrtf((rx * rx + ry * ry) + rz * rz);
     const float den = nrm + 1e-8f;
     const float d = (nrm - a.length_mean) / a.length_std;          // :630

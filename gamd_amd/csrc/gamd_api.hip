@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,10 +88,16 @@ struct MdPending {
 
 }  // namespace
 
+static_assert(sizeof(gamd_config) == 96 && offsetof(gamd_config, n_boxes) == 88 && offsetof(gamd_config, edge_capacity) == 40,
+              "gamd_config layout is part of the C ABI (gamd_amd/_lib.py mirrors it)");
+
 struct gamd_handle {
     gamd_config cfg{};
     int dev = 0;
-    int n = 0, L = 0, n_feat = 44, n_cu = 256;
+    int n = 0, L = 0, n_feat = 44, n_cu = 256;   // n: atoms of ALL boxes together (n_boxes * n_per_box)
+    int n_boxes = 1, n_per_box = 0;              // gamd_config.n_boxes: independent boxes evaluated in one set of launches
+    DevBuf boxes_dev, box_shift;                 // n_boxes > 1: per-box dimensions (BoxRef::boxes), scratch of the row scan
+    std::vector<float> boxes_host;               // [n_boxes][3] as last set
     int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width and their 128-blocks
     bool wide_enc = false, wide_conv = false;    // generic-width kernels of wide.hip
     long long small_tile_limit = 512;            // fp32 path: at most this many 32-edge tiles -> conv_edge_small.hip
@@ -149,6 +156,18 @@ struct gamd_handle {
 
 namespace {
 
+// batches never take the single-workgroup small-system path of neighbor.hip (k_step_small / k_filter_fill_small)
+bool small_path(const gamd_handle* h) { return h->n <= 1024 && h->n_boxes <= 1; }
+
+BoxRef box_ref(const gamd_handle* h) {
+    BoxRef r{};
+    r.n_boxes = h->n_boxes;
+    r.n_per_box = h->n_per_box;
+    r.inv_npb = 1.0f / (float)h->n_per_box;
+    r.boxes = h->n_boxes > 1 ? h->boxes_dev.as<float4>() : nullptr;
+    return r;
+}
+
 int alloc_candidates(gamd_handle* h, long long cap) {
     if (h->cand_col.ensure(sizeof(int) * ((size_t)cap + 64), true)) return fail(-12, "candidate buffer allocation failed");
     h->cand_cap = cap;
@@ -172,22 +191,34 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
         const double grow = std::pow(((double)h->cfg.cutoff + h->skin) / (double)h->cfg.cutoff, 3.0);
         // n > 1024: candidate rows have a fixed width (capacity / n), so what must fit is the LONGEST row, not the total:
         // ~2.5 x the mean row (e_cap is already 1.5 x the density estimate) instead of ~1.65 x
-        const long long want = (long long)((double)e_cap * grow * (h->n > 1024 ? 1.7 : 1.1)) + 1024;
+        const long long want = (long long)((double)e_cap * grow * (small_path(h) ? 1.1 : 1.7)) + 1024;
         if (want > h->cand_cap) return alloc_candidates(h, want);
     }
     return 0;
 }
 
-int set_box(gamd_handle* h, const float* box) {
+// box: host [n_boxes][3].  All boxes share one cell grid nc[] (sized for the smallest box along each axis, so every box's
+// cells are at least cutoff + skin wide); h->box keeps box 0 (the by-value box of the single-box kernels' argument blocks).
+int set_box(gamd_handle* h, const float* box, hipStream_t st = nullptr) {
+    const int nb = h->n_boxes;
+    bool changed = h->boxes_host.size() != (size_t)nb * 3;
+    float bmin[3] = {box[0], box[1], box[2]};
+    for (int b = 0; b < nb; ++b)
+        for (int d = 0; d < 3; ++d) {
+            const float v = box[3 * b + d];
+            if (!(v > 0.f)) return fail(-22, "box[%d][%d] = %g is not positive", b, d, (double)v);
+            if (!changed && h->boxes_host[(size_t)3 * b + d] != v) changed = true;
+            bmin[d] = std::min(bmin[d], v);
+        }
+    if (changed) h->cand_valid = false;                           // candidates were built for another box
     long long ncell = 1;
     for (int d = 0; d < 3; ++d) {
-        if (!(box[d] > 0.f)) return fail(-22, "box[%d] = %g is not positive", d, (double)box[d]);
-        if (h->box[d] != box[d]) h->cand_valid = false;            // candidates were built for another box
         h->box[d] = box[d];
-        int nc = (int)std::floor((double)box[d] / (((double)h->cfg.cutoff + (double)h->skin) * 1.0001));
+        int nc = (int)std::floor((double)bmin[d] / (((double)h->cfg.cutoff + (double)h->skin) * 1.0001));
         h->nc[d] = std::max(1, nc);
         ncell *= h->nc[d];
     }
+    ncell *= nb;
     if (ncell > (1ll << 30)) return fail(-22, "cell grid too large");
     if ((int)ncell > h->ncell_cap) {
         int r = 0;
@@ -196,6 +227,18 @@ int set_box(gamd_handle* h, const float* box) {
         r |= h->cell_start.ensure(sizeof(int) * ((size_t)ncell + 1), true);
         if (r) return fail(-12, "cell buffer allocation failed");
         h->ncell_cap = (int)ncell;
+    }
+    if (changed) {
+        h->boxes_host.assign(box, box + (size_t)nb * 3);
+        if (nb > 1) {
+            // kernels of earlier calls may still read the old dimensions: drain the stream before overwriting them (a box
+            // change is rare: NPT-style drivers)
+            HIP_TRY(hipStreamSynchronize(st));
+            std::vector<float> img((size_t)nb * 8, 0.f);
+            for (int b = 0; b < nb; ++b)
+                for (int d = 0; d < 3; ++d) { img[(size_t)8 * b + d] = box[3 * b + d]; img[(size_t)8 * b + 4 + d] = 0.5f * box[3 * b + d]; }
+            HIP_TRY(hipMemcpy(h->boxes_dev.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
+        }
     }
     return 0;
 }
@@ -211,7 +254,10 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
     }
     a.rc = h->cfg.cutoff;
     a.rc2 = (float)((double)h->cfg.cutoff * (double)h->cfg.cutoff);   // graph_utils.py:59 cutoff ** 2
-    a.ncell = h->nc[0] * h->nc[1] * h->nc[2];
+    a.ncell_box = h->nc[0] * h->nc[1] * h->nc[2];
+    a.ncell = a.ncell_box * h->n_boxes;
+    a.bx = box_ref(h);
+    a.box_shift = h->box_shift.as<int>();
     a.e_cap = h->e_cap;
     a.pos = pos_dev;
     a.species = species_dev;
@@ -245,7 +291,7 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
         a.cand_col = h->cand_col.as<int>();
         a.cand_cap = h->cand_cap;
         // fixed-width candidate rows above the single-workgroup size (neighbor.hip): the width follows the capacity
-        a.cand_stride = h->n > 1024 ? (int)std::min<long long>(h->cand_cap / h->n, 1 << 20) : 0;
+        a.cand_stride = small_path(h) ? 0 : (int)std::min<long long>(h->cand_cap / h->n, 1 << 20);
     }
     return a;
 }
@@ -370,7 +416,7 @@ int fill_rigid(const gamd_handle* h, int rigid_water, float mass_o, float mass_h
                int* use_rigid, RigidWater* g) {
     *use_rigid = 0;
     if (!rigid_water) return 0;
-    if (h->n % 3 != 0) return fail(-22, "rigid_water needs O,H,H triples: n_atoms = %d is not a multiple of 3", h->n);
+    if (h->n_per_box % 3 != 0) return fail(-22, "rigid_water needs O,H,H triples: n_atoms = %d is not a multiple of 3", h->n_per_box);
     if (!(mass_h > 0.f) || !(mass_o > 0.f)) return fail(-22, "rigid_water needs mass_amu (O) and mass_h_amu (H)");
     if (!(r_oh > 0.f) || !(r_hh > 0.f) || !(r_hh < 2.f * r_oh)) return fail(-22, "rigid_water needs 0 < r_hh < 2 r_oh");
     const double rc = 0.5 * (double)r_hh, t = std::sqrt((double)r_oh * r_oh - rc * rc);
@@ -430,6 +476,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.row_ptr = h->row_ptr.as<int>();
     ea.self_loop = na.self_loop;
     for (int d = 0; d < 3; ++d) { ea.box[d] = h->box[d]; ea.half[d] = 0.5f * h->box[d]; }
+    ea.bx = box_ref(h);
     ea.length_mean = h->length_mean;
     ea.length_std = h->length_std;
     ea.gamma = (float)(1.0 / 0.025);             // RBFExpansion(high=1, gap=0.025): gamma = 1/gap (nn_module.py:240)
@@ -633,9 +680,12 @@ const char* gamd_last_error(void) { return g_err; }
 int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     if (!cfg || !out) return fail(-22, "null argument");
     if (cfg->n_atoms <= 0) return fail(-22, "n_atoms must be positive");
+    if (cfg->n_boxes < 0 || cfg->n_boxes > (1 << 20)) return fail(-22, "n_boxes out of range");
+    const int n_boxes = cfg->n_boxes > 1 ? cfg->n_boxes : 1;
     // node-table rows are addressed with 32-bit byte offsets (row * 512 B, scalar base + offset loads) in the conv-layer edge
     // kernels: 2^23 - 1 rows including the zero row (a 288 GB device holds ~5e6 atoms of this model)
-    if (cfg->n_atoms >= (1 << 23) - 1) return fail(-22, "n_atoms = %d: at most %d atoms per box", cfg->n_atoms, (1 << 23) - 2);
+    if ((long long)cfg->n_atoms * n_boxes >= (1 << 23) - 1)
+        return fail(-22, "n_atoms x n_boxes = %lld: at most %d atoms per handle", (long long)cfg->n_atoms * n_boxes, (1 << 23) - 2);
     if (cfg->n_layers <= 0 || cfg->n_layers > 16) return fail(-22, "n_layers out of range");
     if (!(cfg->cutoff > 0.f)) return fail(-22, "cutoff must be positive");
     if (cfg->edge_dtype != GAMD_EDGE_F32 && cfg->edge_dtype != GAMD_EDGE_BF16 && cfg->edge_dtype != GAMD_EDGE_F16X3)
@@ -664,7 +714,9 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     gamd_handle* h = new gamd_handle();
     h->cfg = *cfg;
     h->dev = cfg->device;
-    h->n = cfg->n_atoms;
+    h->n_boxes = n_boxes;
+    h->n_per_box = cfg->n_atoms;
+    h->n = cfg->n_atoms * n_boxes;
     h->L = cfg->n_layers;
     h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
     h->skin = cfg->neighbor_skin;
@@ -677,9 +729,15 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     const size_t n = (size_t)h->n;
     int r = 0;
     r |= h->pos_w.ensure(sizeof(float4) * n, true);
-    r |= h->pos_s.ensure(sizeof(float4) * n, true);
+    // one extra row behind pos_s / perm for the padding edges that align the boxes of a batch (col = n): zero position,
+    // original id -2 (matches no bond partner)
+    r |= h->pos_s.ensure(sizeof(float4) * (n + 1), true);
     r |= h->cell_of.ensure(sizeof(int) * n, true);
-    r |= h->perm.ensure(sizeof(int) * n, true);
+    r |= h->perm.ensure(sizeof(int) * (n + 1), true);
+    if (n_boxes > 1) {
+        r |= h->boxes_dev.ensure(sizeof(float) * 8 * (size_t)n_boxes, true);
+        r |= h->box_shift.ensure(sizeof(int) * ((size_t)n_boxes + 2), true);
+    }
     r |= h->inv_perm.ensure(sizeof(int) * n, true);
     r |= h->deg.ensure(sizeof(int) * n, true);
     r |= h->row_ptr.ensure(sizeof(int) * (n + 1), true);
@@ -698,6 +756,13 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->devflags.ensure(sizeof(int) * DEVFLAG_COUNT, true);
     r |= h->cnt2.ensure(sizeof(int) * 2 * CNT_COUNT, true);
     if (r) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
+    {
+        const int no_atom = -2;
+        if (hipMemcpy(h->perm.as<int>() + n, &no_atom, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            gamd_destroy(h);
+            return fail(-1, "device copy failed");
+        }
+    }
     if ((r = clear_devflags(h))) { gamd_destroy(h); return r; }
     if (hipHostMalloc((void**)&h->counters_host, sizeof(int) * CNT_COUNT) != hipSuccess) {
         gamd_destroy(h);
@@ -717,12 +782,17 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         rr |= h->cand_ptr.ensure(sizeof(int) * (n + 1), true);
         if (rr) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
     }
-    if ((r = set_box(h, cfg->box))) { gamd_destroy(h); return r; }
+    {
+        std::vector<float> all((size_t)n_boxes * 3);              // every box starts with the constructor's box
+        for (int b = 0; b < n_boxes; ++b)
+            for (int d = 0; d < 3; ++d) all[(size_t)3 * b + d] = cfg->box[d];
+        if ((r = set_box(h, all.data()))) { gamd_destroy(h); return r; }
+    }
     long long ecap = cfg->edge_capacity;
     if (ecap <= 0) {
         const double vol = (double)cfg->box[0] * cfg->box[1] * cfg->box[2];
-        const double per_atom = 4.18879 * std::pow((double)cfg->cutoff, 3) * (double)h->n / vol + 1.0;
-        ecap = (long long)(1.5 * per_atom * (double)h->n) + 1024;
+        const double per_atom = 4.18879 * std::pow((double)cfg->cutoff, 3) * (double)h->n_per_box / vol + 1.0;
+        ecap = (long long)(1.5 * per_atom * (double)h->n) + 1024 + 16ll * n_boxes;
     }
     if (cfg->self_loop_mode) ecap += h->n;
     if ((r = alloc_edges(h, ecap))) { gamd_destroy(h); return r; }
@@ -735,7 +805,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     DeviceGuard guard(h->dev);
     h->devflags.release();
     h->cnt2.release();
-    DevBuf* bufs[] = {&h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
+    DevBuf* bufs[] = {&h->boxes_dev, &h->box_shift, &h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
                       &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial,
@@ -968,11 +1038,15 @@ int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds) {
         }
         return -1;
     };
-    for (int64_t b = 0; b < n_bonds; ++b) {
-        const int i = bonds[2 * b], j = bonds[2 * b + 1];
-        if (i < 0 || j < 0 || i >= h->n || j >= h->n) return fail(-22, "bond %lld references atom out of range", (long long)b);
-        if (add(i, j) || add(j, i)) return fail(-22, "more than 4 bonded partners for one atom is not supported");
-    }
+    // several boxes: the bond list names atoms of ONE box (every box has the same topology) and is applied to each of them
+    for (int box = 0; box < h->n_boxes; ++box)
+        for (int64_t b = 0; b < n_bonds; ++b) {
+            int i = bonds[2 * b], j = bonds[2 * b + 1];
+            if (i < 0 || j < 0 || i >= h->n_per_box || j >= h->n_per_box)
+                return fail(-22, "bond %lld references atom out of range", (long long)b);
+            i += box * h->n_per_box; j += box * h->n_per_box;
+            if (add(i, j) || add(j, i)) return fail(-22, "more than 4 bonded partners for one atom is not supported");
+        }
     if (h->bond_nbr.ensure(sizeof(int) * tab.size(), false)) return fail(-12, "bond table allocation failed");
     HIP_TRY(hipMemcpy(h->bond_nbr.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
     h->has_bonds = n_bonds > 0;
@@ -1001,7 +1075,7 @@ int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t
     DeviceGuard guard(h->dev);
     hipStream_t st = (hipStream_t)stream;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        if ((r = set_box(h, box))) return r;
+        if ((r = set_box(h, box, st))) return r;
         h->cur_counters = h->counters.as<int>();
         NbrArgs na = nbr_args(h, pos_dev, species_dev);
         h->cand_valid = false;                                    // the exact build below reorders the atoms
@@ -1024,7 +1098,7 @@ int32_t gamd_forces_async(gamd_handle* h, const float* pos_dev, const uint8_t* s
     if (!pos_dev || !box) return fail(-22, "null argument");
     if ((r = check_model_inputs(h, species_dev))) return r;
     DeviceGuard guard(h->dev);
-    if ((r = set_box(h, box))) return r;
+    if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     h->pending.active = false;
     return enqueue_forward(h, pos_dev, species_dev, out_norm_dev, out_denorm_dev, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
@@ -1100,10 +1174,11 @@ int32_t gamd_forces_edges(gamd_handle* h, const float* pos_dev, const uint8_t* s
     if ((r = check_model_inputs(h, species_dev))) return r;
     if (n_edges > 0x7fff0000ll) return fail(-22, "edge list too long");
     DeviceGuard guard(h->dev);
-    if ((r = set_box(h, box))) return r;
+    if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     h->pending.active = false;
     int status = 0;
-    const long long total = n_edges + (h->cfg.self_loop_mode ? h->n : 0);     // + one appended loop per atom
+    // + one appended loop per atom, + at most 15 padding slots per box of a batch (neighbor.hip: d_box_align)
+    const long long total = n_edges + (h->cfg.self_loop_mode ? h->n : 0) + (h->n_boxes > 1 ? 16ll * h->n_boxes : 0);
     if (total > h->e_cap) {                         // the count is known up front: grow before launching
         if ((r = alloc_edges(h, total + total / 8 + 1024))) return r;
         status = 1;
@@ -1175,7 +1250,7 @@ int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, co
     if (n_steps < 0 || n_steps > 0x3fffffff) return fail(-22, "n_steps out of range");
     if ((r = check_model_inputs(h, species_dev))) return r;
     DeviceGuard guard(h->dev);
-    if ((r = set_box(h, box))) return r;
+    if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     hipStream_t st = (hipStream_t)stream;
     MdArgs m{};
     m.n = h->n; m.x = x_dev; m.v = v_dev; m.f = f_dev;
@@ -1193,6 +1268,7 @@ int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, co
         return r;
     if (m.use_rigid && (r = check_rigid_layout(h, species_dev, st))) return r;
     for (int d = 0; d < 3; ++d) m.box[d] = box[d];
+    m.bx = box_ref(h);
     m.seed = p->seed;
     m.devflags = h->devflags.as<int>();
     MdPending& pd = h->pending;
@@ -1216,7 +1292,7 @@ int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev
     const double* ys = p->num_yoshidasuzuki == 1 ? YS1 : p->num_yoshidasuzuki == 3 ? YS3 : p->num_yoshidasuzuki == 5 ? YS5 : nullptr;
     if (!ys) return fail(-22, "Invalid Yoshida-Suzuki value. Allowed values are: 1,3,5");
     DeviceGuard guard(h->dev);
-    if ((r = set_box(h, box))) return r;
+    if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     hipStream_t st = (hipStream_t)stream;
     NhcArgs a{};
     a.n = h->n; a.x = x_dev; a.v = v_dev; a.f = f_dev;
@@ -1229,19 +1305,22 @@ int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev
         return r;
     if (a.use_rigid && (r = check_rigid_layout(h, species_dev, st))) return r;
     for (int d = 0; d < 3; ++d) a.box[d] = box[d];
+    a.bx = box_ref(h);
     a.kT = 0.00831446261815324 * (double)p->temperature_k;
     a.freq = p->frequency_per_ps;
     a.ndf = p->ndf;
     a.M = p->chain_length; a.n_c = p->num_mts; a.n_ys = p->num_yoshidasuzuki;
     for (int i = 0; i < a.n_ys; ++i) a.w[i] = ys[i];
     a.state = chain_state_dev;
-    a.n_blocks = std::min(256, (3 * h->n + 255) / 256);
-    if (h->ke_partial.ensure(sizeof(double) * 256, true)) return fail(-12, "allocation failed");
+    a.n_blocks = std::min(256, (3 * h->n_per_box + 255) / 256);       // per box
+    if (h->ke_partial.ensure(sizeof(double) * 256 * (size_t)h->n_boxes, true)) return fail(-12, "allocation failed");
     a.partial = h->ke_partial.as<double>();
     a.devflags = h->devflags.as<int>();
     if (p->reset) {
-        std::vector<double> init(3 * a.M + 2, 0.0);
-        for (int i = 0; i < a.M; ++i) init[2 * a.M + i] = -a.freq * a.freq;      // G_i = -frequency^2 (:255)
+        const size_t stride = 3 * (size_t)a.M + 2;
+        std::vector<double> init(stride * (size_t)h->n_boxes, 0.0);
+        for (int b = 0; b < h->n_boxes; ++b)
+            for (int i = 0; i < a.M; ++i) init[stride * b + 2 * a.M + i] = -a.freq * a.freq;      // G_i = -frequency^2 (:255)
         HIP_TRY(hipMemcpyAsync(chain_state_dev, init.data(), sizeof(double) * init.size(), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
@@ -1259,7 +1338,7 @@ int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* specie
     if (!pos_dev || !box || !names || !ms || !n_out) return fail(-22, "null argument");
     if ((r = check_model_inputs(h, species_dev))) return r;
     DeviceGuard guard(h->dev);
-    if ((r = set_box(h, box))) return r;
+    if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     h->pending.active = false;
     hipStream_t st = (hipStream_t)stream;
     const int max_ev = 64;

@@ -21,9 +21,36 @@ enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, 
 //                      half) of the first integrator kernel that found the flag set, -1 if none did: where to resume
 enum { DEVFLAG_FROZEN = 0, DEVFLAG_FROZEN_AT = 1, DEVFLAG_COUNT = 4 };
 
+// ---- several independent boxes in one set of launches (gamd_config.n_boxes > 1) -----------------------------------------
+// Box b owns atoms [b * n_per_box, (b + 1) * n_per_box) in the caller's order AND in the sorted order (cells are numbered
+// box-major: cell = b * cells_per_box + local cell, and every box holds exactly n_per_box atoms).  boxes[2 b] = (Lx, Ly, Lz, 0),
+// boxes[2 b + 1] = (Lx / 2, Ly / 2, Lz / 2, 0).  n_boxes <= 1: the by-value box of the argument block is used and nothing
+// below is read.  The reference evaluates several graphs per forward through build_graph_batches + dgl.batch
+// (nn_module.py:655-661, :520-527); here they share every launch.
+struct BoxRef {
+    int n_boxes, n_per_box;
+    float inv_npb;             // 1 / n_per_box
+    const float4* boxes;       // device, [n_boxes][2]
+};
+__device__ __forceinline__ int gamd_box_of(const BoxRef& r, int i) {
+    int q = (int)(((float)i + 0.5f) * r.inv_npb);          // off by at most one for i < 2^23 (gamd_create's limit)
+    const int rem = i - q * r.n_per_box;
+    q += rem >= r.n_per_box ? 1 : (rem < 0 ? -1 : 0);
+    return q;
+}
+struct BoxDims { float bx, by, bz, hx, hy, hz; };
+__device__ __forceinline__ BoxDims gamd_box_dims(const BoxRef& r, const float (&box)[3], const float (&half)[3], int box_id) {
+    if (r.n_boxes <= 1) return BoxDims{box[0], box[1], box[2], half[0], half[1], half[2]};
+    const float4 b = r.boxes[2 * box_id], h = r.boxes[2 * box_id + 1];
+    return BoxDims{b.x, b.y, b.z, h.x, h.y, h.z};
+}
+
 // ---- neighbour build --------------------------------------------------------------------------
 struct NbrArgs {
-    int n;                 // atoms
+    int n;                 // atoms (all boxes together)
+    BoxRef bx;             // n_boxes > 1: per-box dimensions; nc / ncell_box are shared by all boxes
+    int ncell_box;         // cells per box (= ncell when there is one box)
+    int* box_shift;        // [n_boxes + 1] scratch of the row scan: padding in front of each box's first CSR row (see d_scan_deg)
     int flavour;           // 0: jax-md path (dr^2 < rc^2, self kept); 1: torch path (|dr| <= rc, no self)
     float box[3], half[3]; // box and 0.5*box in fp32 (nn_module.py:617-621)
     float rc, rc2;
@@ -36,12 +63,12 @@ struct NbrArgs {
     int self_loop;         // 1: append one self edge per atom at the end of its row (gamd_config.self_loop_mode)
     int* devflags;         // [DEVFLAG_COUNT]
     float4* pos_w;         // [n] wrapped, original order
-    float4* pos_s;         // [n] wrapped, sorted order; .w = species
+    float4* pos_s;         // [n + 1] wrapped, sorted order; .w = species; row n stays zero (source of padding edges)
     int* cell_of;          // [n]
     int* cell_cnt;         // [ncell]
     int* cell_fill;        // [ncell]
     int* cell_start;       // [ncell+1]
-    int* perm;             // [n] sorted -> original
+    int* perm;             // [n + 1] sorted -> original; perm[n] = -2 (the zero row that padding edges point at)
     int* inv_perm;         // [n] original -> sorted
     int* deg;              // [n]
     int* row_ptr;          // [n+1]
@@ -96,6 +123,7 @@ struct EncArgs {
     const int* row_ptr;        // CSR rows (self_loop: the last edge of a row is the appended zero-feature loop)
     int self_loop;             // gamd_config.self_loop_mode
     float box[3], half[3];
+    BoxRef bx;                 // n_boxes > 1: the box of an edge is the box of its destination atom
     float length_mean, length_std, gamma;
     int n_feat;                // 44 or 45
     int n_ksteps;              // ceil(n_feat/2)
@@ -110,6 +138,10 @@ struct EncArgs {
     long long e_cap;
     float* feat_dbg;           // optional [e_cap][48] raw features (debug/parity), or null
 };
+// dimensions of the box an edge lives in (the box of its destination atom, sorted index)
+__device__ __forceinline__ BoxDims gamd_edge_box(const EncArgs& a, int dst) {
+    return gamd_box_dims(a.bx, a.box, a.half, a.bx.n_boxes > 1 ? gamd_box_of(a.bx, dst) : 0);
+}
 int launch_edge_encode(const EncArgs& a, int n_blocks, hipStream_t st);
 // small edge counts: one tile per 4-wave workgroup, weights straight from L2, bit-identical to launch_edge_encode
 int launch_edge_encode_small(const EncArgs& a, int n_blocks, hipStream_t st);
@@ -208,6 +240,7 @@ struct MdArgs {
     float dt;                  // ps
     float a, b_len_kT;         // exp(-gamma dt), sqrt(1-a^2)*len*sqrt(kT): O-step sigma = b_len_kT*sqrt(1/m)
     float box[3];
+    BoxRef bx;                 // n_boxes > 1: per-box dimensions; box b draws its noise as a single box with seed + b would
     int use_rigid;             // 1: O,H,H triples are rigid (one thread per molecule)
     RigidWater rigid;
     unsigned long long seed; unsigned long long step;
@@ -228,14 +261,15 @@ struct NhcArgs {
     float len;                 // length units per nm
     float dt;                  // ps
     float box[3];
+    BoxRef bx;                 // n_boxes > 1: one chain per box (state / partial are per box), ndf is per box
     int use_rigid;
     RigidWater rigid;
     double kT, freq, ndf;      // kJ/mol, 1/ps, degrees of freedom
     int M, n_c, n_ys;          // chain length, multi-time-step count, Yoshida-Suzuki order
     double w[5];
-    double* state;             // [3*M + 2]: xi[M], vxi[M], G[M], scale, KE2
-    double* partial;           // [n_blocks] per-block sums of m v^2
-    int n_blocks;
+    double* state;             // [n_boxes][3*M + 2]: xi[M], vxi[M], G[M], scale, KE2
+    double* partial;           // [n_boxes][n_blocks] per-block sums of m v^2
+    int n_blocks;              // blocks per box
     int* devflags;             // as in MdArgs
     int step_index;
 };

@@ -38,10 +38,26 @@ __device__ __forceinline__ float atom_inv_mass(const uint8_t* species, float inv
     return (species && inv_mass_h > 0.f && species[i] == 0) ? inv_mass_h : inv_mass;
 }
 
+// Several boxes in one launch (MdArgs::bx.n_boxes > 1): atom i of the batch is atom i - b n_per_box of box b and draws the
+// noise a single-box run with seed + b draws for it, so a batch reproduces its boxes run one by one.
+struct BoxAtom { int box, local; };
+__device__ __forceinline__ BoxAtom md_box_atom(const BoxRef& r, int i) {
+    if (r.n_boxes <= 1) return BoxAtom{0, i};
+    const int b = gamd_box_of(r, i);
+    return BoxAtom{b, i - b * r.n_per_box};
+}
+__device__ __forceinline__ void md_box(const BoxRef& r, const float (&box)[3], int b, float (&out)[3]) {
+    if (r.n_boxes <= 1) { out[0] = box[0]; out[1] = box[1]; out[2] = box[2]; return; }
+    const float4 v = r.boxes[2 * b];
+    out[0] = v.x; out[1] = v.y; out[2] = v.z;
+}
+
 // first half of a step for atom i: B A O A, positions re-wrapped (hack_integrator.py:141-165)
 __device__ __forceinline__ void d_baoab_first_atom(const MdArgs& a, int i) {
-    float xi[3];
-    atom_noise(a.seed, a.step, i, xi);
+    float xi[3], box[3];
+    const BoxAtom ba = md_box_atom(a.bx, i);
+    md_box(a.bx, a.box, ba.box, box);
+    atom_noise(a.seed + (unsigned long long)ba.box, a.step, ba.local, xi);
     const float w = atom_inv_mass(a.species, a.inv_mass, a.inv_mass_h, i);
     const float hdt = 0.5f * a.dt, kick = hdt * a.len * w, bs = a.b_len_kT * sqrtf(w);
 #pragma unroll
@@ -52,7 +68,7 @@ __device__ __forceinline__ void d_baoab_first_atom(const MdArgs& a, int i) {
         v = a.a * v + bs * xi[d];            // O
         x += hdt * v;                        // A
         a.v[3 * i + d] = v;
-        a.x[3 * i + d] = gamd_remainder(x, a.box[d]);
+        a.x[3 * i + d] = gamd_remainder(x, box[d]);
     }
 }
 
@@ -150,6 +166,9 @@ __device__ __forceinline__ void d_baoab_first_mol(const MdArgs& a, int m) {
     load_mol(a.x, m, x); load_mol(a.v, m, v); load_mol(a.f, m, f);
     const float w[3] = {1.0f / a.rigid.m_o, 1.0f / a.rigid.m_h, 1.0f / a.rigid.m_h};
     const float hdt = 0.5f * a.dt;
+    const BoxAtom ba = md_box_atom(a.bx, 3 * m);            // n_per_box is a multiple of 3: a molecule lies in one box
+    float box[3];
+    md_box(a.bx, a.box, ba.box, box);
 #pragma unroll
     for (int k = 0; k < 3; ++k) v[k] = v[k] + ((hdt * a.len * w[k]) * f[k]);          // B  :145
     settle_velocities(x, v, a.rigid);                                                     //    :146
@@ -166,14 +185,14 @@ __device__ __forceinline__ void d_baoab_first_mol(const MdArgs& a, int m) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {                                                 // O  :157
                 float xi[3];
-                atom_noise(a.seed, a.step, 3 * m + k, xi);
+                atom_noise(a.seed + (unsigned long long)ba.box, a.step, ba.local + k, xi);
                 const float bs = a.b_len_kT * sqrtf(w[k]);
                 v[k] = (a.a * v[k]) + Vec3{bs * xi[0], bs * xi[1], bs * xi[2]};
             }
             settle_velocities(x, v, a.rigid);                                             //    :158
         }
     }
-    wrap_mol(x, a.box);
+    wrap_mol(x, box);
     store_mol(a.x, m, x); store_mol(a.v, m, v);
 }
 

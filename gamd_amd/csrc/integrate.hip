@@ -60,14 +60,19 @@ __global__ void k_baoab_second_rigid(MdArgs a) {
 // ---- Nose-Hoover chain -------------------------------------------------------------------------
 // sum of m v^2 (kJ/mol: v converted to nm/ps) per block, optionally after the half kick of the second half
 // (and, for rigid water, the velocity constraint that follows it: hack_integrator.py:427-428)
+// Several boxes (a.bx.n_boxes > 1): blockIdx.y is the box; every box has its own chain, kinetic energy and velocity scale.
+__device__ __forceinline__ int nhc_npb(const NhcArgs& a) { return a.bx.n_boxes > 1 ? a.bx.n_per_box : a.n; }
+__device__ __forceinline__ int nhc_state_stride(const NhcArgs& a) { return 3 * a.M + 2; }
+
 template <bool KICK>
 __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
     GAMD_MD_GATE(KICK ? 1 : 0);
     __shared__ double red[4];
     double s = 0.0;
     const double inv_len = 1.0 / (double)a.len;
+    const int npb = nhc_npb(a), a0 = blockIdx.y * npb, a1 = a0 + npb;        // this box's atoms [a0, a1)
     if (a.use_rigid) {
-        for (int m = blockIdx.x * blockDim.x + threadIdx.x; 3 * m < a.n; m += gridDim.x * blockDim.x) {
+        for (int m = a0 / 3 + blockIdx.x * blockDim.x + threadIdx.x; 3 * m < a1; m += gridDim.x * blockDim.x) {
             Vec3 v[3];
             load_mol(a.v, m, v);
             const float ms[3] = {a.rigid.m_o, a.rigid.m_h, a.rigid.m_h};
@@ -86,7 +91,7 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
             }
         }
     } else {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * a.n; i += gridDim.x * blockDim.x) {
+        for (int i = 3 * a0 + blockIdx.x * blockDim.x + threadIdx.x; i < 3 * a1; i += gridDim.x * blockDim.x) {
             const float w = atom_inv_mass(a.species, 1.0f / a.mass, a.mass_h > 0.f ? 1.0f / a.mass_h : 0.f, i / 3);
             float v = a.v[i];
             if (KICK) { v += 0.5f * a.dt * a.len * w * a.f[i]; a.v[i] = v; }   // hack_integrator.py:427 v+0.5*dt*gnn_force/m
@@ -98,19 +103,21 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) a.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) a.partial[blockIdx.y * a.n_blocks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // propagateNHC (hack_integrator.py:289-316), in double like OpenMM's global variables
 __global__ void k_nhc_chain(NhcArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int box = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per box (one box: thread 0)
+    if (box >= (a.bx.n_boxes > 1 ? a.bx.n_boxes : 1)) return;
     if (a.devflags[DEVFLAG_FROZEN]) return;                 // k_nhc_ke2 in front of it has recorded the position
     double KE2 = 0.0;
-    for (int b = 0; b < a.n_blocks; ++b) KE2 += a.partial[b];
+    for (int b = 0; b < a.n_blocks; ++b) KE2 += a.partial[box * a.n_blocks + b];
     const int M = a.M;
-    double* xi = a.state;
-    double* vxi = a.state + M;
-    double* G = a.state + 2 * M;
+    double* st = a.state + (size_t)box * nhc_state_stride(a);
+    double* xi = st;
+    double* vxi = st + M;
+    double* G = st + 2 * M;
     const double Q = a.kT / (a.freq * a.freq), Q0 = a.ndf * Q;
     double scale = 1.0;
     G[0] = (KE2 - a.ndf * a.kT) / Q0;
@@ -133,8 +140,8 @@ __global__ void k_nhc_chain(NhcArgs a) {
             }
             vxi[M - 1] += 0.25 * wdt * G[M - 1];
         }
-    a.state[3 * M] = scale;
-    a.state[3 * M + 1] = KE2;
+    st[3 * M] = scale;
+    st[3 * M + 1] = KE2;
 }
 
 // first half tail: v = scale*v; v += dt/2 f_last/m; x += dt v   (hack_integrator.py:274-280)
@@ -142,14 +149,17 @@ __global__ void k_nhc_apply_first(NhcArgs a) {
     GAMD_MD_GATE(0);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const float scale = (float)a.state[3 * a.M];
+    const BoxAtom ba = md_box_atom(a.bx, i);
+    float box[3];
+    md_box(a.bx, a.box, ba.box, box);
+    const float scale = (float)a.state[(size_t)ba.box * nhc_state_stride(a) + 3 * a.M];
     const float kick = 0.5f * a.dt * a.len * atom_inv_mass(a.species, 1.0f / a.mass, a.mass_h > 0.f ? 1.0f / a.mass_h : 0.f, i);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         float v = a.v[3 * i + d] * scale;
         v += kick * a.f[3 * i + d];
         a.v[3 * i + d] = v;
-        a.x[3 * i + d] = gamd_remainder(a.x[3 * i + d] + a.dt * v, a.box[d]);
+        a.x[3 * i + d] = gamd_remainder(a.x[3 * i + d] + a.dt * v, box[d]);
     }
 }
 
@@ -160,7 +170,10 @@ __global__ void k_nhc_apply_first_rigid(NhcArgs a) {
     if (3 * m >= a.n) return;
     Vec3 x[3], v[3], f[3], x1[3], xc[3];
     load_mol(a.x, m, x); load_mol(a.v, m, v); load_mol(a.f, m, f);
-    const float scale = (float)a.state[3 * a.M];
+    const BoxAtom ba = md_box_atom(a.bx, 3 * m);
+    float box[3];
+    md_box(a.bx, a.box, ba.box, box);
+    const float scale = (float)a.state[(size_t)ba.box * nhc_state_stride(a) + 3 * a.M];
     const float w[3] = {1.0f / a.rigid.m_o, 1.0f / a.rigid.m_h, 1.0f / a.rigid.m_h};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -171,7 +184,7 @@ __global__ void k_nhc_apply_first_rigid(NhcArgs a) {
     settle_positions(x, xc, a.rigid);
 #pragma unroll
     for (int k = 0; k < 3; ++k) v[k] = v[k] + ((1.0f / a.dt) * (xc[k] - x1[k]));
-    wrap_mol(xc, a.box);
+    wrap_mol(xc, box);
     store_mol(a.x, m, xc); store_mol(a.v, m, v);
 }
 
@@ -179,14 +192,15 @@ __global__ void k_nhc_apply_second(NhcArgs a) {
     GAMD_MD_GATE(1);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * a.n) return;
-    a.v[i] *= (float)a.state[3 * a.M];
+    a.v[i] *= (float)a.state[(size_t)md_box_atom(a.bx, i / 3).box * nhc_state_stride(a) + 3 * a.M];
 }
 
 }  // namespace
 
 int launch_nhc_first(const NhcArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_nhc_ke2<false>, dim3(a.n_blocks), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_nhc_chain, dim3(1), dim3(64), 0, st, a); GAMD_CHECK_LAUNCH();
+    const int nb = a.bx.n_boxes > 1 ? a.bx.n_boxes : 1;
+    hipLaunchKernelGGL(k_nhc_ke2<false>, dim3(a.n_blocks, nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_nhc_chain, dim3((nb + 63) / 64), dim3(64), 0, st, a); GAMD_CHECK_LAUNCH();
     if (a.use_rigid) hipLaunchKernelGGL(k_nhc_apply_first_rigid, dim3((a.n / 3 + 255) / 256), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_nhc_apply_first, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
     GAMD_CHECK_LAUNCH();
@@ -194,8 +208,9 @@ int launch_nhc_first(const NhcArgs& a, hipStream_t st) {
 }
 
 int launch_nhc_second(const NhcArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_nhc_ke2<true>, dim3(a.n_blocks), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_nhc_chain, dim3(1), dim3(64), 0, st, a); GAMD_CHECK_LAUNCH();
+    const int nb = a.bx.n_boxes > 1 ? a.bx.n_boxes : 1;
+    hipLaunchKernelGGL(k_nhc_ke2<true>, dim3(a.n_blocks, nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_nhc_chain, dim3((nb + 63) / 64), dim3(64), 0, st, a); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_nhc_apply_second, dim3((3 * a.n + 255) / 256), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
     return 0;
 }

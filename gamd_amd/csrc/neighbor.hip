@@ -30,16 +30,23 @@ __device__ __forceinline__ float node_feature(const NbrArgs& a, int v) {
     return a.feat ? a.feat[v] : (a.species ? (float)a.species[v] : 0.f);
 }
 
+// box of atom i (caller's order or sorted order: box b owns [b n_per_box, (b + 1) n_per_box) in both) and its dimensions
+__device__ __forceinline__ int box_id(const NbrArgs& a, int i) { return a.bx.n_boxes > 1 ? gamd_box_of(a.bx, i) : 0; }
+__device__ __forceinline__ BoxDims box_dims(const NbrArgs& a, int b) { return gamd_box_dims(a.bx, a.box, a.half, b); }
+
 __device__ __forceinline__ void d_bin(const NbrArgs& a, int i) {
+    const int bi = box_id(a, i);
+    const BoxDims B = box_dims(a, bi);
     float4 p;
-    p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);    // graph_utils.py:31 jnp.mod(pos, box)
-    p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
-    p.z = gamd_remainder(a.pos[3 * i + 2], a.box[2]);
+    p.x = gamd_remainder(a.pos[3 * i + 0], B.bx);    // graph_utils.py:31 jnp.mod(pos, box)
+    p.y = gamd_remainder(a.pos[3 * i + 1], B.by);
+    p.z = gamd_remainder(a.pos[3 * i + 2], B.bz);
     p.w = 0.f;
     a.pos_w[i] = p;
     if (a.ref_pos) a.ref_pos[i] = p;
-    const int c = (cell_coord(p.x, a.box[0], a.nc[0]) * a.nc[1] + cell_coord(p.y, a.box[1], a.nc[1])) * a.nc[2] +
-                  cell_coord(p.z, a.box[2], a.nc[2]);
+    // cells are numbered box-major: atoms of different boxes never share a cell, so they are never neighbours
+    const int c = bi * a.ncell_box + (cell_coord(p.x, B.bx, a.nc[0]) * a.nc[1] + cell_coord(p.y, B.by, a.nc[1])) * a.nc[2] +
+                  cell_coord(p.z, B.bz, a.nc[2]);
     a.cell_of[i] = c;
     atomicAdd(&a.cell_cnt[c], 1);
 }
@@ -158,9 +165,12 @@ __global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
 template <typename V>
 __device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit) {
     const float4 pc = a.pos_s[ctr];
-    const int cx = cell_coord(pc.x, a.box[0], a.nc[0]);
-    const int cy = cell_coord(pc.y, a.box[1], a.nc[1]);
-    const int cz = cell_coord(pc.z, a.box[2], a.nc[2]);
+    const int bi = box_id(a, ctr);
+    const BoxDims B = box_dims(a, bi);
+    const int cbase = bi * a.ncell_box;
+    const int cx = cell_coord(pc.x, B.bx, a.nc[0]);
+    const int cy = cell_coord(pc.y, B.by, a.nc[1]);
+    const int cz = cell_coord(pc.z, B.bz, a.nc[2]);
     // axes with fewer than 3 cells: visit every cell of that axis exactly once
     const int lx = a.nc[0] >= 3 ? -1 : -cx, hx = a.nc[0] >= 3 ? 1 : a.nc[0] - 1 - cx;
     const int ly = a.nc[1] >= 3 ? -1 : -cy, hy = a.nc[1] >= 3 ? 1 : a.nc[1] - 1 - cy;
@@ -171,7 +181,7 @@ __device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit)
             int y = cy + dy; y += y < 0 ? a.nc[1] : 0; y -= y >= a.nc[1] ? a.nc[1] : 0;
             for (int dz = lz; dz <= hz; ++dz) {
                 int z = cz + dz; z += z < 0 ? a.nc[2] : 0; z -= z >= a.nc[2] ? a.nc[2] : 0;
-                const int c = (x * a.nc[1] + y) * a.nc[2] + z;
+                const int c = cbase + (x * a.nc[1] + y) * a.nc[2] + z;
                 const int s = a.cell_start[c], e = a.cell_start[c + 1];
                 for (int b0 = s; b0 < e; b0 += 32) {
                     const int b = b0 + l;
@@ -179,9 +189,9 @@ __device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit)
                     if (b < e) {
                         const float4 pb = a.pos_s[b];
                         // rel = pos[neigh] - pos[centre], min image (nn_module.py:615-621)
-                        const float rx = gamd_min_image_wrapped(pb.x - pc.x, a.box[0], a.half[0]);
-                        const float ry = gamd_min_image_wrapped(pb.y - pc.y, a.box[1], a.half[1]);
-                        const float rz = gamd_min_image_wrapped(pb.z - pc.z, a.box[2], a.half[2]);
+                        const float rx = gamd_min_image_wrapped(pb.x - pc.x, B.bx, B.hx);
+                        const float ry = gamd_min_image_wrapped(pb.y - pc.y, B.by, B.hy);
+                        const float rz = gamd_min_image_wrapped(pb.z - pc.z, B.bz, B.hz);
                         const float d2 = (rx * rx + ry * ry) + rz * rz;
                         if (a.flavour == 0) ok = d2 < a.rc2;                      // graph_utils.py:59, self kept
                         else ok = (sqrtf(d2) <= a.rc) && (b != ctr);              // md_module.py:111
@@ -211,6 +221,28 @@ __device__ __forceinline__ void d_count(const NbrArgs& a, int ctr, int l) {
 __global__ void __launch_bounds__(256) k_count(NbrArgs a) {
     GAMD_GATE();
     d_count(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31);
+}
+
+// Several boxes (gamd_config.n_boxes > 1): on entry row_ptr = exscan(deg) over all atoms.  Every box's first row is moved to
+// the next 16-edge chunk boundary by giving the LAST atom of the box in front of it pad_b = (-E_b) mod 16 extra slots (deg is
+// updated; the fill pass points them at the all-zero row).  The partial-sum pieces of an atom are cut at chunk boundaries, so
+// with aligned starts box b's rows are cut exactly where a single-box evaluation cuts them: the forces of a batch are
+// bit-identical to the boxes evaluated one by one.  Whole 1024-thread workgroup; at most 15 slots per box.
+__device__ void d_box_align(const NbrArgs& a) {
+    const int nb = a.bx.n_boxes, npb = a.bx.n_per_box;
+    block_exclusive_scan(nb, [&](int b) {
+        const int T = a.row_ptr[(b + 1) * npb] - a.row_ptr[b * npb];
+        return b + 1 < nb ? ((-T) & (GAMD_CHUNK - 1)) : 0;
+    }, a.box_shift);
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n; i += 1024) {
+        const int b = gamd_box_of(a.bx, i);
+        const int sh = a.box_shift[b];
+        if (sh) a.row_ptr[i] += sh;
+        if (i == (b + 1) * npb - 1) a.deg[i] += a.box_shift[b + 1] - sh;
+    }
+    if (threadIdx.x == 0) a.row_ptr[a.n] += a.box_shift[nb];
+    __syncthreads();
 }
 
 // row_ptr = exscan(deg); NA = inclusive count of non-empty segments that start off a chunk boundary;
@@ -246,11 +278,22 @@ __device__ void d_scan_deg_fast(const NbrArgs& a) {
     for (int w = 0; w < 16; ++w) { const int t = s_tot[0][w]; if (w < wv) run += t; E_all += t; }
     int f[IPT], rp[IPT], mine2 = 0;
 #pragma unroll
+    for (int k = 0; k < IPT; ++k) { rp[k] = run; run += v[k]; }
+    if (a.cand_pass == 0 && a.bx.n_boxes > 1) {
+        // publish the plain offsets, align the boxes' first rows in global memory (d_box_align), take the result back
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) if (i0 + k < a.n) a.row_ptr[i0 + k] = rp[k];
+        if (tid == 0) a.row_ptr[a.n] = E_all;
+        __syncthreads();
+        d_box_align(a);
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) if (i0 + k < a.n) { rp[k] = a.row_ptr[i0 + k]; v[k] = a.deg[i0 + k]; }
+        E_all = a.row_ptr[a.n];
+    }
+#pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        rp[k] = run;
         f[k] = (a.cand_pass == 0 && i0 + k < a.n && v[k] > 0 && (rp[k] % GAMD_CHUNK) != 0) ? 1 : 0;
         mine2 += f[k];
-        run += v[k];
     }
     if (i0 + IPT <= a.n) {
 #pragma unroll
@@ -303,6 +346,7 @@ __device__ void d_scan_deg(const NbrArgs& a) {
     if (a.n <= 16 * 1024) { d_scan_deg_fast(a); return; }
     block_exclusive_scan(a.n, [&](int i) { return a.deg[i]; }, a.row_ptr);
     __syncthreads();
+    if (!a.cand_pass && a.bx.n_boxes > 1) d_box_align(a);
     if (a.cand_pass) {                                     // candidate CSR: only its size and overflow matter
         if (threadIdx.x == 0) {
             const int nc = a.row_ptr[a.n];
@@ -332,6 +376,18 @@ __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
     d_scan_deg(a);
 }
 
+// Several boxes: the scan (d_box_align) has made every box's first CSR row start on a 16-edge chunk boundary by lengthening
+// the row of the box's LAST atom; the half-wave that fills that row writes the extra slots behind its real edges: source =
+// the all-zero row n of the node tables (message exactly 0), destination = the atom itself.
+__device__ __forceinline__ void d_fill_padding(const NbrArgs& a, int c, int l, long long w_end) {
+    if (a.bx.n_boxes <= 1) return;
+    const int b = gamd_box_of(a.bx, c);
+    if (c != (b + 1) * a.bx.n_per_box - 1 || b + 1 >= a.bx.n_boxes) return;
+    long long end = a.row_ptr[c + 1];
+    if (end > a.e_cap) end = a.e_cap;
+    for (long long x = w_end + l; x < end; x += 32) { a.col[x] = a.n; if (a.erow) a.erow[x] = c; }
+}
+
 __device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l) {
     const bool live = ctr < a.n;
     const int c = live ? ctr : a.n - 1;
@@ -346,6 +402,7 @@ __device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l) {
     });
     // self_loop_mode 1: the loop DGL's in-place add_self_loop would append (nn_module.py:650-652), last in the row
     if (a.self_loop && live && l == 0 && w < a.e_cap) { a.col[w] = c; if (a.erow) a.erow[w] = c; }
+    if (live && !a.cand_pass) d_fill_padding(a, c, l, w + (a.self_loop ? 1 : 0));
 }
 
 __global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
@@ -388,18 +445,19 @@ __global__ void k_chunk_meta(NbrArgs a) {
 // candidate list was built (or the host forces it).  jax-md does the same test in update_neighbor_lst
 // (graph_utils.py:36-44) with dr_threshold = cutoff/6.
 __device__ __forceinline__ bool d_skin_check(const NbrArgs& a, int i) {
+    const BoxDims B = box_dims(a, box_id(a, i));
     float4 p;
-    p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);
-    p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
-    p.z = gamd_remainder(a.pos[3 * i + 2], a.box[2]);
+    p.x = gamd_remainder(a.pos[3 * i + 0], B.bx);
+    p.y = gamd_remainder(a.pos[3 * i + 1], B.by);
+    p.z = gamd_remainder(a.pos[3 * i + 2], B.bz);
     p.w = 0.f;
     a.pos_w[i] = p;
     bool moved = a.force_rebuild != 0;
     if (!moved) {
         const float4 r = a.ref_pos[i];
-        const float dx = gamd_min_image_wrapped(p.x - r.x, a.box[0], a.half[0]);
-        const float dy = gamd_min_image_wrapped(p.y - r.y, a.box[1], a.half[1]);
-        const float dz = gamd_min_image_wrapped(p.z - r.z, a.box[2], a.half[2]);
+        const float dx = gamd_min_image_wrapped(p.x - r.x, B.bx, B.hx);
+        const float dy = gamd_min_image_wrapped(p.y - r.y, B.by, B.hy);
+        const float dz = gamd_min_image_wrapped(p.z - r.z, B.bz, B.hz);
         moved = !(((dx * dx + dy * dy) + dz * dz) <= a.skin_half2);      // NaN positions force a rebuild too
     }
     // current position in the (so far frozen) sorted order; a rebuild later in this call overwrites pos_s and the order
@@ -503,6 +561,7 @@ __device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPt
     const bool live = ctr < a.n;
     const int c = live ? ctr : a.n - 1;
     const float4 pc = a.pos_s[c];
+    const BoxDims B = box_dims(a, box_id(a, c));
     long long s, e;
     if (a.cand_stride > 0) {
         const int dgc = a.cand_deg[c];
@@ -521,9 +580,9 @@ __device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPt
         if (b0 + l < e) {
             b = a.cand_col[b0 + l];
             const float4 pb = a.pos_s[b];
-            const float rx = gamd_min_image_wrapped(pb.x - pc.x, a.box[0], a.half[0]);
-            const float ry = gamd_min_image_wrapped(pb.y - pc.y, a.box[1], a.half[1]);
-            const float rz = gamd_min_image_wrapped(pb.z - pc.z, a.box[2], a.half[2]);
+            const float rx = gamd_min_image_wrapped(pb.x - pc.x, B.bx, B.hx);
+            const float ry = gamd_min_image_wrapped(pb.y - pc.y, B.by, B.hy);
+            const float rz = gamd_min_image_wrapped(pb.z - pc.z, B.bz, B.hz);
             const float d2 = (rx * rx + ry * ry) + rz * rz;
             if (a.flavour == 0) ok = d2 < a.rc2;
             else ok = (sqrtf(d2) <= a.rc) && (b != c);
@@ -540,6 +599,7 @@ __device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPt
         }
     }
     if (FILL && a.self_loop && live && l == 0 && w < a.e_cap) { a.col[w] = c; a.erow[w] = c; }
+    if (FILL && live) d_fill_padding(a, c, l, w + (a.self_loop ? 1 : 0));
     if (!FILL && live && l == 0) a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
 }
 
@@ -729,10 +789,11 @@ __global__ void __launch_bounds__(256) k_filter_fill_small(NbrArgs a) {
 __global__ void k_identity_sort(NbrArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
+    const BoxDims B = box_dims(a, box_id(a, i));
     float4 p;
-    p.x = gamd_remainder(a.pos[3 * i + 0], a.box[0]);
-    p.y = gamd_remainder(a.pos[3 * i + 1], a.box[1]);
-    p.z = gamd_remainder(a.pos[3 * i + 2], a.box[2]);
+    p.x = gamd_remainder(a.pos[3 * i + 0], B.bx);
+    p.y = gamd_remainder(a.pos[3 * i + 1], B.by);
+    p.z = gamd_remainder(a.pos[3 * i + 2], B.bz);
     p.w = node_feature(a, i);
     a.pos_w[i] = p;
     a.pos_s[i] = p;
@@ -770,11 +831,16 @@ __global__ void __launch_bounds__(256) k_edges_sort_rows(NbrArgs a, const int* _
     const long long s = a.row_ptr[row];
     long long e = a.row_ptr[row + 1];
     if (e > a.e_cap) e = a.e_cap;
-    int cnt = (int)(e - s);
-    if (a.self_loop && cnt > 0) {                             // last slot of the row: the appended loop
-        --cnt;
-        if (lane == 0) { a.col[s + cnt] = row; a.erow[s + cnt] = row; }
+    const int total = (int)(e - s);
+    // row layout: [the caller's edges][the appended loop (self_loop_mode 1)][padding slots (last atom of a box, n_boxes > 1)]
+    int cnt = a.cell_of[row];                                 // edges k_edges_fill placed in this row
+    if (cnt > total) cnt = total;
+    int behind = cnt;
+    if (a.self_loop && behind < total) {
+        if (lane == 0) { a.col[s + behind] = row; a.erow[s + behind] = row; }
+        ++behind;
     }
+    for (int x = behind + lane; x < total; x += 64) { a.col[s + x] = a.n; a.erow[s + x] = row; }
     if (cnt <= 0) return;
     if (cnt <= 64) {
         const int v = lane < cnt ? tmp_eid[s + lane] : 0x7fffffff;
@@ -819,7 +885,7 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
 int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     hipError_t e;
     const int tb = 256, gb = (a.n + tb - 1) / tb, ga = (a.n + 7) / 8;
-    if (a.counters_next && a.n <= 1024) {
+    if (a.counters_next && a.n <= 1024 && a.bx.n_boxes <= 1) {
         // small system (n <= 1024): 3 launches and no memset node instead of 13 + 1 (+ 2 integrator launches): counters
         // ping-pong, cell arrays cleared inside the rebuild, integrator halves folded in
         MdArgs md{};

@@ -77,9 +77,10 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
         const bool valid = active && x < E;
         const int src = valid ? a.col[x] : 0, dst = valid ? a.erow[x] : 0;
         const float4 ps = a.pos_s[src], pd = a.pos_s[dst];
-        const float rx = gamd_min_image_wrapped(ps.x - pd.x, a.box[0], a.half[0]);
-        const float ry = gamd_min_image_wrapped(ps.y - pd.y, a.box[1], a.half[1]);
-        const float rz = gamd_min_image_wrapped(ps.z - pd.z, a.box[2], a.half[2]);
+        const BoxDims B = gamd_edge_box(a, dst);
+        const float rx = gamd_min_image_wrapped(ps.x - pd.x, B.bx, B.hx);
+        const float ry = gamd_min_image_wrapped(ps.y - pd.y, B.by, B.hy);
+        const float rz = gamd_min_image_wrapped(ps.z - pd.z, B.bz, B.hz);
         const float nrm = sqrtf((rx * rx + ry * ry) + rz * rz);
         const float den = nrm + 1e-8f;
         const float d = (nrm - a.length_mean) / a.length_std;

@@ -36,12 +36,31 @@ def _box3(box) -> np.ndarray:
     return b.astype(np.float32)
 
 
+def _boxes(box, n_boxes: int) -> np.ndarray:
+    """scalar | [3] (every box the same) | [n_boxes] of scalars or [3]s -> float32 [n_boxes, 3]."""
+    b = np.asarray(box, dtype=np.float64)
+    if b.ndim == 0 or b.size == 1 or (b.ndim == 1 and b.size == 3 and n_boxes != 3):
+        return np.tile(_box3(b), (n_boxes, 1))
+    if b.ndim == 1 and b.size == n_boxes:
+        return np.repeat(b.astype(np.float32)[:, None], 3, axis=1)
+    if b.ndim == 2 and b.shape == (n_boxes, 3):
+        return b.astype(np.float32)
+    if b.ndim == 1 and b.size == 3:              # n_boxes == 3 and three numbers: one box for all (use [n_boxes, 3] to differ)
+        return np.tile(_box3(b), (n_boxes, 1))
+    raise ValueError(f"box must be a scalar, 3 values, or one of those per box ({n_boxes} boxes)")
+
+
 class GamdForce:
     """One GPU-resident force model for a fixed atom count.
 
     Parameters mirror build_model()/ParticleNetLightning.__init__ of the reference:
     ``state_dict`` (reference key names), ``box``/``cutoff`` (BOX_SIZE / CUTOFF_RADIUS
     module constants there), ``bond`` (create_water_bond) and the scaler (mean, var).
+
+    ``n_boxes`` > 1: that many INDEPENDENT boxes of ``n_atoms`` atoms each share every launch (the reference's
+    several-graphs-per-forward, nn_module.py:655-661,676-679; a replica ensemble on one GPU).  Positions / species /
+    forces are then [n_boxes * n_atoms, ...] (or [n_boxes, n_atoms, ...]), box-major; ``box`` may differ per box
+    ([n_boxes, 3]); ``bond`` names atoms of one box.  Results are bit-identical to the boxes evaluated one by one.
     """
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], n_atoms: int, box, cutoff: float,
@@ -49,7 +68,7 @@ class GamdForce:
                  nbr_flavour: str = "jaxmd", device: int = 0, keep_stages: bool = False,
                  edge_capacity: int = 0, cfg: Optional[ModelConfig] = None, edge_dtype: str = "f32",
                  neighbor_skin: float = 0.0, self_loop_mode: str = "dgl07_noop", kernel_select: int = 0,
-                 small_tile_limit: int = 0):
+                 small_tile_limit: int = 0, n_boxes: int = 1):
         self._h = C.c_void_p()
         self._lib = _lib.load()
         if not torch.cuda.is_available():
@@ -64,11 +83,14 @@ class GamdForce:
                              f"n_rbf={cfg.n_rbf})")
         validate_state_dict(state_dict, cfg)
         self.cfg = cfg
-        self.n = int(n_atoms)
+        self.n = int(n_atoms)                          # atoms per box
+        self.n_boxes = max(1, int(n_boxes))
+        self.n_total = self.n * self.n_boxes
         self.device = torch.device("cuda", device)
-        self.box = _box3(box)
+        self.box = _box3(box)                          # constructor box (every box starts with it)
         self.cutoff = float(cutoff)
         c = GamdConfig()
+        c.n_boxes = self.n_boxes
         c.n_atoms, c.kind, c.n_layers = self.n, KIND[cfg.kind], cfg.conv_layer
         c.use_bond, c.nbr_flavour, c.device = int(cfg.use_bond), FLAVOUR[nbr_flavour], device
         c.cutoff = self.cutoff
@@ -99,8 +121,8 @@ class GamdForce:
             b = np.ascontiguousarray(np.asarray(bond, dtype=np.int32))
             check(self._lib.gamd_set_bonds(self._h, b.ctypes.data_as(C.c_void_p), b.shape[0]), "gamd_set_bonds")
         self._feat = None
-        self._out = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
-        self._out_den = torch.empty((self.n, 3), dtype=torch.float32, device=self.device)
+        self._out = torch.empty((self.n_total, 3), dtype=torch.float32, device=self.device)
+        self._out_den = torch.empty((self.n_total, 3), dtype=torch.float32, device=self.device)
         self.last_status = 0
 
     # -- lifetime -----------------------------------------------------------------------------
@@ -131,9 +153,18 @@ class GamdForce:
         if isinstance(pos, np.ndarray):
             pos = torch.from_numpy(np.ascontiguousarray(pos, dtype=np.float32))
         pos = pos.to(device=self.device, dtype=torch.float32).contiguous()
-        if tuple(pos.shape) != (self.n, 3):
-            raise ValueError(f"pos must be [{self.n}, 3], got {tuple(pos.shape)}")
+        if tuple(pos.shape) == (self.n_boxes, self.n, 3):
+            pos = pos.view(self.n_total, 3)
+        if tuple(pos.shape) != (self.n_total, 3):
+            raise ValueError(f"pos must be [{self.n_total}, 3]" + (f" or [{self.n_boxes}, {self.n}, 3]" if self.n_boxes > 1 else "")
+                             + f", got {tuple(pos.shape)}")
         return pos
+
+    def _md_state(self, *ts):
+        for t in ts:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                    and tuple(t.shape) in ((self.n_total, 3), (self.n_boxes, self.n, 3))):
+                raise ValueError(f"x, v, f must be contiguous float32 CUDA tensors of shape [{self.n_total}, 3]")
 
     def _dev_species(self, species) -> Optional[torch.Tensor]:
         """species / node feature [N] or [N,1] -> uint8 O=1/H=0 flags on the device (what the integrators pick masses
@@ -145,7 +176,9 @@ class GamdForce:
         if isinstance(species, np.ndarray):
             species = torch.from_numpy(species)
         s = species.reshape(-1).to(device=self.device)
-        if s.numel() != self.n:
+        if s.numel() == self.n and self.n_boxes > 1:
+            s = s.repeat(self.n_boxes)                    # one box's species, the same for every box
+        if s.numel() != self.n_total:
             raise ValueError("species must have one entry per atom")
         self._set_features(s.to(torch.float32).contiguous() if s.dtype.is_floating_point and self.cfg.kind != "lj" else None)
         return (s != 0).to(torch.uint8).contiguous()
@@ -158,8 +191,8 @@ class GamdForce:
               "gamd_set_node_features")
 
     def _box_arg(self, box):
-        b = self.box if box is None else _box3(box)
-        return (C.c_float * 3)(*[float(x) for x in b])
+        b = _boxes(self.box if box is None else box, self.n_boxes)
+        return (C.c_float * (3 * self.n_boxes))(*[float(x) for x in b.reshape(-1)])
 
     # -- the hot path ----------------------------------------------------------------------------
     def forward(self, pos: ArrayLike, box=None, species=None, denormalize: bool = False,
@@ -228,18 +261,24 @@ class GamdForce:
         return out
 
     def debug_perm(self) -> np.ndarray:
-        return self._dbg(0, (self.n,), np.int32)
+        return self._dbg(0, (self.n_total,), np.int32)
 
     def debug_csr(self) -> Tuple[np.ndarray, np.ndarray]:
         e = self.counts()[0]
-        return self._dbg(1, (self.n + 1,), np.int32), self._dbg(2, (e,), np.int32)
+        return self._dbg(1, (self.n_total + 1,), np.int32), self._dbg(2, (e,), np.int32)
 
     def debug_edges(self) -> np.ndarray:
-        """[2,E] (centre, neighbour) in ORIGINAL atom ids, CSR order."""
+        """[2,E] (centre, neighbour) in ORIGINAL atom ids (box-major over all boxes), CSR order.  The padding slots that
+        align the boxes of a batch (source index n_total) are not edges and are left out."""
         perm = self.debug_perm().astype(np.int64)
         row_ptr, col = self.debug_csr()
-        dst = np.repeat(np.arange(self.n), np.diff(row_ptr))
-        return np.stack([perm[dst], perm[col]])
+        dst = np.repeat(np.arange(self.n_total), np.diff(row_ptr))
+        real = col < self.n_total
+        return np.stack([perm[dst[real]], perm[col[real]]])
+
+    def debug_edge_rows(self) -> np.ndarray:
+        """CSR slots that hold real edges (bool [E]): the rows of debug_e / debug_feat that debug_edges lists."""
+        return self.debug_csr()[1] < self.n_total
 
     def debug_e(self) -> np.ndarray:
         """e [E, edge_embedding_dim] de-fragmented to CSR edge order."""
@@ -281,7 +320,7 @@ class GamdForce:
 
     def debug_h(self, layer: int) -> np.ndarray:
         """residual stream h_layer [N, encoding_size] in ORIGINAL atom order."""
-        hs = self._dbg(16 + layer, (self.n, self.cfg.encoding_size), np.float32)
+        hs = self._dbg(16 + layer, (self.n_total, self.cfg.encoding_size), np.float32)
         out = np.empty_like(hs)
         out[self.debug_perm()] = hs
         return out
@@ -297,8 +336,7 @@ class GamdForce:
         ``rigid_water`` holds every O,H,H triple rigid at (r_oh, r_hh) like OpenMM's constrained water
         (positions must then be whole molecules; they are kept whole).  ``length_per_nm`` is the length
         unit of x/v/box (10 = Angstrom, the default; 18.8972613 = bohr for the DFT model)."""
-        for t in (x, v, f):
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n, 3)
+        self._md_state(x, v, f)
         s = self._dev_species(species)
         p = GamdMdParams(dt_ps, mass_amu, temperature_k, gamma_per_ps, seed, first_step, mass_h_amu, length_per_nm,
                          int(rigid_water), r_oh, r_hh, 0)
@@ -316,16 +354,18 @@ class GamdForce:
                    remove_cm_motion: Optional[bool] = None) -> torch.Tensor:
         """Split Nose-Hoover-chain steps (hack_integrator.py:182-493).  Returns the chain state tensor
         (float64 [3*chain_length+2] on the device); pass it back in to continue a trajectory.
+        Several boxes: one chain per box (state [n_boxes, 3*chain_length+2]), ``ndf`` is per box.
         ``ndf`` defaults to what hack_integrator.py:226-235 computes from the OpenMM System: 3 per particle, minus the
         constraints (three per rigid molecule), minus 3 when the System holds a CMMotionRemover.
         ``remove_cm_motion`` says whether it does: default True with ``rigid_water`` (the water drivers build an
         openmmtools WaterBox, whose System carries one), False otherwise (the LJ drivers' ndf is 3N)."""
-        for t in (x, v, f):
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (self.n, 3)
+        self._md_state(x, v, f)
         reset = chain_state is None
         if reset:
-            chain_state = torch.zeros(3 * chain_length + 2, dtype=torch.float64, device=self.device)
-        assert chain_state.dtype == torch.float64 and chain_state.numel() == 3 * chain_length + 2
+            shape = (3 * chain_length + 2,) if self.n_boxes == 1 else (self.n_boxes, 3 * chain_length + 2)
+            chain_state = torch.zeros(shape, dtype=torch.float64, device=self.device)
+        assert chain_state.dtype == torch.float64 and chain_state.is_contiguous() \
+            and chain_state.numel() == self.n_boxes * (3 * chain_length + 2)
         s = self._dev_species(species)
         if remove_cm_motion is None:
             remove_cm_motion = bool(rigid_water)

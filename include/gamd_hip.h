@@ -14,7 +14,8 @@
  *     buffers overflowed and were regrown (the analogue of jax-md's
  *     did_buffer_overflow -> re-allocate, graph_utils.py:41-42), < 0 = error
  *     (text via gamd_last_error).  No exceptions cross the ABI.
- *   - one handle per GPU, not thread-safe (the reference is single-threaded too).
+ *   - one handle per GPU (holding one box, or gamd_config.n_boxes independent boxes), not thread-safe (the reference
+ *     is single-threaded too).
  *   - atoms keep the CALLER's order at the boundary; internally they are renumbered
  *     in cell order every call.
  */
@@ -78,6 +79,18 @@ typedef struct gamd_config {
                                 of wide.hip */
     int32_t small_tile_limit;/* fp32 path: edge counts of at most this many 32-edge tiles run the latency-oriented conv kernel
                                 (one tile per 4-wave workgroup, bit-identical results).  0 = default (512), -1 = never */
+    int32_t n_boxes;         /* 0 or 1: one box (default).  B > 1: B INDEPENDENT boxes of n_atoms atoms each, evaluated and
+                                integrated in one set of launches — the reference's several-graphs-per-forward
+                                (build_graph_batches + dgl.batch, nn_module.py:655-661, :520-527, :676-679) and the "more
+                                replicas than GPUs" half of the ensemble.  Every `[n][3]` / `[n]` device array of the entry
+                                points below is then `[B][n][3]` / `[B][n]` (box-major, contiguous), every `box` argument is
+                                HOST float [B][3] (a box per graph, as WaterMDDynamicBoxNet.forward's box_size_lst), bonds name
+                                atoms of one box and apply to each, gamd_md_run's seed means seed + b for box b, and
+                                gamd_md_run_nhc's chain_state_dev is [B][3*chain_length + 2] with ndf per box.  Atoms of
+                                different boxes are never neighbours (the box index is folded into the cell index); results are
+                                bit-identical to the boxes evaluated one by one (each box's CSR rows start on a 16-edge
+                                boundary; gamd_get_counts / GAMD_DBG_COL include those <= 15 padding slots per box, source
+                                index B*n).  A neighbour-buffer overflow in any box regrows the shared buffers. */
 } gamd_config;
 enum { GAMD_SELF_LOOP_DGL07_NOOP = 0, GAMD_SELF_LOOP_APPEND_ZERO_FEATURE = 1 };
 enum { GAMD_KSEL_FORCE_GENERIC_WIDTH = 1 };

@@ -43,7 +43,7 @@ def test_version_and_error_strings(lib):
 
 def test_struct_layout_matches_header():
     from gamd_amd._lib import GamdConfig, GamdMdParams, GamdNhcParams
-    assert ctypes.sizeof(GamdConfig) == 88 and GamdConfig.neighbor_skin.offset == 72 and GamdConfig.edge_capacity.offset == 40 and GamdConfig.edge_dtype.offset == 52
+    assert ctypes.sizeof(GamdConfig) == 96 and GamdConfig.n_boxes.offset == 88 and GamdConfig.neighbor_skin.offset == 72 and GamdConfig.edge_capacity.offset == 40 and GamdConfig.edge_dtype.offset == 52
     assert GamdConfig.self_loop_mode.offset == 76 and GamdConfig.kernel_select.offset == 80 and GamdConfig.small_tile_limit.offset == 84
     assert GamdConfig.encoding_size.offset == 56 and GamdConfig.no_expand_edge.offset == 68
     assert ctypes.sizeof(GamdMdParams) == 56 and GamdMdParams.seed.offset == 16 and GamdMdParams.mass_h_amu.offset == 32

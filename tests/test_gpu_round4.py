@@ -113,10 +113,12 @@ def test_full_size_forces_per_atom_error(name, edge_dtype):
 WIDE = ["lj258_w256_seed9", "tip3p774_w256_seed10"]
 
 
-def _wide_case(name, **kw):
+def _wide_case(name, skin_frac=0.0, **kw):
     g, cfg, sd = load_golden(name)
     assert (cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim) == (256, 128, 256)
     box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+    if skin_frac:
+        kw["neighbor_skin"] = skin_frac * rc
     bond = g["bond"] if "bond" in g else None
     species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
     eng = _engine(sd, n, box, rc, bond=bond, scaler=(g["scaler_mean"], g["scaler_var"]), **kw)
@@ -154,7 +156,7 @@ def test_wide_fixed_box_goldens_stage_by_stage(name):
 def test_wide_fixed_box_skin_reuse_and_md_run(name):
     """Skin mode: the golden forces again, then along a random walk the edge SET equals the exact rebuild's at every step;
     then a short deterministic MD run (T = 0) against the oracle integrator driven by oracle forces."""
-    g, cfg, sd, eng, box, rc, n, bond, species = _wide_case(name, neighbor_skin=rc / 6.0)
+    g, cfg, sd, eng, box, rc, n, bond, species = _wide_case(name, skin_frac=1.0 / 6.0)
     exact = _engine(sd, n, box, rc, bond=bond, scaler=(g["scaler_mean"], g["scaler_var"]))
     posw = np.mod(g["pos"], box)
     assert rel_err(eng.forward(torch.from_numpy(posw).float(), species=species).cpu().numpy(), g["out_norm"]) < TOL
