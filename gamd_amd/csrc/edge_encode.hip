@@ -24,6 +24,10 @@ constexpr int ENC_LDS_FLOATS = ENC_W1_FLOATS + 2 * GAMD_WFRAG_FLOATS + 5 * 128 +
 template <int NFEAT, int ABL, typename CPtr>
 __device__ __forceinline__ void edge_features(const EncArgs& a, CPtr cen, int src, int dst, const float4& ps, const float4& pd,
                                               int half, float (&F)[24]) {
+    // No floating-point contraction in here: which multiply-add pairs hipcc fuses depends on the kernel the function is inlined
+    // into, and k_edge_encode / k_edge_encode_small must produce the same bits (the host switches between them by edge count).
+    // Fused operations are written out (fmaf) where they are meant.
+#pragma clang fp contract(off)
     // nn_module.py:615-624
     const BoxDims B = gamd_edge_box(a, dst);
     const float rx = gamd_min_image_wrapped(ps.x - pd.x, B.bx, B.hx);

@@ -118,6 +118,7 @@ __device__ __forceinline__ float gamd_gelu_hw(float x) {
 // falls back to the table otherwise.
 struct RbfGrid { int uniform; float c0, delta, A, B, C; };
 __device__ __forceinline__ void gamd_rbf_chains(float d, int half, float gexp, const RbfGrid& g, float (&F)[24]) {
+#pragma clang fp contract(off)      // the same bits in every kernel this is inlined into (see edge_features, edge_encode.hip)
     const float s = 2.0f * g.delta;
     const float dh = d - (g.c0 + (half ? g.delta : 0.0f));
 #pragma unroll
