@@ -146,6 +146,7 @@ struct gamd_handle {
 
     float box[3] = {0, 0, 0};
     int nc[3] = {1, 1, 1};
+    int ncell = 1;                  // cells of all boxes together
 
     // live timing of the conv-edge kernel (gamd_timing_*)
     bool timing = false;
@@ -197,29 +198,34 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
     return 0;
 }
 
-// box: host [n_boxes][3].  All boxes share one cell grid nc[] (sized for the smallest box along each axis, so every box's
-// cells are at least cutoff + skin wide); h->box keeps box 0 (the by-value box of the single-box kernels' argument blocks).
+// box: host [n_boxes][3].  Every box gets the cell grid a single-box handle would give it (cells at least cutoff + skin
+// wide), cells numbered box after box; h->box / h->nc keep box 0 (what the single-box kernels' argument blocks carry).
 int set_box(gamd_handle* h, const float* box, hipStream_t st = nullptr) {
     const int nb = h->n_boxes;
     bool changed = h->boxes_host.size() != (size_t)nb * 3;
-    float bmin[3] = {box[0], box[1], box[2]};
     for (int b = 0; b < nb; ++b)
         for (int d = 0; d < 3; ++d) {
             const float v = box[3 * b + d];
             if (!(v > 0.f)) return fail(-22, "box[%d][%d] = %g is not positive", b, d, (double)v);
             if (!changed && h->boxes_host[(size_t)3 * b + d] != v) changed = true;
-            bmin[d] = std::min(bmin[d], v);
         }
-    if (changed) h->cand_valid = false;                           // candidates were built for another box
-    long long ncell = 1;
-    for (int d = 0; d < 3; ++d) {
-        h->box[d] = box[d];
-        int nc = (int)std::floor((double)bmin[d] / (((double)h->cfg.cutoff + (double)h->skin) * 1.0001));
-        h->nc[d] = std::max(1, nc);
-        ncell *= h->nc[d];
+    if (!changed) return 0;
+    h->cand_valid = false;                                        // candidates were built for another box
+    std::vector<int> grid((size_t)nb * 4);
+    long long ncell = 0;
+    for (int b = 0; b < nb; ++b) {
+        long long nc_b = 1;
+        for (int d = 0; d < 3; ++d) {
+            const int nc = std::max(1, (int)std::floor((double)box[3 * b + d] / (((double)h->cfg.cutoff + (double)h->skin) * 1.0001)));
+            grid[(size_t)4 * b + d] = nc;
+            nc_b *= nc;
+        }
+        if (ncell + nc_b > (1ll << 30)) return fail(-22, "cell grid too large");
+        grid[(size_t)4 * b + 3] = (int)ncell;
+        ncell += nc_b;
     }
-    ncell *= nb;
-    if (ncell > (1ll << 30)) return fail(-22, "cell grid too large");
+    for (int d = 0; d < 3; ++d) { h->box[d] = box[d]; h->nc[d] = grid[d]; }
+    h->ncell = (int)ncell;
     if ((int)ncell > h->ncell_cap) {
         int r = 0;
         // counters | cell_cnt | cell_fill in one buffer so the per-call clear is a single memset
@@ -228,17 +234,17 @@ int set_box(gamd_handle* h, const float* box, hipStream_t st = nullptr) {
         if (r) return fail(-12, "cell buffer allocation failed");
         h->ncell_cap = (int)ncell;
     }
-    if (changed) {
-        h->boxes_host.assign(box, box + (size_t)nb * 3);
-        if (nb > 1) {
-            // kernels of earlier calls may still read the old dimensions: drain the stream before overwriting them (a box
-            // change is rare: NPT-style drivers)
-            HIP_TRY(hipStreamSynchronize(st));
-            std::vector<float> img((size_t)nb * 8, 0.f);
-            for (int b = 0; b < nb; ++b)
-                for (int d = 0; d < 3; ++d) { img[(size_t)8 * b + d] = box[3 * b + d]; img[(size_t)8 * b + 4 + d] = 0.5f * box[3 * b + d]; }
-            HIP_TRY(hipMemcpy(h->boxes_dev.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
+    h->boxes_host.assign(box, box + (size_t)nb * 3);
+    if (nb > 1) {
+        // kernels of earlier calls may still read the old dimensions: drain the stream before overwriting them (a box
+        // change is rare: NPT-style drivers)
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<float> img((size_t)nb * 12, 0.f);
+        for (int b = 0; b < nb; ++b) {
+            for (int d = 0; d < 3; ++d) { img[(size_t)12 * b + d] = box[3 * b + d]; img[(size_t)12 * b + 4 + d] = 0.5f * box[3 * b + d]; }
+            memcpy(&img[(size_t)12 * b + 8], &grid[(size_t)4 * b], 4 * sizeof(int));
         }
+        HIP_TRY(hipMemcpy(h->boxes_dev.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -254,8 +260,7 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
     }
     a.rc = h->cfg.cutoff;
     a.rc2 = (float)((double)h->cfg.cutoff * (double)h->cfg.cutoff);   // graph_utils.py:59 cutoff ** 2
-    a.ncell_box = h->nc[0] * h->nc[1] * h->nc[2];
-    a.ncell = a.ncell_box * h->n_boxes;
+    a.ncell = h->ncell;
     a.bx = box_ref(h);
     a.box_shift = h->box_shift.as<int>();
     a.e_cap = h->e_cap;
@@ -735,7 +740,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->cell_of.ensure(sizeof(int) * n, true);
     r |= h->perm.ensure(sizeof(int) * (n + 1), true);
     if (n_boxes > 1) {
-        r |= h->boxes_dev.ensure(sizeof(float) * 8 * (size_t)n_boxes, true);
+        r |= h->boxes_dev.ensure(sizeof(float) * 12 * (size_t)n_boxes, true);
         r |= h->box_shift.ensure(sizeof(int) * ((size_t)n_boxes + 2), true);
     }
     r |= h->inv_perm.ensure(sizeof(int) * n, true);

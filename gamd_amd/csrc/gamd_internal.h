@@ -23,14 +23,15 @@ enum { DEVFLAG_FROZEN = 0, DEVFLAG_FROZEN_AT = 1, DEVFLAG_COUNT = 4 };
 
 // ---- several independent boxes in one set of launches (gamd_config.n_boxes > 1) -----------------------------------------
 // Box b owns atoms [b * n_per_box, (b + 1) * n_per_box) in the caller's order AND in the sorted order (cells are numbered
-// box-major: cell = b * cells_per_box + local cell, and every box holds exactly n_per_box atoms).  boxes[2 b] = (Lx, Ly, Lz, 0),
-// boxes[2 b + 1] = (Lx / 2, Ly / 2, Lz / 2, 0).  n_boxes <= 1: the by-value box of the argument block is used and nothing
-// below is read.  The reference evaluates several graphs per forward through build_graph_batches + dgl.batch
+// box-major: cell = first cell of box b + local cell, and every box holds exactly n_per_box atoms).  boxes[3 b] = (Lx, Ly, Lz, 0),
+// boxes[3 b + 1] = (Lx / 2, Ly / 2, Lz / 2, 0), boxes[3 b + 2] = the bits of int4 (cells along x, y, z, first cell of box b):
+// every box has the cell grid a single-box handle would give it, so its CSR rows come out in the same order.
+// n_boxes <= 1: the by-value box of the argument block is used and nothing below is read.  The reference evaluates several graphs per forward through build_graph_batches + dgl.batch
 // (nn_module.py:655-661, :520-527); here they share every launch.
 struct BoxRef {
     int n_boxes, n_per_box;
     float inv_npb;             // 1 / n_per_box
-    const float4* boxes;       // device, [n_boxes][2]
+    const float4* boxes;       // device, [n_boxes][3]
 };
 __device__ __forceinline__ int gamd_box_of(const BoxRef& r, int i) {
     int q = (int)(((float)i + 0.5f) * r.inv_npb);          // off by at most one for i < 2^23 (gamd_create's limit)
@@ -41,15 +42,14 @@ __device__ __forceinline__ int gamd_box_of(const BoxRef& r, int i) {
 struct BoxDims { float bx, by, bz, hx, hy, hz; };
 __device__ __forceinline__ BoxDims gamd_box_dims(const BoxRef& r, const float (&box)[3], const float (&half)[3], int box_id) {
     if (r.n_boxes <= 1) return BoxDims{box[0], box[1], box[2], half[0], half[1], half[2]};
-    const float4 b = r.boxes[2 * box_id], h = r.boxes[2 * box_id + 1];
+    const float4 b = r.boxes[3 * box_id], h = r.boxes[3 * box_id + 1];
     return BoxDims{b.x, b.y, b.z, h.x, h.y, h.z};
 }
 
 // ---- neighbour build --------------------------------------------------------------------------
 struct NbrArgs {
     int n;                 // atoms (all boxes together)
-    BoxRef bx;             // n_boxes > 1: per-box dimensions; nc / ncell_box are shared by all boxes
-    int ncell_box;         // cells per box (= ncell when there is one box)
+    BoxRef bx;             // n_boxes > 1: per-box dimensions and cell grids (nc[] below is then unused)
     int* box_shift;        // [n_boxes + 1] scratch of the row scan: padding in front of each box's first CSR row (see d_scan_deg)
     int flavour;           // 0: jax-md path (dr^2 < rc^2, self kept); 1: torch path (|dr| <= rc, no self)
     float box[3], half[3]; // box and 0.5*box in fp32 (nn_module.py:617-621)

@@ -48,7 +48,7 @@ __device__ __forceinline__ BoxAtom md_box_atom(const BoxRef& r, int i) {
 }
 __device__ __forceinline__ void md_box(const BoxRef& r, const float (&box)[3], int b, float (&out)[3]) {
     if (r.n_boxes <= 1) { out[0] = box[0]; out[1] = box[1]; out[2] = box[2]; return; }
-    const float4 v = r.boxes[2 * b];
+    const float4 v = r.boxes[3 * b];
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
 }
 

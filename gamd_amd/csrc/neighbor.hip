@@ -33,6 +33,13 @@ __device__ __forceinline__ float node_feature(const NbrArgs& a, int v) {
 // box of atom i (caller's order or sorted order: box b owns [b n_per_box, (b + 1) n_per_box) in both) and its dimensions
 __device__ __forceinline__ int box_id(const NbrArgs& a, int i) { return a.bx.n_boxes > 1 ? gamd_box_of(a.bx, i) : 0; }
 __device__ __forceinline__ BoxDims box_dims(const NbrArgs& a, int b) { return gamd_box_dims(a.bx, a.box, a.half, b); }
+// cell grid of box b: cells along x, y, z and the index of its first cell
+struct BoxCells { int nx, ny, nz, base; };
+__device__ __forceinline__ BoxCells box_cells(const NbrArgs& a, int b) {
+    if (a.bx.n_boxes <= 1) return BoxCells{a.nc[0], a.nc[1], a.nc[2], 0};
+    const int4 c = reinterpret_cast<const int4*>(a.bx.boxes)[3 * b + 2];
+    return BoxCells{c.x, c.y, c.z, c.w};
+}
 
 __device__ __forceinline__ void d_bin(const NbrArgs& a, int i) {
     const int bi = box_id(a, i);
@@ -45,8 +52,8 @@ __device__ __forceinline__ void d_bin(const NbrArgs& a, int i) {
     a.pos_w[i] = p;
     if (a.ref_pos) a.ref_pos[i] = p;
     // cells are numbered box-major: atoms of different boxes never share a cell, so they are never neighbours
-    const int c = bi * a.ncell_box + (cell_coord(p.x, B.bx, a.nc[0]) * a.nc[1] + cell_coord(p.y, B.by, a.nc[1])) * a.nc[2] +
-                  cell_coord(p.z, B.bz, a.nc[2]);
+    const BoxCells G = box_cells(a, bi);
+    const int c = G.base + (cell_coord(p.x, B.bx, G.nx) * G.ny + cell_coord(p.y, B.by, G.ny)) * G.nz + cell_coord(p.z, B.bz, G.nz);
     a.cell_of[i] = c;
     atomicAdd(&a.cell_cnt[c], 1);
 }
@@ -167,21 +174,21 @@ __device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit)
     const float4 pc = a.pos_s[ctr];
     const int bi = box_id(a, ctr);
     const BoxDims B = box_dims(a, bi);
-    const int cbase = bi * a.ncell_box;
-    const int cx = cell_coord(pc.x, B.bx, a.nc[0]);
-    const int cy = cell_coord(pc.y, B.by, a.nc[1]);
-    const int cz = cell_coord(pc.z, B.bz, a.nc[2]);
+    const BoxCells G = box_cells(a, bi);
+    const int cx = cell_coord(pc.x, B.bx, G.nx);
+    const int cy = cell_coord(pc.y, B.by, G.ny);
+    const int cz = cell_coord(pc.z, B.bz, G.nz);
     // axes with fewer than 3 cells: visit every cell of that axis exactly once
-    const int lx = a.nc[0] >= 3 ? -1 : -cx, hx = a.nc[0] >= 3 ? 1 : a.nc[0] - 1 - cx;
-    const int ly = a.nc[1] >= 3 ? -1 : -cy, hy = a.nc[1] >= 3 ? 1 : a.nc[1] - 1 - cy;
-    const int lz = a.nc[2] >= 3 ? -1 : -cz, hz = a.nc[2] >= 3 ? 1 : a.nc[2] - 1 - cz;
+    const int lx = G.nx >= 3 ? -1 : -cx, hx = G.nx >= 3 ? 1 : G.nx - 1 - cx;
+    const int ly = G.ny >= 3 ? -1 : -cy, hy = G.ny >= 3 ? 1 : G.ny - 1 - cy;
+    const int lz = G.nz >= 3 ? -1 : -cz, hz = G.nz >= 3 ? 1 : G.nz - 1 - cz;
     for (int dx = lx; dx <= hx; ++dx) {
-        int x = cx + dx; x += x < 0 ? a.nc[0] : 0; x -= x >= a.nc[0] ? a.nc[0] : 0;
+        int x = cx + dx; x += x < 0 ? G.nx : 0; x -= x >= G.nx ? G.nx : 0;
         for (int dy = ly; dy <= hy; ++dy) {
-            int y = cy + dy; y += y < 0 ? a.nc[1] : 0; y -= y >= a.nc[1] ? a.nc[1] : 0;
+            int y = cy + dy; y += y < 0 ? G.ny : 0; y -= y >= G.ny ? G.ny : 0;
             for (int dz = lz; dz <= hz; ++dz) {
-                int z = cz + dz; z += z < 0 ? a.nc[2] : 0; z -= z >= a.nc[2] ? a.nc[2] : 0;
-                const int c = cbase + (x * a.nc[1] + y) * a.nc[2] + z;
+                int z = cz + dz; z += z < 0 ? G.nz : 0; z -= z >= G.nz ? G.nz : 0;
+                const int c = G.base + (x * G.ny + y) * G.nz + z;
                 const int s = a.cell_start[c], e = a.cell_start[c + 1];
                 for (int b0 = s; b0 < e; b0 += 32) {
                     const int b = b0 + l;

@@ -163,7 +163,7 @@ def test_wide_fixed_box_skin_reuse_and_md_run(name):
     rng = np.random.default_rng(2)
     x = posw.copy()
     for step in range(12):
-        x = x + rng.normal(0, 0.12, x.shape)
+        x = x + rng.normal(0, 0.04, x.shape)
         a = eng.forward(torch.from_numpy(x).float(), species=species).cpu().numpy()
         b = exact.forward(torch.from_numpy(x).float(), species=species).cpu().numpy()
         assert np.array_equal(edge_set(eng.debug_edges()), edge_set(exact.debug_edges())), step
