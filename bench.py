@@ -37,6 +37,10 @@ FLOP_PER_EDGE_CONV = 8 * 128 * 128          # 4 GEMMs 128x128 per edge per conv-
 PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E spec peak
 CPU_SAMPLE_ATOMS = 2000
+C1_BATCH_BOXES = 38                         # 38 x 258 = 9 804 atoms: a C2-sized set of launches
+# SURVEY.md 8d algorithmic FLOPs of one force evaluation (F = 44, L = 4, H = 128), src/dst Linears on node rows
+FLOP_PER_EDGE_STEP = 2 * (44 * 128 + 2 * 128 * 128) + 4 * (8 * 128 * 128 + 4 * 128)      # 603 136
+FLOP_PER_NODE_STEP = 4 * (10 * 128 * 128) + 2 * (128 * 128 + 3 * 128)                    # 688 896
 # the files whose contents decide k_conv_edge's memory traffic: profiles/pmc_conv_edge.json is stamped with their hash
 PMC_SOURCES = ("gamd_amd/csrc/conv_edge.hip", "gamd_amd/csrc/gamd_common.h", "gamd_amd/csrc/gamd_internal.h",
                "gamd_amd/csrc/neighbor.hip")
@@ -57,9 +61,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short C1/C3/C5 runs and the per-kernel replays")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c5", "c5b", "dft"],
-                    help="c2 (default, the headline metric): 10k-atom LJ fp32; c1: 258-atom LJ box (the reference's own "
-                         "driver size); c3: 4 170-atom TIP3P fp32; c5: TIP4P-Ew-sized box of 2 000 molecules = 6 000 network "
+    ap.add_argument("--workload", default="c2", choices=["c1", "c1_batch", "c2", "c3", "c5", "c5b", "dft"],
+                    help="c2 (default, the headline metric): 10k-atom LJ fp32; c1: the reference's own 258-atom LJ snapshot "
+                         "(code/LJ/init_pos.npy); c1_batch: 38 such boxes in one set of launches (gamd_config.n_boxes); c3: 4 170-atom TIP3P fp32; c5: TIP4P-Ew-sized box of 2 000 molecules = 6 000 network "
                          "atoms, bf16 edge-MLP; c5b: the other reading of BASELINE config 5, 2 667 molecules = 8 001 network "
                          "atoms; dft: the 774-atom DFT-water configuration (256/256/128 x 5 layers, bohr, cutoff 9.5)")
     ap.add_argument("--skin", type=float, default=1.0 / 6.0,
@@ -145,7 +149,7 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
     w = Workload()
     w.name, w.species, w.mass, w.dtype_name = name, None, 39.9, "f32"
     w.md_extra, w.flop_per_edge, w.kernel_name = {}, FLOP_PER_EDGE_CONV, "k_conv_edge"
-    w.dt_ps, w.uses_skin = 0.0005, False
+    w.dt_ps, w.uses_skin, w.n_boxes = 0.0005, False, 1
     if name == "dft":
         # water/test_script/test_nosehoover_hb.py:64-113: 258 molecules, (20 A)^3 box and positions in bohr, cutoff 9.5
         from gamd_amd.compat import HARTREE_PER_BOHR_TO_KJ_PER_MOL_NM as CONV
@@ -165,21 +169,35 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         w.label = ("DFT-water configuration: 258 rigid molecules = 774 atoms, positions/box in bohr (L = 37.8), cutoff 9.5, "
                    "WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, fp32, random-init weights (seed 5), SETTLE on "
                    "device, 1 box per GPU")
-    elif name in ("c2", "c1"):
+    elif name in ("c2", "c1", "c1_batch"):
         n = N_ATOMS if name == "c2" else 258
         w.cutoff = 3.0 * wk.LJ_SIGMA if name == "c2" else 7.5       # C1: CUTOFF_RADIUS of LJ/train_network_lj.py:26-29
-        pos, box = wk.lj_box(n, seed=ens.box_seed(1234, ctx))
+        w.n_boxes = C1_BATCH_BOXES if name == "c1_batch" else 1
+        if name == "c2":
+            pos, box = wk.lj_box(n, seed=ens.box_seed(1234, ctx))
+        else:
+            # C1 = the reference's code/LJ/init_pos.npy verbatim (committed as the `pos` array of the golden
+            # fixture oracle/make_golden.py wrote from it), BOX_SIZE 27.27.  c1_batch: box 0 is the snapshot, the others are
+            # the snapshot plus N(0, 0.05 sigma) jitter (different microstates of the same system)
+            snap = np.load(os.path.join(ROOT, "tests", "golden", "lj258_seed0.npz"))["pos"].astype(np.float64)
+            box = 27.27
+            rng = np.random.default_rng(ens.box_seed(4321, ctx))
+            pos = np.concatenate([np.mod(snap + (rng.normal(0.0, 0.05 * wk.LJ_SIGMA, snap.shape) if b else 0.0), box)
+                                  for b in range(w.n_boxes)])
         w.sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
         w.eng = GamdForce(w.sd, n, box, w.cutoff, scaler=SHIPPED_SCALERS["lj"], device=dev,
-                          neighbor_skin=skin * w.cutoff, edge_dtype=edge_dtype)
+                          neighbor_skin=skin * w.cutoff, edge_dtype=edge_dtype, n_boxes=w.n_boxes)
         w.uses_skin = skin > 0
         if edge_dtype == "f16x3":
             w.dtype_name, w.kernel_name = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)", "k_conv_edge_f16x3"
         w.dt_ps = 0.002
         w.label = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
                    "random-init weights (seed 0), 1 box per GPU") if name == "c2" else \
-                  ("C1-sized: 258-atom LJ box, rho*=0.5, L=27.27 A, cutoff 7.5 A (the reference's LJ driver system, "
-                   "lattice + jitter positions), fp32, random-init weights (seed 0)")
+                  ("C1: the reference's 258-atom LJ snapshot (code/LJ/init_pos.npy), L=27.27 A, cutoff 7.5 A, fp32, "
+                   "random-init weights (seed 0)") if name == "c1" else \
+                  (f"C1 x {w.n_boxes}: {w.n_boxes} independent 258-atom LJ boxes (the reference's snapshot + per-box jitter) "
+                   "evaluated and integrated in one set of launches (gamd_config.n_boxes), L=27.27 A, cutoff 7.5 A, fp32, "
+                   "random-init weights (seed 0)")
     else:
         nmol, dens, scal, seed0 = {"c3": (1390, 258.0, "tip3p", 2345), "c5": (2000, 251.0, "tip4p", 3456),
                                    "c5b": (2667, 251.0, "tip4p", 3456)}[name]
@@ -199,7 +217,7 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         w.label = (f"{name.upper()}: {nmol} rigid water molecules (SETTLE on device) = {pos.shape[0]} network atoms, cutoff 4.2 A, "
                    f"bond feature, {'bf16 edge-MLP operands / fp32 accumulate' if w.dtype_name == 'bf16' else 'fp32'}, "
                    "random-init weights (seed 3), 1 box per GPU")
-    w.n_atoms, w.box, w.pos = pos.shape[0], box, pos
+    w.n_atoms, w.box, w.pos = pos.shape[0], box, pos            # n_atoms: all boxes of this rank together
     w.x = torch.from_numpy(pos).float().cuda(dev)
     w.v = torch.from_numpy(wk.maxwell_boltzmann(w.n_atoms, mass_amu=w.mass, seed=99 + ctx.rank)).float().cuda(dev)
     if name == "dft":
@@ -288,6 +306,11 @@ def cpu_baseline(w, dev):
         out = orc.forward(w.sd, xw, edges, w.box)
         times.append(time.perf_counter() - t0)
     err = float(np.abs(gpu - out.numpy()).max() / np.abs(out.numpy()).max())
+    # per-atom statistic next to the max-norm figure: |df_i| / |f_i| over the atoms whose force exceeds 1e-3 of the largest
+    ref64 = out.numpy().astype(np.float64)
+    nrm = np.linalg.norm(ref64, axis=1)
+    keep = nrm > 1e-3 * nrm.max()
+    rel_i = np.linalg.norm(gpu.astype(np.float64) - ref64, axis=1)[keep] / nrm[keep]
     sec = min(times)
     return {"value": w.n_atoms / sec, "unit": "atom-steps/s", "cores": best_thr, "kind": "port",
             "sample": f"force evaluation of the timed run's own {w.n_atoms}-atom LJ box (positions after the timed steps, "
@@ -295,6 +318,9 @@ def cpu_baseline(w, dev):
                       f"(best) with {best_thr} torch threads on a {ncpu}-thread host (os.cpu_count()); neighbour search "
                       "and integrator excluded",
             "seconds_per_eval": sec, "seconds_all": times, "host_threads": ncpu, "gpu_vs_cpu_rel_err": err,
+            "gpu_vs_cpu_per_atom": {"median": float(np.median(rel_i)), "p99": float(np.percentile(rel_i, 99)),
+                                    "max": float(rel_i.max()), "atoms": int(keep.sum()),
+                                    "definition": "|f_gpu_i - f_cpu_i| / |f_cpu_i| over atoms with |f_cpu_i| > 1e-3 max|f_cpu|"},
             "sample_2000": {"value": CPU_SAMPLE_ATOMS / best_s, "seconds_per_eval": best_s, "edges": int(edges_s.shape[1]),
                             "gpu_vs_cpu_rel_err": err_s, "same_edge_count": bool(same_edges_s),
                             "note": "2 000-atom box of the same density, cutoff and weights: thread-count scan "
@@ -416,6 +442,11 @@ def main():
                               "post-ops (3 x 64 SiLU, S add, message / segment sum per 32-edge tile) cost 5-7 %, weight copies 1 %, "
                               "accumulator initialisation 0.8 %; gathers, barrier skew and LDS latency nothing")
         # SURVEY.md §8d "neighbour gather" figure: L2-served rows, so this is not HBM traffic; stated with its bound
+        # the whole MD step against the fp32 matrix peak: SURVEY.md 8d algorithmic FLOPs of one force evaluation
+        step_flop = FLOP_PER_EDGE_STEP * float(n_edges) + FLOP_PER_NODE_STEP * float(w.n_atoms)
+        rl["whole_step_frac"] = step_flop / (line["ms_per_step"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+        rl["whole_step_note"] = ("(603 136 E + 688 896 N) FLOP per step / ms_per_step / fp32 matrix peak: neighbour stage, "
+                                 "encoder, 4 conv layers, node kernels, decoder and integrator together")
         n_layers = 4
         gather_bytes = n_layers * (n_edges * 1028.0 + w.n_atoms * 1024.0)
         gather_s = rl["avg_launch_ms"] * 1e-3 * n_layers
@@ -458,13 +489,16 @@ def main():
     if single and not args.no_secondary and args.workload == "c2":
         sec = {}
         w.eng.close()
-        for name in ("c1", "c3", "c5", "c5b"):
-            s = build_workload(name, ctx, dev, args.skin, "f32")
+        # (entry, workload, edge dtype): the other single-GPU BASELINE configs, the batched C1, the opt-in split-fp16 run of
+        # C2 and the DFT-water configuration, 20 timed steps each
+        for name, wname, dt_name in (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c3", "c3", "f32"), ("c5", "c5", "f32"),
+                                     ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("dft", "dft", "f32")):
+            s = build_workload(wname, ctx, dev, args.skin if wname != "dft" else 0.0, dt_name)
             sdt, _, sconv_ms, sconv_n = timed_run(s, 20, 5, ctx, dev, ddev)
             se = s.eng.counts()[0]
             ok = bool(torch.isfinite(s.x).all().item() and torch.isfinite(s.f).all().item())
             rb = roofline_block(s, se, sconv_ms, sconv_n)
-            sec[name] = {"workload": s.label, "n_atoms": s.n_atoms, "edges_per_step": se, "dtype": s.dtype_name,
+            sec[name] = {"workload": s.label, "n_atoms": s.n_atoms, "n_boxes": s.n_boxes, "edges_per_step": se, "dtype": s.dtype_name,
                          "steps": 20, "warmup": 5, "ms_per_step": sdt / 20 * 1e3, "value": s.n_atoms * 20 / sdt,
                          "unit": "atom-steps/s", "finite": ok,
                          "conv_kernel": {k: rb[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}

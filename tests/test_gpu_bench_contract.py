@@ -167,13 +167,18 @@ def test_secondary_block_kernels_list_and_cpu_baseline_on_c2():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and "10000-atom" in cb["sample"] and cb["cores"] >= 1 and cb["host_threads"] >= cb["cores"]
     assert cb["gpu_vs_cpu_rel_err"] < 1e-5 and cb["sample_2000"]["same_edge_count"] is True
+    assert cb["gpu_vs_cpu_per_atom"]["p99"] < 1e-5 and cb["gpu_vs_cpu_per_atom"]["atoms"] > 9000
+    assert 0.5 < d["roofline"]["whole_step_frac"] < 1.0
     assert d["value"] / cb["value"] > 10.0                                # north star: >= 10x the CPU path
     names = [k["kernel"] for k in d["roofline"]["kernels"]]
     assert names[0] == "k_edge_encode" and any(n.startswith("k_node") for n in names) and any("neighbour" in n for n in names)
     enc = d["roofline"]["kernels"][0]
     assert enc["bound"] == "mfma" and 0.3 < enc["frac"] < 1.0 and abs(enc["frac"] - enc["achieved"] / 157.3) < 1e-9
     s = d["secondary"]
-    assert set(s) == {"c1", "c3", "c5", "c5b"}
+    assert set(s) == {"c1", "c1_batch", "c3", "c5", "c5b", "c2_f16x3", "dft"}
+    assert s["c1_batch"]["n_boxes"] == 38 and s["c1_batch"]["n_atoms"] == 38 * 258 and s["c1_batch"]["value"] > 1.5 * s["c1"]["value"]
+    assert s["c2_f16x3"]["dtype"].startswith("f16x3") and s["c2_f16x3"]["n_atoms"] == 10000 and s["dft"]["n_atoms"] == 774
+    assert s["c1"]["edges_per_step"] > 6000                      # the reference snapshot (6 114 edges at the start)
     assert s["c1"]["n_atoms"] == 258 and s["c3"]["n_atoms"] == 4170 and s["c5"]["n_atoms"] == 6000 and s["c5b"]["n_atoms"] == 8001
     assert s["c5"]["dtype"] == "bf16" and s["c5"]["conv_kernel"]["bound"] == "hbm" and s["c3"]["dtype"] == "f32"
     for v in s.values():
