@@ -26,7 +26,7 @@ class GamdConfig(C.Structure):
 
 # common tail of both integrator parameter blocks (masses per species, length unit, rigid water)
 _MD_EXT = [("mass_h_amu", C.c_float), ("length_per_nm", C.c_float), ("rigid_water", C.c_int32),
-           ("r_oh", C.c_float), ("r_hh", C.c_float), ("reserved", C.c_int32)]
+           ("r_oh", C.c_float), ("r_hh", C.c_float), ("remove_cm_motion", C.c_int32)]
 
 
 class GamdNhcParams(C.Structure):

@@ -124,7 +124,7 @@ struct gamd_handle {
     // edges
     long long e_cap = 0;
     DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg;
-    DevBuf counters, tdbg, tmp_eid, ke_partial;
+    DevBuf counters, tdbg, tmp_eid, ke_partial, com_partial;
     DevBuf cnt2;                    // small systems in skin mode: two counter blocks used alternately (no per-call memset)
     int cnt_parity = 0;
     long long skin_calls = 0;       // skin-mode force evaluations so far (rebuild-frequency estimate)
@@ -167,6 +167,17 @@ BoxRef box_ref(const gamd_handle* h) {
     r.inv_npb = 1.0f / (float)h->n_per_box;
     r.boxes = h->n_boxes > 1 ? h->boxes_dev.as<float4>() : nullptr;
     return r;
+}
+
+// centre-of-mass motion removal (MdCom): per-box, per-block momentum sums
+int fill_com(gamd_handle* h, int enabled, MdCom* c) {
+    c->enabled = enabled ? 1 : 0;
+    c->blocks = std::max(1, std::min(16, (h->n_per_box + 1023) / 1024));
+    c->partial = nullptr;
+    if (!c->enabled) return 0;
+    if (h->com_partial.ensure(sizeof(double) * 4 * (size_t)c->blocks * (size_t)h->n_boxes, true)) return fail(-12, "allocation failed");
+    c->partial = h->com_partial.as<double>();
+    return 0;
 }
 
 int alloc_candidates(gamd_handle* h, long long cap) {
@@ -645,7 +656,22 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
         for (long long s = s_begin; s < p.n_steps; ++s) {
             p.m.step = p.first_step + (unsigned long long)s;
             p.m.step_index = (int)s;
-            const MdFuse fuse{&p.m, s > s_begin ? 1 : 0, (skip_first && s == s_begin) ? 0 : 1};
+            int do_second = s > s_begin ? 1 : 0;
+            const int do_first = (skip_first && s == s_begin) ? 0 : 1;
+            if (p.m.com.enabled) {
+                // COM motion removal sits between the B of step s-1 and the first half of step s and needs a sum over all
+                // atoms: the B is launched on its own, then the momentum sums; only the first half rides in the neighbour kernel
+                if (do_second) {
+                    MdArgs prev = p.m;
+                    prev.step_index = (int)(s - 1);
+                    if ((r = launch_baoab_second(prev, p.st))) return fail(-1, "integrator launch failed (%d)", r);
+                    do_second = 0;
+                }
+                if (do_first && (r = launch_com_partial(p.m.com, p.m.v, p.m.species, p.m.inv_mass, p.m.inv_mass_h, p.m.n, p.m.bx,
+                                                        p.m.devflags, p.st)))
+                    return fail(-1, "integrator launch failed (%d)", r);
+            }
+            const MdFuse fuse{&p.m, do_second, do_first};
             if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, &fuse,
                                      s + 1 == p.n_steps)))
                 return r;
@@ -813,7 +839,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     DevBuf* bufs[] = {&h->boxes_dev, &h->box_shift, &h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
-                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial,
+                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial, &h->com_partial,
                       &h->ref_pos, &h->cand_deg, &h->cand_ptr, &h->cand_col};
     for (DevBuf* b : bufs) b->release();
     if (h->counters_host) (void)hipHostFree(h->counters_host);
@@ -1274,6 +1300,7 @@ int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, co
     if (m.use_rigid && (r = check_rigid_layout(h, species_dev, st))) return r;
     for (int d = 0; d < 3; ++d) m.box[d] = box[d];
     m.bx = box_ref(h);
+    if ((r = fill_com(h, p->remove_cm_motion, &m.com))) return r;
     m.seed = p->seed;
     m.devflags = h->devflags.as<int>();
     MdPending& pd = h->pending;
@@ -1311,6 +1338,7 @@ int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev
     if (a.use_rigid && (r = check_rigid_layout(h, species_dev, st))) return r;
     for (int d = 0; d < 3; ++d) a.box[d] = box[d];
     a.bx = box_ref(h);
+    if ((r = fill_com(h, p->remove_cm_motion, &a.com))) return r;
     a.kT = 0.00831446261815324 * (double)p->temperature_k;
     a.freq = p->frequency_per_ps;
     a.ndf = p->ndf;

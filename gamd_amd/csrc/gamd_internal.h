@@ -230,6 +230,15 @@ int launch_node_wide(const NodeArgs& a, int ht, hipStream_t st);
 // rigid 3-site water (atoms O,H,H): masses and the SETTLE canonical triangle (Miyamoto & Kollman 1992):
 // rc = d_HH/2, ra = distance O - centre of mass, rb = distance centre of mass - HH midpoint
 struct RigidWater { float m_o, m_h, ra, rb, rc; };
+// OpenMM's CMMotionRemover, which the first-half integrators run through addUpdateContextState() at the top of every step
+// (hack_integrator.py:142, :272) when the System carries one (the water drivers' openmmtools WaterBox does; :226-235 takes 3
+// degrees of freedom off for it): v_i -= sum_j m_j v_j / sum_j m_j, per box.  k_com_partial leaves per-block sums
+// (sum m vx, sum m vy, sum m vz, sum m) in `partial`; every first-half thread adds up the `blocks` rows of its box in order.
+struct MdCom {
+    int enabled;
+    int blocks;                // partial rows per box
+    double* partial;           // [n_boxes][blocks][4]
+};
 struct MdArgs {
     int n;
     float* x; float* v;        // [n][3] length unit L (Angstrom | bohr), L/ps
@@ -246,6 +255,7 @@ struct MdArgs {
     unsigned long long seed; unsigned long long step;
     int* devflags;             // [DEVFLAG_COUNT]: frozen -> return, first kernel to see it records 2 * step_index + half
     int step_index;            // index of this step inside the gamd_md_run call
+    MdCom com;                 // centre-of-mass motion removal at the start of the first half (hack_integrator.py:142)
 };
 int launch_baoab_first(const MdArgs& a, hipStream_t st);    // B A O A  (hack_integrator.py:141-165)
 int launch_baoab_second(const MdArgs& a, hipStream_t st);   // B        (hack_integrator.py:175-178)
@@ -272,6 +282,10 @@ struct NhcArgs {
     int n_blocks;              // blocks per box
     int* devflags;             // as in MdArgs
     int step_index;
+    MdCom com;                 // as in MdArgs: removed at the top of the first half, before the kinetic energy is taken
 };
+// per-block momentum sums of the current velocities (first kernel of a step whose integrator removes the COM motion)
+int launch_com_partial(const MdCom& com, const float* v, const uint8_t* species, float inv_mass, float inv_mass_h, int n,
+                       const BoxRef& bx, const int* devflags, hipStream_t st);
 int launch_nhc_first(const NhcArgs& a, hipStream_t st);     // propagateNHC; v *= scale; v += dt/2 f/m; x += dt v
 int launch_nhc_second(const NhcArgs& a, hipStream_t st);    // v += dt/2 f/m; propagateNHC; v *= scale

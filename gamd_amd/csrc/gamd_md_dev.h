@@ -52,17 +52,28 @@ __device__ __forceinline__ void md_box(const BoxRef& r, const float (&box)[3], i
     out[0] = v.x; out[1] = v.y; out[2] = v.z;
 }
 
-// first half of a step for atom i: B A O A, positions re-wrapped (hack_integrator.py:141-165)
+// centre-of-mass velocity of box `box` from k_com_partial's per-block sums, added up in block order (every thread of the box
+// gets the same bits); OpenMM's CMMotionRemover accumulates in double as well
+__device__ __forceinline__ void md_com_velocity(const MdCom& c, int box, float (&out)[3]) {
+    double px = 0.0, py = 0.0, pz = 0.0, m = 0.0;
+    const double* p = c.partial + (size_t)box * c.blocks * 4;
+    for (int k = 0; k < c.blocks; ++k) { px += p[4 * k]; py += p[4 * k + 1]; pz += p[4 * k + 2]; m += p[4 * k + 3]; }
+    const double inv = 1.0 / m;
+    out[0] = (float)(px * inv); out[1] = (float)(py * inv); out[2] = (float)(pz * inv);
+}
+
+// first half of a step for atom i: [COM motion removal] B A O A, positions re-wrapped (hack_integrator.py:141-165)
 __device__ __forceinline__ void d_baoab_first_atom(const MdArgs& a, int i) {
-    float xi[3], box[3];
+    float xi[3], box[3], com[3] = {0.f, 0.f, 0.f};
     const BoxAtom ba = md_box_atom(a.bx, i);
     md_box(a.bx, a.box, ba.box, box);
+    if (a.com.enabled) md_com_velocity(a.com, ba.box, com);          // updateContextState :142
     atom_noise(a.seed + (unsigned long long)ba.box, a.step, ba.local, xi);
     const float w = atom_inv_mass(a.species, a.inv_mass, a.inv_mass_h, i);
     const float hdt = 0.5f * a.dt, kick = hdt * a.len * w, bs = a.b_len_kT * sqrtf(w);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        float v = a.v[3 * i + d], x = a.x[3 * i + d];
+        float v = a.v[3 * i + d] - com[d], x = a.x[3 * i + d];
         v += kick * a.f[3 * i + d];          // B
         x += hdt * v;                        // A
         v = a.a * v + bs * xi[d];            // O
@@ -169,6 +180,12 @@ __device__ __forceinline__ void d_baoab_first_mol(const MdArgs& a, int m) {
     const BoxAtom ba = md_box_atom(a.bx, 3 * m);            // n_per_box is a multiple of 3: a molecule lies in one box
     float box[3];
     md_box(a.bx, a.box, ba.box, box);
+    if (a.com.enabled) {                                                                   // updateContextState :142
+        float com[3];
+        md_com_velocity(a.com, ba.box, com);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = v[k] - Vec3{com[0], com[1], com[2]};
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) v[k] = v[k] + ((hdt * a.len * w[k]) * f[k]);          // B  :145
     settle_velocities(x, v, a.rigid);                                                     //    :146

@@ -57,6 +57,33 @@ __global__ void k_baoab_second_rigid(MdArgs a) {
     if (3 * m < a.n) d_baoab_second_mol(a, m);
 }
 
+// ---- centre-of-mass motion removal (MdCom) ------------------------------------------------------
+// per-block sums of m v and m over this block's share of box blockIdx.y's atoms; double accumulation, fixed reduction tree
+__global__ void __launch_bounds__(256) k_com_partial(MdCom c, const float* __restrict__ v, const uint8_t* __restrict__ species,
+                                                     float inv_mass, float inv_mass_h, int n, BoxRef bx, const int* devflags) {
+    if (devflags[DEVFLAG_FROZEN]) return;                   // the first-half kernel behind this one records the position
+    __shared__ double red[4][4];
+    const int npb = bx.n_boxes > 1 ? bx.n_per_box : n, a0 = blockIdx.y * npb, a1 = a0 + npb;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = a0 + blockIdx.x * blockDim.x + threadIdx.x; i < a1; i += gridDim.x * blockDim.x) {
+        const double m = 1.0 / (double)atom_inv_mass(species, inv_mass, inv_mass_h, i);
+        s[0] += m * (double)v[3 * i]; s[1] += m * (double)v[3 * i + 1]; s[2] += m * (double)v[3 * i + 2]; s[3] += m;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s[k] += __shfl_down(s[k], d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        c.partial[((size_t)blockIdx.y * c.blocks + blockIdx.x) * 4 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ---- Nose-Hoover chain -------------------------------------------------------------------------
 // sum of m v^2 (kJ/mol: v converted to nm/ps) per block, optionally after the half kick of the second half
 // (and, for rigid water, the velocity constraint that follows it: hack_integrator.py:427-428)
@@ -71,6 +98,10 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
     double s = 0.0;
     const double inv_len = 1.0 / (double)a.len;
     const int npb = nhc_npb(a), a0 = blockIdx.y * npb, a1 = a0 + npb;        // this box's atoms [a0, a1)
+    // first half: updateContextState (hack_integrator.py:272) = the CMMotionRemover, before the kinetic energy is taken
+    float com[3] = {0.f, 0.f, 0.f};
+    const bool decom = !KICK && a.com.enabled;
+    if (decom) md_com_velocity(a.com, blockIdx.y, com);
     if (a.use_rigid) {
         for (int m = a0 / 3 + blockIdx.x * blockDim.x + threadIdx.x; 3 * m < a1; m += gridDim.x * blockDim.x) {
             Vec3 v[3];
@@ -84,6 +115,11 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
                 settle_velocities(x, v, a.rigid);
                 store_mol(a.v, m, v);
             }
+            if (decom) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[k] = v[k] - Vec3{com[0], com[1], com[2]};
+                store_mol(a.v, m, v);
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const double vx = inv_len * v[k].x, vy = inv_len * v[k].y, vz = inv_len * v[k].z;
@@ -95,6 +131,7 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
             const float w = atom_inv_mass(a.species, 1.0f / a.mass, a.mass_h > 0.f ? 1.0f / a.mass_h : 0.f, i / 3);
             float v = a.v[i];
             if (KICK) { v += 0.5f * a.dt * a.len * w * a.f[i]; a.v[i] = v; }   // hack_integrator.py:427 v+0.5*dt*gnn_force/m
+            if (decom) { v -= com[i % 3]; a.v[i] = v; }
             const double vn = inv_len * (double)v;
             s += vn * vn / (double)w;
         }
@@ -197,8 +234,21 @@ __global__ void k_nhc_apply_second(NhcArgs a) {
 
 }  // namespace
 
+int launch_com_partial(const MdCom& com, const float* v, const uint8_t* species, float inv_mass, float inv_mass_h, int n,
+                       const BoxRef& bx, const int* devflags, hipStream_t st) {
+    const int nb = bx.n_boxes > 1 ? bx.n_boxes : 1;
+    hipLaunchKernelGGL(k_com_partial, dim3(com.blocks, nb), dim3(256), 0, st, com, v, species, inv_mass, inv_mass_h, n, bx, devflags);
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}
+
 int launch_nhc_first(const NhcArgs& a, hipStream_t st) {
     const int nb = a.bx.n_boxes > 1 ? a.bx.n_boxes : 1;
+    if (a.com.enabled) {
+        int r = launch_com_partial(a.com, a.v, a.species, 1.0f / a.mass, a.mass_h > 0.f ? 1.0f / a.mass_h : 0.f, a.n, a.bx,
+                                   a.devflags, st);
+        if (r) return r;
+    }
     hipLaunchKernelGGL(k_nhc_ke2<false>, dim3(a.n_blocks, nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_nhc_chain, dim3((nb + 63) / 64), dim3(64), 0, st, a); GAMD_CHECK_LAUNCH();
     if (a.use_rigid) hipLaunchKernelGGL(k_nhc_apply_first_rigid, dim3((a.n / 3 + 255) / 256), dim3(256), 0, st, a);
@@ -216,6 +266,10 @@ int launch_nhc_second(const NhcArgs& a, hipStream_t st) {
 }
 
 int launch_baoab_first(const MdArgs& a, hipStream_t st) {
+    if (a.com.enabled) {
+        int r = launch_com_partial(a.com, a.v, a.species, a.inv_mass, a.inv_mass_h, a.n, a.bx, a.devflags, st);
+        if (r) return r;
+    }
     if (a.use_rigid) hipLaunchKernelGGL(k_baoab_first_rigid, dim3((a.n / 3 + 255) / 256), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_baoab_first, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
     GAMD_CHECK_LAUNCH();

@@ -329,17 +329,22 @@ class GamdForce:
     def md_run(self, x: torch.Tensor, v: torch.Tensor, f: torch.Tensor, n_steps: int, dt_ps=0.002,
                mass_amu=39.9, temperature_k=100.0, gamma_per_ps=25.0, seed=0, first_step=0,
                box=None, species=None, sync: bool = True, mass_h_amu=0.0, length_per_nm=0.0,
-               rigid_water: bool = False, r_oh=0.0, r_hh=0.0) -> None:
+               rigid_water: bool = False, r_oh=0.0, r_hh=0.0, remove_cm_motion: Optional[bool] = None) -> None:
         """Advance (x, v, f) in place by n_steps; f holds denormalised forces (kJ/mol/nm) at x.
 
         Water: ``mass_amu`` is the oxygen mass and ``mass_h_amu`` the mass of the species-0 atoms;
         ``rigid_water`` holds every O,H,H triple rigid at (r_oh, r_hh) like OpenMM's constrained water
         (positions must then be whole molecules; they are kept whole).  ``length_per_nm`` is the length
-        unit of x/v/box (10 = Angstrom, the default; 18.8972613 = bohr for the DFT model)."""
+        unit of x/v/box (10 = Angstrom, the default; 18.8972613 = bohr for the DFT model).
+        ``remove_cm_motion``: subtract the centre-of-mass velocity at the top of every step like the CMMotionRemover that
+        hack_integrator.py:142 runs when the OpenMM System has one; default True with ``rigid_water`` (the water drivers'
+        openmmtools WaterBox carries one), False otherwise (the LJ fluid does not)."""
         self._md_state(x, v, f)
         s = self._dev_species(species)
+        if remove_cm_motion is None:
+            remove_cm_motion = bool(rigid_water)
         p = GamdMdParams(dt_ps, mass_amu, temperature_k, gamma_per_ps, seed, first_step, mass_h_amu, length_per_nm,
-                         int(rigid_water), r_oh, r_hh, 0)
+                         int(rigid_water), r_oh, r_hh, int(bool(remove_cm_motion)))
         st = self._lib.gamd_md_run(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()),
                                    C.c_void_p(f.data_ptr()), C.c_void_p(s.data_ptr()) if s is not None else None,
                                    self._box_arg(box), C.byref(p), int(n_steps), self._stream())
@@ -358,7 +363,8 @@ class GamdForce:
         ``ndf`` defaults to what hack_integrator.py:226-235 computes from the OpenMM System: 3 per particle, minus the
         constraints (three per rigid molecule), minus 3 when the System holds a CMMotionRemover.
         ``remove_cm_motion`` says whether it does: default True with ``rigid_water`` (the water drivers build an
-        openmmtools WaterBox, whose System carries one), False otherwise (the LJ drivers' ndf is 3N)."""
+        openmmtools WaterBox, whose System carries one), False otherwise (the LJ drivers' ndf is 3N).  When it does, the
+        centre-of-mass velocity is also subtracted on the device at the top of every step (hack_integrator.py:272)."""
         self._md_state(x, v, f)
         reset = chain_state is None
         if reset:
@@ -373,7 +379,7 @@ class GamdForce:
             ndf = (2 * self.n if rigid_water else 3 * self.n) - (3 if remove_cm_motion else 0)
         p = GamdNhcParams(dt_ps, mass_amu, temperature_k, frequency_per_ps, chain_length, num_mts, num_yoshidasuzuki,
                           int(reset), float(ndf),
-                          mass_h_amu, length_per_nm, int(rigid_water), r_oh, r_hh, 0)
+                          mass_h_amu, length_per_nm, int(rigid_water), r_oh, r_hh, int(bool(remove_cm_motion)))
         st = self._lib.gamd_md_run_nhc(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(v.data_ptr()),
                                        C.c_void_p(f.data_ptr()), C.c_void_p(s.data_ptr()) if s is not None else None,
                                        self._box_arg(box), C.byref(p), C.c_void_p(chain_state.data_ptr()), int(n_steps),

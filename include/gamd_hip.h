@@ -207,7 +207,10 @@ typedef struct gamd_md_params {
                                 of the water drivers at every addConstrainPositions / addConstrainVelocities of
                                 hack_integrator.py:145-164,178,277-280,427-428 (SETTLE + analytic velocity constraint) */
     float r_oh, r_hh;        /* constraint lengths in the length unit (TIP3P: 0.9572, 1.5139 A) */
-    int32_t reserved;
+    int32_t remove_cm_motion;/* 1 = subtract the centre-of-mass velocity (sum m v / sum m, per box) at the top of every step, as
+                                OpenMM's CMMotionRemover does through addUpdateContextState() (hack_integrator.py:142) when the
+                                System carries one: the water drivers' openmmtools WaterBox does, the LJ fluid does not.  GNN
+                                forces do not sum to zero, so without it the centre of mass random-walks in long rollouts */
 } gamd_md_params;
 int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
                     const float* box, const gamd_md_params* p, int64_t n_steps, void* stream);
@@ -237,7 +240,7 @@ typedef struct gamd_nhc_params {
                                 of the water drivers at every addConstrainPositions / addConstrainVelocities of
                                 hack_integrator.py:145-164,178,277-280,427-428 (SETTLE + analytic velocity constraint) */
     float r_oh, r_hh;        /* constraint lengths in the length unit (TIP3P: 0.9572, 1.5139 A) */
-    int32_t reserved;
+    int32_t remove_cm_motion;/* as in gamd_md_params (hack_integrator.py:272; ndf is then 3 smaller, :226-235) */
 } gamd_nhc_params;
 int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
                         const float* box, const gamd_nhc_params* p, double* chain_state_dev, int64_t n_steps, void* stream);

@@ -296,6 +296,16 @@ def baoab_second_half(v, f, inv_m, dt):
     return v + (0.5 * dt) * f * inv_m
 
 
+def remove_cm_motion(v, mass):
+    """OpenMM's CMMotionRemover (third-party, absent here; frequency 1), which the first-half integrators run through
+    addUpdateContextState() at the top of every step (hack_integrator.py:142, :272) when the System carries one — the water
+    drivers' openmmtools WaterBox does, and hack_integrator.py:226-235 takes 3 degrees of freedom off for it:
+    v_i -= sum_j m_j v_j / sum_j m_j  (restated from OpenMM's ReferenceRemoveCMMotionKernel)."""
+    v = np.asarray(v, dtype=np.float64)
+    m = np.broadcast_to(np.asarray(mass, dtype=np.float64).reshape(-1, 1) if np.ndim(mass) else np.float64(mass), (v.shape[0], 1))
+    return v - (m * v).sum(axis=0) / m.sum()
+
+
 YS_WEIGHTS = {1: [1.0], 3: [0.8289815435887510, -0.6579630871775020, 0.8289815435887510],
               5: [0.2967324292201065, 0.2967324292201065, -0.1869297168804260, 0.2967324292201065,
                   0.2967324292201065]}                       # hack_integrator.py:183-187

@@ -160,6 +160,7 @@ def test_rigid_water_langevin_matches_shake_rattle_oracle():
     steps = 2
     eng.md_run(x, v, f, steps, rigid_water=True, r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH, **kw)
     for s in range(steps):
+        vr = orc.remove_cm_motion(vr, mass)                           # the WaterBox System's CMMotionRemover (:142); default on
         xr, vr = orc.baoab_first_half_rigid(xr, vr, fr, 1.0 / mass, dt, a, bs, device_noise(s), pairs, lengths)
         fr = _oracle_water_forces(sd, xr, box, species, bonds)
         vr = orc.baoab_second_half_rigid(xr, vr, fr, 1.0 / mass, dt, pairs)
@@ -231,9 +232,11 @@ def test_rigid_water_halves_fused_into_the_skin_check_match_the_separate_kernels
     assert np.abs(xf - pos).max() > 1e-3                              # it moved
 
 
-def test_rigid_water_nose_hoover_matches_oracle():
+@pytest.mark.parametrize("remove_com", [False, True])
+def test_rigid_water_nose_hoover_matches_oracle(remove_com):
     """HackNoseHooverIntegrator / HackHalfNoseHooverIntegrator with constraints (hack_integrator.py:274-280,
-    427-430), ndf = 3N - N constraints (:226-235)."""
+    427-430), ndf = 3N - N constraints (:226-235), minus 3 and with the COM motion removed at the top of every step (:272)
+    when the System carries a CMMotionRemover (the default for rigid water)."""
     from gamd_amd import workloads as wl
     eng, sd, pos, box, species, bonds, mass, pairs, lengths, v0 = _water_setup()
     n = pos.shape[0]
@@ -245,10 +248,12 @@ def test_rigid_water_nose_hoover_matches_oracle():
     steps = 3
     chain = eng.md_run_nhc(x, v, f, steps, dt_ps=dt, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, temperature_k=T,
                            frequency_per_ps=freq, chain_length=M, species=species, rigid_water=True,
-                           r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH, remove_cm_motion=False)
+                           r_oh=wl.TIP3P_R_OH, r_hh=wl.TIP3P_R_HH, **({} if remove_com else dict(remove_cm_motion=False)))
     st = orc.nhc_init(M, freq)
-    kT, ndf = wl.KB * T, 2.0 * n
+    kT, ndf = wl.KB * T, 2.0 * n - (3.0 if remove_com else 0.0)
     for _ in range(steps):
+        if remove_com:
+            vr = orc.remove_cm_motion(vr, mass)
         xr, vr = orc.nhc_first_half_rigid(st, xr, vr, fr, mass, dt, kT, freq, ndf, pairs, lengths)
         fr = _oracle_water_forces(sd, xr, box, species, bonds)
         vr = orc.nhc_second_half_rigid(st, xr, vr, fr, mass, dt, kT, freq, ndf, pairs)
@@ -293,4 +298,89 @@ def test_species_masses_and_bohr_units_with_the_dft_model():
     assert rel_err(x.cpu().numpy(), xr) < 1e-5
     assert rel_err(v.cpu().numpy(), vr) < 1e-4
     assert rel_err(f.cpu().numpy(), fr) < 1e-4
+    eng.close()
+
+
+# ---- centre-of-mass motion removal (hack_integrator.py:142, :272: addUpdateContextState -> CMMotionRemover) ------------
+@pytest.mark.parametrize("n,skin_frac", [(258, 0.0), (258, 1.0 / 6.0), (2000, 0.0), (2000, 1.0 / 6.0)])
+def test_com_motion_removal_langevin_free_atoms(n, skin_frac):
+    """remove_cm_motion on the LJ system: T = 0 run against the oracle (COM removed at the top of every step), on the
+    standalone integrator kernels (no skin), inside k_step_small (n <= 1024, skin) and inside k_skin_check (n > 1024, skin).
+    The COM velocity the run ends with is what one second half-kick with the GNN forces adds (they do not sum to zero)."""
+    from gamd_amd.engine import GamdForce
+    from gamd_amd.weights import ModelConfig, make_state_dict
+    from gamd_amd.workloads import lj_box
+    rc = 7.5
+    pos, box = lj_box(n, seed=3)
+    sd = make_state_dict(ModelConfig(), 0, 5.3, 1.6)
+    eng = GamdForce(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=skin_frac * rc)
+    x = torch.from_numpy(pos).float().cuda()
+    v = torch.from_numpy(np.random.default_rng(1).normal(0, 1.4, (n, 3)) + np.array([0.7, -0.4, 0.2])).float().cuda()
+    f = eng.forward(x, denormalize=True).clone()
+    xr, vr, fr = x.cpu().double().numpy(), v.cpu().double().numpy(), f.cpu().double().numpy()
+    dt, m, gamma, steps = 0.002, 39.9, 25.0, 3
+    eng.md_run(x, v, f, steps, dt_ps=dt, mass_amu=m, temperature_k=0.0, gamma_per_ps=gamma, remove_cm_motion=True)
+    a = np.exp(-gamma * dt)
+    mean, var = SHIPPED_SCALERS["lj"]
+    for _ in range(steps):
+        vr = orc.remove_cm_motion(vr, m)
+        xr, vr = orc.baoab_first_half(xr, vr, fr, 10.0 / m, dt, a, 0.0, 0.0)
+        xr = np.mod(xr, box)
+        fr = orc.predict_forces(sd, xr, box, rc, var=var, mean=mean)
+        vr = orc.baoab_second_half(vr, fr, 10.0 / m, dt)
+    assert rel_err(x.cpu().numpy(), xr) < 1e-5
+    assert rel_err(v.cpu().numpy(), vr) < 1e-4
+    vcom = v.cpu().double().numpy().mean(axis=0)
+    kick = 0.5 * dt * 10.0 / m * fr.mean(axis=0)
+    assert np.abs(vcom - kick).max() < 1e-5 and np.abs(vcom).max() < 0.05          # the initial drift (0.7, -0.4, 0.2) is gone
+    # without the remover the drift stays
+    x2 = torch.from_numpy(pos).float().cuda()
+    v2 = torch.from_numpy(np.random.default_rng(1).normal(0, 1.4, (n, 3)) + np.array([0.7, -0.4, 0.2])).float().cuda()
+    f2 = eng.forward(x2, denormalize=True).clone()
+    eng.md_run(x2, v2, f2, steps, dt_ps=dt, mass_amu=m, temperature_k=0.0, gamma_per_ps=gamma)
+    assert np.abs(v2.cpu().numpy().mean(axis=0)).max() > 0.1
+    eng.close()
+
+
+def test_com_motion_removal_is_mass_weighted_and_per_box():
+    """Two species (O / H masses, unconstrained) in a batch of three boxes with different drifts: after one step with
+    gamma dt >> 1 and T = 0 the velocities are the second half-kick only, so sum m v per box = (dt/2) sum f per box; and a
+    Nose-Hoover batch removes each box's own drift too."""
+    from gamd_amd.engine import GamdForce
+    from gamd_amd import workloads as wl
+    g, cfg, sd = load_golden("tip3p774_seed3")
+    nb, n = 3, 774
+    box, rc = float(g["box"]), float(g["cutoff"])
+    species = g["node_feat"].reshape(-1) != 0
+    mass = np.where(species, wl.MASS_O, wl.MASS_H).astype(np.float64).reshape(-1, 1)
+    eng = GamdForce(sd, n, box, rc, bond=g["bond"], scaler=SHIPPED_SCALERS["tip3p"], n_boxes=nb)
+    rng = np.random.default_rng(4)
+    pos = np.concatenate([np.mod(g["pos"], box) + rng.normal(0, 0.02, (n, 3)) for _ in range(nb)])
+    drift = np.array([[3.0, 0.0, -1.0], [0.0, -2.0, 0.5], [-1.5, 1.0, 2.0]])
+    v0 = np.concatenate([rng.normal(0, 2.0, (n, 3)) + drift[b] for b in range(nb)])
+    sp = np.tile(species, nb)
+    kw = dict(dt_ps=0.0005, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, species=sp)
+    x = torch.from_numpy(pos).float().cuda(); v = torch.from_numpy(v0).float().cuda()
+    f = eng.forward(x, species=sp, denormalize=True).clone()
+    # NHC, one step: the first thing it does is remove each box's COM velocity; compare with the oracle per box
+    xn, vn, fn = x.clone(), v.clone(), f.clone()
+    chain = eng.md_run_nhc(xn, vn, fn, 1, temperature_k=300.0, remove_cm_motion=True, ndf=3.0 * n - 3.0, **kw)
+    for b in range(nb):
+        sl = slice(b * n, (b + 1) * n)
+        st = orc.nhc_init(10, 25.0)
+        vr = orc.remove_cm_motion(v0[sl], mass)
+        xr, vr = orc.nhc_first_half(st, pos[sl], vr, f[sl].cpu().double().numpy(), mass, 0.0005, wl.KB * 300.0, 25.0, 3.0 * n - 3.0)
+        fr = fn[sl].cpu().double().numpy()
+        vr = orc.nhc_second_half(st, vr, fr, mass, 0.0005, wl.KB * 300.0, 25.0, 3.0 * n - 3.0)
+        assert rel_err(vn[sl].cpu().numpy(), vr) < 1e-4, b
+        assert rel_err(chain[b].cpu().numpy()[10:20], st["vxi"]) < 1e-3, b
+    # Langevin: per-box momentum after a step with the remover
+    eng.md_run(x, v, f, 1, temperature_k=0.0, gamma_per_ps=0.0, remove_cm_motion=True, **kw)
+    vd, fd = v.cpu().double().numpy(), f.cpu().double().numpy()
+    f_old = eng.forward(torch.from_numpy(pos).float(), species=sp, denormalize=True).cpu().double().numpy()
+    for b in range(nb):
+        sl = slice(b * n, (b + 1) * n)
+        p = (mass * vd[sl]).sum(axis=0)
+        expect = 0.5 * 0.0005 * 10.0 * (f_old[sl].sum(axis=0) + fd[sl].sum(axis=0))     # the two half-kicks; the drift is gone
+        assert np.abs(p - expect).max() < 2e-3 * np.abs(mass * drift[b]).sum(), (b, p, expect)
     eng.close()
