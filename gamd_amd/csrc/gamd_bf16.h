@@ -40,7 +40,8 @@ __device__ __forceinline__ void pack_chain_bf16(const f32x16 (&X)[4], bf16x8 (&P
 
 // acc (+)= W * P^T (F1, chain layout out) or P * W^T (F2, row layout out); 32 MFMAs, 4 independent
 // accumulators rotate inside every K-step
-template <bool F2, typename WPtr>
+// (HALFREAD: timing ablation of the profiling build — both K steps u use the u = 0 fragment, i.e. half the LDS reads)
+template <bool F2, bool HALFREAD = false, typename WPtr>
 __device__ __forceinline__ void gemm128_bf16(WPtr W, int lane, const bf16x8 (&P)[4][2], f32x16 (&acc)[4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -48,8 +49,43 @@ __device__ __forceinline__ void gemm128_bf16(WPtr W, int lane, const bf16x8 (&P)
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {
-                const bf16x8 w = W[((tp * 4 + t) * 2 + u) * 64 + lane];
+                const bf16x8 w = W[((tp * 4 + t) * 2 + (HALFREAD ? 0 : u)) * 64 + lane];
                 acc[tp] = F2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(P[t][u], w, acc[tp], 0, 0, 0)
                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, P[t][u], acc[tp], 0, 0, 0);
             }
+}
+
+// The same GEMM with the weight fragments read D MFMAs ahead through an explicit ring of D x 4 registers.  hipcc's own schedule
+// of gemm128_bf16 is read -> s_waitcnt -> MFMA with one or two fragments in flight, so every 32-cycle MFMA sits out most of an
+// LDS round trip: 97 cycles per MFMA measured in k_conv_edge_bf16 (tools/bf16_variants.py: the kernel without its MFMAs took
+// 17 us, with them 49 us, for 10 us of matrix time).  Scheduling barriers in front of and behind the GEMM keep other memory
+// instructions out of it, sched_group_barrier pins the pattern (one LDS read, one MFMA) inside; the waits are hipcc's own
+// counted lgkmcnt (LDS reads return in order), so they stay correct whatever else is in flight.
+template <bool F2, int D>
+__device__ __forceinline__ void gemm128_bf16_pf(const bf16x8* W, int lane, const bf16x8 (&P)[4][2], f32x16 (&acc)[4]) {
+    // MFMA i = (t, u, tp) with tp fastest: four independent accumulators rotate; its fragment sits at ((tp*4 + t)*2 + u) * 64
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 w[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) w[i] = W[((((i & 3) * 4 + (i >> 3)) * 2) + ((i >> 2) & 1)) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int tp = i & 3, t = i >> 3, u = (i >> 2) & 1;
+        const bf16x8 cur = w[i % D];
+        acc[tp] = F2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(P[t][u], cur, acc[tp], 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, P[t][u], acc[tp], 0, 0, 0);
+        if (i + D < 32) {
+            const int j = i + D;
+            w[i % D] = W[((((j & 3) * 4 + (j >> 3)) * 2) + ((j >> 2) & 1)) * 64 + lane];
+        }
+    }
+    // D reads up front, then (MFMA, read) pairs, then the last D MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, D, 0);
+#pragma unroll
+    for (int i = 0; i < 32 - D; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, D, 0);
+    __builtin_amdgcn_sched_barrier(0);
 }

@@ -31,11 +31,17 @@ __device__ __forceinline__ void wide_barrier() {
 // edge features + edge encoder + LayerNorm(Eh)
 //   MLP NFEAT -> 128 -> 128 -> Eh (GELU), nn_module.py:306-317; features nn_module.py:322-336 / :603-634
 // ================================================================================================
+// Waves per workgroup of the encoder: 8 (two per SIMD, 256 registers each) for Eh = 128; for Eh = 256 the LayerNorm needs both
+// 128-wide output blocks of a tile at once — X + Y[0] + Y[1] = 192 registers next to the weight fragments in flight — which
+// does not fit 256 registers (66 spilled registers in round 3): 4 waves, one per SIMD with the whole register file, no scratch.
+template <int EHT> struct EncWaves { static constexpr int value = EHT == 2 ? 4 : 8; };
+
 template <int NFEAT, int EHT>
-__global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
+__global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(EncArgs a) {
     if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     static_assert(EHT == 1 || EHT == 2, "edge embedding width 128 or 256");
     constexpr int EH = 128 * EHT;
+    constexpr int NW = EncWaves<EHT>::value, NT = 64 * NW;
     constexpr bool EXPAND = NFEAT >= 44;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w1 = lds;
@@ -52,26 +58,26 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
     const int lane = tid & 63, slot = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lane16 = (unsigned)lane * 16u;
-    for (int i = tid; i < WIDE_ENC_W1_FLOATS / 4; i += 512) ((f32x4*)w1)[i] = ((const f32x4*)a.w1p)[i];
-    for (int i = tid; i < GAMD_WFRAG_FLOATS / 4; i += 512) ((f32x4*)w2)[i] = ((const f32x4*)a.w2p)[i];
+    for (int i = tid; i < WIDE_ENC_W1_FLOATS / 4; i += NT) ((f32x4*)w1)[i] = ((const f32x4*)a.w1p)[i];
+    for (int i = tid; i < GAMD_WFRAG_FLOATS / 4; i += NT) ((f32x4*)w2)[i] = ((const f32x4*)a.w2p)[i];
     if (EHT == 1)
-        for (int i = tid; i < GAMD_WFRAG_FLOATS / 4; i += 512) ((f32x4*)ws)[i] = ((const f32x4*)a.w3p)[i];
+        for (int i = tid; i < GAMD_WFRAG_FLOATS / 4; i += NT) ((f32x4*)ws)[i] = ((const f32x4*)a.w3p)[i];
     if (tid < 128) { vb1[tid] = a.b1[tid]; vb2[tid] = a.b2[tid]; }
-    if (tid < EH) { vb3[tid] = a.b3[tid]; vg[tid] = a.ln_g[tid]; vbeta[tid] = a.ln_b[tid]; }
+    for (int i = tid; i < EH; i += NT) { vb3[i] = a.b3[i]; vg[i] = a.ln_g[i]; vbeta[i] = a.ln_b[i]; }
     if (EXPAND && tid < 40) cen[tid] = a.centers[tid];
     __syncthreads();
 
     long long E = a.counters[CNT_E];
     if (E > a.e_cap) E = a.e_cap;
     const int n_tiles = (int)((E + GAMD_TILE - 1) / GAMD_TILE);
-    const int n_wg_tiles = (n_tiles + 7) / 8;
+    const int n_wg_tiles = (n_tiles + NW - 1) / NW;
     int first, end, step;
     gamd_xcd_range(n_wg_tiles, blockIdx.x, gridDim.x, first, end, step);
     constexpr int KSTEPS = (NFEAT + 1) / 2;
 
     for (int wt = first; wt < end; wt += step) {          // uniform over the workgroup (barriers inside)
         asm volatile("" ::: "memory");
-        const int tile = wt * 8 + wave;
+        const int tile = wt * NW + wave;
         const bool active = tile < n_tiles;
         const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = active && x < E;
@@ -141,11 +147,13 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_wide(EncArgs a) {
         for (int ob = 0; ob < EHT; ++ob) {
             if (EHT > 1) {
                 wide_barrier();                            // previous readers of the slot are done
-                gamd_stage_weight<8>(a.w3p + (size_t)ob * GAMD_WFRAG_FLOATS, ws, wave, lane16);
+                gamd_stage_weight<NW>(a.w3p + (size_t)ob * GAMD_WFRAG_FLOATS, ws, wave, lane16);
                 wide_barrier();
             }
             load_bias_chain(vb3 + 128 * ob, half, Y[ob]);
-            gemm128<false>((const f32x4*)ws, lane, X, Y[ob]);
+            unsigned ws_off = (unsigned)((WIDE_ENC_W1_FLOATS + GAMD_WFRAG_FLOATS) * sizeof(float));
+            asm volatile("" : "+s"(ws_off));                 // one base register + immediate offsets (see k_conv_edge_wide)
+            gemm128<false>((const f32x4*)((const char*)lds + ws_off), lane, X, Y[ob]);
         }
         // LayerNorm over Eh features (torch: biased variance, eps inside the sqrt)
         float s1 = 0.f;
@@ -225,7 +233,13 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
     auto begin_phase = [&]() -> const f32x4* {
         const int nb = (blk + 1 == NP) ? 0 : blk + 1;
         gamd_stage_weight_raw_contig<8>(a.w1p + (size_t)nb * GAMD_WFRAG_FLOATS, lds + ((g + 1) & 1u) * GAMD_WFRAG_FLOATS, wave, lane16);
-        return (const f32x4*)(lds + (g & 1u) * GAMD_WFRAG_FLOATS);
+        // The slot offset stays a run-time value: with an even number of phases per tile (EHT + 2 + HT = 4 or 6) the slot of
+        // every phase is a compile-time constant, and hipcc then materialises one address register per 1 KiB fragment of the
+        // upper slot (its byte offsets >= 65 536 do not fit the 16-bit offset field of ds_read_b128): ~30 loop-invariant
+        // registers, 8-14 of them spilled to scratch in round 3.  One base register + immediate offsets instead.
+        unsigned off = (g & 1u) * (unsigned)(GAMD_WFRAG_FLOATS * sizeof(float));
+        asm volatile("" : "+s"(off));
+        return (const f32x4*)((const char*)lds + off);
     };
     auto end_phase = [&]() { wide_barrier(); ++g; blk = (blk + 1 == NP) ? 0 : blk + 1; };
 
@@ -566,7 +580,7 @@ int enc_launch(const EncArgs& a, int n_blocks, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_edge_encode_wide<NFEAT, EHT>), dim3(n_blocks), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_edge_encode_wide<NFEAT, EHT>), dim3(n_blocks), dim3(64 * EncWaves<EHT>::value), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
 }
