@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         // ---- GEMM 3 + LayerNorm ----
         load_bias_chain(vb3, half, acc);
         gemm128<false>((const f32x4*)w3, lane, X, acc);
-        if (!(ABL & 2)) layernorm_chain_centered(acc, vg, vbeta, half, 1e-5f);     // W3, b3 arrive centred
+        if (!(ABL & 2)) layernorm_chain_centered(acc, vg, vbeta, half, 1e-5f, a.ln_inv_width);     // W3, b3 arrive centred
         if (a.self_loop) {
             // self_loop_mode 1: the last edge of every row is the loop an in-place add_self_loop would have appended AFTER
             // edata['e'] was set (nn_module.py:649-652): its embedding is DGL's zero fill, not an encoded feature row
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) k_edge_encode_small(EncArgs a) {
         __syncthreads();                                   // previous tile's readers of red[] are done
         red[quarter][lane] = v;
         __syncthreads();
-        const float var = gamd_xhalf_sum((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * (1.0f / 128.0f);
+        const float var = gamd_xhalf_sum((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * a.ln_inv_width;
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         const f32x16 g = load_slice(a.ln_g, quarter, half), b = load_slice(a.ln_b, quarter, half);
         const bool zero_row = a.self_loop && valid && x == (long long)a.row_ptr[dst + 1] - 1;      // appended loop: e = 0

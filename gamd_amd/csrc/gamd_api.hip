@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -98,7 +99,8 @@ struct gamd_handle {
     int n_boxes = 1, n_per_box = 0;              // gamd_config.n_boxes: independent boxes evaluated in one set of launches
     DevBuf boxes_dev, box_shift;                 // n_boxes > 1: per-box dimensions (BoxRef::boxes), scratch of the row scan
     std::vector<float> boxes_host;               // [n_boxes][3] as last set
-    int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width and their 128-blocks
+    int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width (PADDED to 128-blocks) and their block counts
+    int H_true = 128, Eh_true = 128, D_true = 128;   // encoding_size, edge_embedding_dim, hidden_dim as given (<= the padded ones)
     bool wide_enc = false, wide_conv = false;    // generic-width kernels of wide.hip
     long long small_tile_limit = 512;            // fp32 path: at most this many 32-edge tiles -> conv_edge_small.hip
     std::map<std::string, HostTensor> host_w;
@@ -496,6 +498,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.length_mean = h->length_mean;
     ea.length_std = h->length_std;
     ea.gamma = (float)(1.0 / 0.025);             // RBFExpansion(high=1, gap=0.025): gamma = 1/gap (nn_module.py:240)
+    ea.ln_inv_width = 1.0f / (float)h->Eh_true;
+    ea.ln_n_pad = (float)(h->Eh - h->Eh_true);
     ea.n_feat = h->n_feat;
     ea.n_ksteps = (h->n_feat + 1) / 2;
     ea.centers = h->centers;
@@ -559,6 +563,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     no.hn_perm = (!h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F16X3) ? 1 : 0;
     no.hn_out = h->hn.as<float>(); no.S_out = h->S.as<float>(); no.D_out = h->D.as<float>(); no.P_out = h->P.as<float>();
     no.dec_w1p = h->dec_w1p; no.dec_b1 = h->dec_b1; no.dec_w2 = h->dec_w2; no.dec_b2 = h->dec_b2;
+    no.ln_inv_width = 1.0f / (float)h->H_true;
+    no.ln_n_pad = (float)(h->H - h->H_true);
     no.scale = (float)std::sqrt(h->scaler_var);
     no.shift = (float)h->scaler_mean;
     no.perm = h->perm.as<int>();
@@ -735,12 +741,18 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     DeviceGuard guard(cfg->device);            // the caller's current device is restored on every return path
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
-    const int H = cfg->encoding_size ? cfg->encoding_size : 128, Eh = cfg->edge_embedding_dim ? cfg->edge_embedding_dim : 128;
-    if ((H != 128 && H != 256) || (Eh != 128 && Eh != 256))
-        return fail(-22, "encoding_size and edge_embedding_dim must be 128 or 256 (got %d, %d)", H, Eh);
-    if (cfg->hidden_dim != 0 && cfg->hidden_dim != 128) return fail(-22, "hidden_dim must be 128 (got %d)", cfg->hidden_dim);
+    // Widths as build_model hands them to the model constructors (nn_module.py:561-601, :410-460, :266-320).  The kernels work
+    // in 128-wide blocks: narrower (or in-between) widths are zero-padded by gamd_finalize_weights — padded features stay
+    // exact zeros through every Linear / SiLU / GELU, and the two LayerNorms divide by the true width.
+    const int H_true = cfg->encoding_size ? cfg->encoding_size : 128, Eh_true = cfg->edge_embedding_dim ? cfg->edge_embedding_dim : 128;
+    const int D_true = cfg->hidden_dim ? cfg->hidden_dim : 128;
+    if (H_true < 1 || H_true > 256 || Eh_true < 1 || Eh_true > 256)
+        return fail(-22, "encoding_size and edge_embedding_dim must be in [1, 256] (got %d, %d)", H_true, Eh_true);
+    if (D_true < 1 || D_true > 128) return fail(-22, "hidden_dim must be in [1, 128] (got %d)", D_true);
+    const int H = H_true <= 128 ? 128 : 256, Eh = Eh_true <= 128 ? 128 : 256;
+    const bool exact128 = H_true == 128 && Eh_true == 128 && D_true == 128;
     const bool generic = H != 128 || Eh != 128 || cfg->no_expand_edge;
-    if (generic && cfg->edge_dtype != GAMD_EDGE_F32)
+    if ((generic || !exact128) && cfg->edge_dtype != GAMD_EDGE_F32)
         return fail(-22, "the bf16 and split-fp16 edge-MLPs are built for the 128-wide RBF-expanded configuration only");
     gamd_handle* h = new gamd_handle();
     h->cfg = *cfg;
@@ -750,6 +762,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     h->n = cfg->n_atoms * n_boxes;
     h->L = cfg->n_layers;
     h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
+    h->H_true = H_true; h->Eh_true = Eh_true; h->D_true = D_true;
     h->skin = cfg->neighbor_skin;
     if (cfg->small_tile_limit != 0) h->small_tile_limit = cfg->small_tile_limit < 0 ? -1 : cfg->small_tile_limit;
     const bool forced = (cfg->kernel_select & GAMD_KSEL_FORCE_GENERIC_WIDTH) && cfg->edge_dtype == GAMD_EDGE_F32;
@@ -864,12 +877,29 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     if (!h) return fail(-22, "null handle");
     DeviceGuard guard(h->dev);
     const int F = h->n_feat, L = h->L;
-    const int64_t H = h->H, Eh = h->Eh, HT = h->HT, EHT = h->EHT;
+    const int64_t H = h->H, Eh = h->Eh, HT = h->HT, EHT = h->EHT;         // padded widths the kernels work in
+    const int64_t Ht = h->H_true, Et = h->Eh_true, Dt = h->D_true;        // the state_dict's widths
     const bool expand = !h->cfg.no_expand_edge;
     BlobBuilder bb;
     struct Off { size_t w1p, w2p, w3p, w4p, b1, b3, b4, lng, lnb, wsp, wdp, wpdp, bS, bP, wpep, wphip, bphi; };
     std::vector<Off> lo(L);
-    auto get = [&](const std::string& nm, std::initializer_list<int64_t> shp) { return find_w(h, nm, shp); };
+    // get(name, true shape, padded shape): the tensor as the reference stores it, zero-padded to the kernels' block widths.
+    // Padded output rows / input columns are zeros, so padded features are exact zeros through every layer.
+    std::deque<HostTensor> padded;
+    auto get = [&](const std::string& nm, std::initializer_list<int64_t> shp, std::initializer_list<int64_t> pad) -> const HostTensor* {
+        const HostTensor* t = find_w(h, nm, shp);
+        if (!t) return nullptr;
+        const std::vector<int64_t> ps(pad);
+        if (t->shape == ps) return t;
+        HostTensor o;
+        o.shape = ps;
+        const int64_t r = ps.size() == 2 ? t->shape[0] : 1, c = ps.size() == 2 ? t->shape[1] : t->shape[0];
+        const int64_t cp = ps.size() == 2 ? ps[1] : ps[0], rp = ps.size() == 2 ? ps[0] : 1;
+        o.data.assign((size_t)(rp * cp), 0.f);
+        for (int64_t i = 0; i < r; ++i) std::copy(t->data.begin() + i * c, t->data.begin() + (i + 1) * c, o.data.begin() + i * cp);
+        padded.push_back(std::move(o));
+        return &padded.back();
+    };
     auto put_vec = [&](const HostTensor* t) { size_t o = bb.add(t->data.size()); std::copy(t->data.begin(), t->data.end(), bb.host.begin() + o); return o; };
     // [128 OB][128 KB] matrix -> OB*KB packed 128x128 blocks, block (ob, kb) at index ob*KB + kb
     auto put_blocks = [&](const HostTensor* t, int OB, int KB) {
@@ -904,17 +934,17 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     for (int l = 0; l < L; ++l) {
         const std::string p = "graph_conv.conv." + std::to_string(l);
         // edge_affine = MLP(Eh, hidden_dim, hidden_layer=2): its inner width is MLP's default 128 (nn_module.py:25,95)
-        const HostTensor *ea0w = get(p + ".edge_affine.mlp_layer.0.weight", {128, Eh}), *ea0b = get(p + ".edge_affine.mlp_layer.0.bias", {128});
-        const HostTensor *ea2w = get(p + ".edge_affine.mlp_layer.2.weight", {128, 128}), *ea2b = get(p + ".edge_affine.mlp_layer.2.bias", {128});
-        const HostTensor *sw = get(p + ".src_affine.weight", {128, H}), *sb = get(p + ".src_affine.bias", {128});
-        const HostTensor *dw = get(p + ".dst_affine.weight", {128, H}), *db = get(p + ".dst_affine.bias", {128});
-        const HostTensor *t1w = get(p + ".theta_edge.mlp_layer.1.weight", {128, 128}), *t1b = get(p + ".theta_edge.mlp_layer.1.bias", {128});
-        const HostTensor *t3w = get(p + ".theta_edge.mlp_layer.3.weight", {H, 128}), *t3b = get(p + ".theta_edge.mlp_layer.3.bias", {H});
-        const HostTensor *pdw = get(p + ".phi_dst.weight", {128, H}), *pdb = get(p + ".phi_dst.bias", {128});
-        const HostTensor *pew = get(p + ".phi_edge.weight", {128, H}), *peb = get(p + ".phi_edge.bias", {128});
-        const HostTensor *phw = get(p + ".phi.mlp_layer.1.weight", {H, 128}), *phb = get(p + ".phi.mlp_layer.1.bias", {H});
-        const HostTensor *ng = get("graph_conv.norm_layers." + std::to_string(l) + ".weight", {H});
-        const HostTensor *nb = get("graph_conv.norm_layers." + std::to_string(l) + ".bias", {H});
+        const HostTensor *ea0w = get(p + ".edge_affine.mlp_layer.0.weight", {128, Et}, {128, Eh}), *ea0b = get(p + ".edge_affine.mlp_layer.0.bias", {128}, {128});
+        const HostTensor *ea2w = get(p + ".edge_affine.mlp_layer.2.weight", {Dt, 128}, {128, 128}), *ea2b = get(p + ".edge_affine.mlp_layer.2.bias", {Dt}, {128});
+        const HostTensor *sw = get(p + ".src_affine.weight", {Dt, Ht}, {128, H}), *sb = get(p + ".src_affine.bias", {Dt}, {128});
+        const HostTensor *dw = get(p + ".dst_affine.weight", {Dt, Ht}, {128, H}), *db = get(p + ".dst_affine.bias", {Dt}, {128});
+        const HostTensor *t1w = get(p + ".theta_edge.mlp_layer.1.weight", {Dt, Dt}, {128, 128}), *t1b = get(p + ".theta_edge.mlp_layer.1.bias", {Dt}, {128});
+        const HostTensor *t3w = get(p + ".theta_edge.mlp_layer.3.weight", {Ht, Dt}, {H, 128}), *t3b = get(p + ".theta_edge.mlp_layer.3.bias", {Ht}, {H});
+        const HostTensor *pdw = get(p + ".phi_dst.weight", {Dt, Ht}, {128, H}), *pdb = get(p + ".phi_dst.bias", {Dt}, {128});
+        const HostTensor *pew = get(p + ".phi_edge.weight", {Dt, Ht}, {128, H}), *peb = get(p + ".phi_edge.bias", {Dt}, {128});
+        const HostTensor *phw = get(p + ".phi.mlp_layer.1.weight", {Ht, Dt}, {H, 128}), *phb = get(p + ".phi.mlp_layer.1.bias", {Ht}, {H});
+        const HostTensor *ng = get("graph_conv.norm_layers." + std::to_string(l) + ".weight", {Ht}, {H});
+        const HostTensor *nb = get("graph_conv.norm_layers." + std::to_string(l) + ".bias", {Ht}, {H});
         if (!ea0w || !ea0b || !ea2w || !ea2b || !sw || !sb || !dw || !db || !t1w || !t1b || !t3w || !t3b || !pdw ||
             !pdb || !pew || !peb || !phw || !phb || !ng || !nb)
             return -2;
@@ -961,14 +991,14 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         for (int i = 0; i < 128; ++i) bb.host[o.bP + i] = pdb->data[i] + peb->data[i];
         o.wpep = put_node(pew, 1, (int)HT); o.wphip = put_node(phw, (int)HT, 1); o.bphi = put_vec(phb);
     }
-    const HostTensor *e0w = get("edge_encoder.mlp_layer.0.weight", {128, (int64_t)F}), *e0b = get("edge_encoder.mlp_layer.0.bias", {128});
-    const HostTensor *e2w = get("edge_encoder.mlp_layer.2.weight", {128, 128}), *e2b = get("edge_encoder.mlp_layer.2.bias", {128});
-    const HostTensor *e4w = get("edge_encoder.mlp_layer.4.weight", {Eh, 128}), *e4b = get("edge_encoder.mlp_layer.4.bias", {Eh});
-    const HostTensor *elg = get("edge_layer_norm.weight", {Eh}), *elb = get("edge_layer_norm.bias", {Eh});
-    const HostTensor *cen = expand ? get("edge_expand.centers", {40}) : nullptr;
-    const HostTensor *lm = get("length_mean", {1}), *ls = get("length_std", {1});
-    const HostTensor *d0w = get("graph_decoder.mlp_layer.0.weight", {128, H}), *d0b = get("graph_decoder.mlp_layer.0.bias", {128});
-    const HostTensor *d2w = get("graph_decoder.mlp_layer.2.weight", {3, 128}), *d2b = get("graph_decoder.mlp_layer.2.bias", {3});
+    const HostTensor *e0w = get("edge_encoder.mlp_layer.0.weight", {Dt, (int64_t)F}, {128, (int64_t)F}), *e0b = get("edge_encoder.mlp_layer.0.bias", {Dt}, {128});
+    const HostTensor *e2w = get("edge_encoder.mlp_layer.2.weight", {Dt, Dt}, {128, 128}), *e2b = get("edge_encoder.mlp_layer.2.bias", {Dt}, {128});
+    const HostTensor *e4w = get("edge_encoder.mlp_layer.4.weight", {Et, Dt}, {Eh, 128}), *e4b = get("edge_encoder.mlp_layer.4.bias", {Et}, {Eh});
+    const HostTensor *elg = get("edge_layer_norm.weight", {Et}, {Eh}), *elb = get("edge_layer_norm.bias", {Et}, {Eh});
+    const HostTensor *cen = expand ? get("edge_expand.centers", {40}, {40}) : nullptr;
+    const HostTensor *lm = get("length_mean", {1}, {1}), *ls = get("length_std", {1}, {1});
+    const HostTensor *d0w = get("graph_decoder.mlp_layer.0.weight", {Dt, Ht}, {128, H}), *d0b = get("graph_decoder.mlp_layer.0.bias", {Dt}, {128});
+    const HostTensor *d2w = get("graph_decoder.mlp_layer.2.weight", {3, Dt}, {3, 128}), *d2b = get("graph_decoder.mlp_layer.2.bias", {3}, {3});
     if (!e0w || !e0b || !e2w || !e2b || !e4w || !e4b || !elg || !elb || (expand && !cen) || !lm || !ls || !d0w || !d0b ||
         !d2w || !d2b)
         return -2;
@@ -983,16 +1013,17 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     // (layernorm_chain_centered; wide.hip's generic LayerNorm sees a mean of ~0 and is unaffected).
     HostTensor e4w_c = *e4w, e4b_c = *e4b;
     if (!bf16_edges && !f16x3_edges) {
+        // (the mean is over the Et true output rows; zero-padded rows stay zero)
         for (int64_t k = 0; k < 128; ++k) {
             double m = 0.0;
-            for (int64_t o = 0; o < Eh; ++o) m += (double)e4w->data[(size_t)(o * 128 + k)];
-            m /= (double)Eh;
-            for (int64_t o = 0; o < Eh; ++o) e4w_c.data[(size_t)(o * 128 + k)] = (float)((double)e4w->data[(size_t)(o * 128 + k)] - m);
+            for (int64_t o = 0; o < Et; ++o) m += (double)e4w->data[(size_t)(o * 128 + k)];
+            m /= (double)Et;
+            for (int64_t o = 0; o < Et; ++o) e4w_c.data[(size_t)(o * 128 + k)] = (float)((double)e4w->data[(size_t)(o * 128 + k)] - m);
         }
         double mb = 0.0;
-        for (int64_t o = 0; o < Eh; ++o) mb += (double)e4b->data[(size_t)o];
-        mb /= (double)Eh;
-        for (int64_t o = 0; o < Eh; ++o) e4b_c.data[(size_t)o] = (float)((double)e4b->data[(size_t)o] - mb);
+        for (int64_t o = 0; o < Et; ++o) mb += (double)e4b->data[(size_t)o];
+        mb /= (double)Et;
+        for (int64_t o = 0; o < Et; ++o) e4b_c.data[(size_t)o] = (float)((double)e4b->data[(size_t)o] - mb);
     }
     const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : f16x3_edges ? put_edge_f16x3(e4w) : put_blocks(&e4w_c, (int)EHT, 1);
     const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(&e4b_c), o_elg = put_vec(elg), o_elb = put_vec(elb);
@@ -1000,11 +1031,11 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     const size_t o_d1 = put_node(d0w, 1, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
     size_t o_emb = 0, o_nw = 0, o_nb = 0;
     if (h->cfg.kind == GAMD_KIND_LJ) {
-        const HostTensor* emb = get("node_emb", {1, H});
+        const HostTensor* emb = get("node_emb", {1, Ht}, {1, H});
         if (!emb) return -2;
         o_emb = put_vec(emb);
     } else {
-        const HostTensor *nw = get("node_encoder.weight", {H, 1}), *nb = get("node_encoder.bias", {H});
+        const HostTensor *nw = get("node_encoder.weight", {Ht, 1}, {H, 1}), *nb = get("node_encoder.bias", {Ht}, {H});
         if (!nw || !nb) return -2;
         o_nw = put_vec(nw); o_nb = put_vec(nb);
     }

@@ -369,8 +369,10 @@ __device__ __forceinline__ void exchange(float* xbuf, int quarter, int slot, int
 // The same for rows whose mean over the 128 features is zero BY CONSTRUCTION: the edge encoder's last Linear is packed
 // with its output rows centred (W - mean_rows(W), b - mean(b): gamd_finalize_weights), which is LayerNorm's mean
 // subtraction done once on the host instead of per edge (64 adds + 64 subtracts + a shuffle per 32 x 128 block).
+// inv_width = 1 / (true width): rows narrower than 128 are zero-padded (their outputs are exact zeros and add nothing to the sum)
 template <typename GPtr>
-__device__ __forceinline__ void layernorm_chain_centered(f32x16 (&X)[4], GPtr gamma, GPtr beta, int half, float eps) {
+__device__ __forceinline__ void layernorm_chain_centered(f32x16 (&X)[4], GPtr gamma, GPtr beta, int half, float eps,
+                                                         float inv_width = 1.0f / 128.0f) {
     // sum of squares per 32-feature block, then a fixed tree over the blocks: the order the small-system encoder
     // (one block per wave, edge_encode.hip) reproduces, so both give the same bits
     float vt[4];
@@ -380,7 +382,7 @@ __device__ __forceinline__ void layernorm_chain_centered(f32x16 (&X)[4], GPtr ga
 #pragma unroll
         for (int r = 0; r < 16; ++r) vt[t] = fmaf(X[t][r], X[t][r], vt[t]);
     }
-    const float var = gamd_xhalf_sum((vt[0] + vt[1]) + (vt[2] + vt[3])) * (1.0f / 128.0f);
+    const float var = gamd_xhalf_sum((vt[0] + vt[1]) + (vt[2] + vt[3])) * inv_width;
     const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int t = 0; t < 4; ++t)

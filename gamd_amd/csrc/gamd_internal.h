@@ -125,6 +125,9 @@ struct EncArgs {
     float box[3], half[3];
     BoxRef bx;                 // n_boxes > 1: the box of an edge is the box of its destination atom
     float length_mean, length_std, gamma;
+    // edge_layer_norm over the TRUE edge-embedding width: widths below the 128-blocks the kernels work in are zero-padded by
+    // gamd_finalize_weights (padded outputs are exact zeros); 1 / width and the number of padded features
+    float ln_inv_width, ln_n_pad;
     int n_feat;                // 44 or 45
     int n_ksteps;              // ceil(n_feat/2)
     const float* centers;      // [40]
@@ -211,6 +214,7 @@ struct NodeArgs {
     // decoder (mode 2)
     const float* dec_w1p; const float* dec_b1; const float* dec_w2; const float* dec_b2;   // w2: [3][128] plain
     float scale, shift;        // sqrt(var), mean of the force scaler (fp32 copy for the device path)
+    float ln_inv_width, ln_n_pad;   // graph_conv.norm_layers over the TRUE node width (zero-padded to the 128-blocks): 1 / width, #pad
     const int* perm;
     // outputs
     float* h_out;              // [n][128]

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         ps = group_sum(ps);
         if (g == 0) red[0][w][la] = ps;
         __syncthreads();
-        const float mean = ((red[0][0][la] + red[0][1][la]) + (red[0][2][la] + red[0][3][la])) * (1.0f / 128.0f);
+        const float mean = ((red[0][0][la] + red[0][1][la]) + (red[0][2][la] + red[0][3][la])) * a.ln_inv_width;
         float pv = 0.f;
 #pragma unroll
         for (int o = 0; o < 2; ++o)
@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         pv = group_sum(pv);
         if (g == 0) red[1][w][la] = pv;
         __syncthreads();
-        const float var = ((red[1][0][la] + red[1][1][la]) + (red[1][2][la] + red[1][3][la])) * (1.0f / 128.0f);
+        // zero-padded features (width < 128) each added mean^2 to the sum of squared deviations: taken out again (n_pad = 0: x - 0)
+        const float var = (((red[1][0][la] + red[1][1][la]) + (red[1][2][la] + red[1][3][la])) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width;
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         {
             f32x4 gg[2], bb[2];

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s1 += Y[ob][t][r];
-        const float mean = gamd_xhalf_sum(s1) * (1.0f / EH);
+        const float mean = gamd_xhalf_sum(s1) * a.ln_inv_width;
         float s2 = 0.f;
 #pragma unroll
         for (int ob = 0; ob < EHT; ++ob)
@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { const float dd = Y[ob][t][r] - mean; s2 += dd * dd; }
-        const float rstd = 1.0f / sqrtf(gamd_xhalf_sum(s2) * (1.0f / EH) + 1e-5f);
+        // (zero-padded features each added mean^2 to s2: taken out again)
+        const float rstd = 1.0f / sqrtf((gamd_xhalf_sum(s2) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width + 1e-5f);
         // self_loop_mode 1: the appended loop (last edge of its row) carries DGL's zero-filled embedding (nn_module.py:364)
         const bool zero_row = a.self_loop && valid && x == (long long)a.row_ptr[dst + 1] - 1;
         if (active) {
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         ps = gamd_xhalf_sum(ps);
         if (half == 0) red[0][quarter][slot] = ps;
         __syncthreads();
-        const float mean = ((red[0][0][slot] + red[0][1][slot]) + (red[0][2][slot] + red[0][3][slot])) * (1.0f / H);
+        const float mean = ((red[0][0][slot] + red[0][1][slot]) + (red[0][2][slot] + red[0][3][slot])) * a.ln_inv_width;
         float pv = 0.f;
 #pragma unroll
         for (int b = 0; b < HT; ++b)
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         pv = gamd_xhalf_sum(pv);
         if (half == 0) red[1][quarter][slot] = pv;
         __syncthreads();
-        const float var = ((red[1][0][slot] + red[1][1][slot]) + (red[1][2][slot] + red[1][3][slot])) * (1.0f / H);
+        const float var = (((red[1][0][slot] + red[1][1][slot]) + (red[1][2][slot] + red[1][3][slot])) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width;
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
         for (int b = 0; b < HT; ++b) {

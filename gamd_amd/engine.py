@@ -75,12 +75,16 @@ class GamdForce:
             raise _lib.GamdError("GamdForce needs a HIP device (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
         cfg = cfg or infer_config(state_dict)
-        if (cfg.encoding_size not in (128, 256) or cfg.edge_embedding_dim not in (128, 256) or cfg.hidden_dim != 128
+        # build_model's widths (nn_module.py:561-601): anything up to 256 / 128 / 256 — the library zero-pads to its 128-wide
+        # blocks and normalises over the true widths
+        if (not 1 <= cfg.encoding_size <= 256 or not 1 <= cfg.edge_embedding_dim <= 256 or not 1 <= cfg.hidden_dim <= 128
                 or cfg.n_rbf not in (0, 40)):
-            raise ValueError("the gfx950 kernels cover encoding_size / edge_embedding_dim in {128, 256}, hidden_dim 128 "
+            raise ValueError("the gfx950 kernels cover encoding_size / edge_embedding_dim up to 256, hidden_dim up to 128 "
                              "and the RBF expansion on (40 centres) or off "
                              f"(got enc={cfg.encoding_size} hidden={cfg.hidden_dim} edge={cfg.edge_embedding_dim} "
                              f"n_rbf={cfg.n_rbf})")
+        if edge_dtype != "f32" and (cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim) != (128, 128, 128):
+            raise ValueError("edge_dtype bf16 / f16x3 is built for the 128 / 128 / 128 configuration only")
         validate_state_dict(state_dict, cfg)
         self.cfg = cfg
         self.n = int(n_atoms)                          # atoms per box
@@ -299,7 +303,7 @@ class GamdForce:
                         feat = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half
                         out[rows, feat[None, :]] = val[:, t, u, :, j]
             return out[:e]
-        nb = self.cfg.edge_embedding_dim // 128
+        nb = (self.cfg.edge_embedding_dim + 127) // 128               # widths below a 128-block are zero-padded on the device
         frag = self._dbg(3, (nt, nb, 4, 4, 64, 4), np.float32)
         lane = np.arange(64)
         slot, half = lane & 31, lane >> 5
@@ -312,7 +316,7 @@ class GamdForce:
                     for j in range(4):
                         feat = 128 * b + 32 * t + 8 * q + 4 * half + j           # per lane
                         out[rows, feat[None, :]] = frag[:, b, t, q, :, j]
-        return out[:e]
+        return out[:e, :self.cfg.edge_embedding_dim]
 
     def debug_feat(self, n_feat: int) -> np.ndarray:
         e = self.counts()[0]
@@ -320,7 +324,8 @@ class GamdForce:
 
     def debug_h(self, layer: int) -> np.ndarray:
         """residual stream h_layer [N, encoding_size] in ORIGINAL atom order."""
-        hs = self._dbg(16 + layer, (self.n_total, self.cfg.encoding_size), np.float32)
+        hp = 128 * ((self.cfg.encoding_size + 127) // 128)
+        hs = self._dbg(16 + layer, (self.n_total, hp), np.float32)[:, :self.cfg.encoding_size]
         out = np.empty_like(hs)
         out[self.debug_perm()] = hs
         return out

@@ -244,3 +244,55 @@ def test_throughput_and_latency_kernels_agree_bit_for_bit_on_the_reference_snaps
         for a, b in zip(res[0], res[1]):
             assert np.array_equal(a, b), name
         assert rel_err(res[0][0], g["out_norm"]) < TOL
+
+
+# ---- widths other than 128 / 256 (build_model accepts any: nn_module.py:561-601; --hidden_dim, LJ/train_network_lj.py:395) ----
+def test_reduced_width_golden_runs_on_the_gpu():
+    """tests/golden/lj64_h32: encoding 32 / hidden 32 / edge embedding 32, 2 layers, the reference's own outputs.  The library
+    zero-pads to its 128-wide blocks and normalises over the true widths; every stage within 1e-5."""
+    g, cfg, sd = load_golden("lj64_h32")
+    assert (cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim, cfg.conv_layer) == (32, 32, 32, 2)
+    box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+    for kw in (dict(), dict(small_tile_limit=-1), dict(kernel_select=1)):          # latency, throughput and generic-width kernels
+        eng = _engine(sd, n, box, rc, scaler=(g["scaler_mean"], g["scaler_var"]), keep_stages=True, **kw)
+        posw = np.mod(g["pos"], box).astype(np.float32)
+        out = eng.forward(torch.from_numpy(posw)).cpu().numpy()
+        edges = eng.debug_edges()
+        assert np.array_equal(edge_set(edges), edge_set(g["edge_idx"]))
+        s = int(g["edge_stride"])
+        gkey = g["edge_idx"][0].astype(np.int64) * n + g["edge_idx"][1]
+        pos_of = {k: i for i, k in enumerate(edges[0] * n + edges[1])}
+        rows = np.array([pos_of[k] for k in gkey[::s]])
+        e = eng.debug_e()
+        assert e.shape[1] == 32 and rel_err(e[rows], g["e_rows"]) < TOL, kw
+        for l in range(g["h_layers"].shape[0]):
+            h = eng.debug_h(l)
+            assert h.shape == (n, 32) and rel_err(h, g["h_layers"][l]) < TOL, (kw, l)
+        assert rel_err(out, g["out_norm"]) < TOL, kw
+        eng.close()
+
+
+@pytest.mark.parametrize("enc,hid,emb,kind", [(96, 64, 128, "lj"), (128, 100, 200, "water"), (200, 128, 72, "water"), (256, 48, 256, "lj")])
+def test_odd_widths_against_the_oracle(enc, hid, emb, kind):
+    """Widths that are neither 128 nor 256, mixed: the oracle (pinned by the reduced-width and the wide goldens) on seeded
+    weights, through the specialised kernels (enc, emb <= 128) or the generic-width ones."""
+    cfg = ModelConfig(kind=kind, encoding_size=enc, hidden_dim=hid, edge_embedding_dim=emb, conv_layer=3, use_bond=kind == "water")
+    sd = make_state_dict(cfg, 21, 2.9, 1.1)
+    if kind == "water":
+        pos, box, species, bonds = workloads.water_box(100, seed=8)
+        feat, rc = torch.from_numpy(species.astype(np.float32)).view(-1, 1), 4.2
+    else:
+        pos, box = workloads.lj_box(300, seed=8)
+        species = bonds = feat = None
+        rc = 7.5
+    n = pos.shape[0]
+    eng = _engine(sd, n, box, rc, bond=bonds)
+    p = torch.from_numpy(pos).float()
+    out = eng.forward(p, species=species).cpu().numpy()
+    edges = orc.neighbor_edges(torch.remainder(p, float(box)), box, rc, "jaxmd")
+    assert np.array_equal(edge_set(eng.debug_edges()), edge_set(edges.numpy()))
+    ref = orc.forward(sd, torch.remainder(p, float(box)), edges, box, feat=feat, bond=bonds).numpy()
+    assert rel_err(out, ref) < TOL
+    med, p99, worst, cnt = per_atom_err(out, ref)
+    assert p99 < P99_TOL, (med, p99, worst)
+    eng.close()
