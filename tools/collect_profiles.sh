@@ -4,7 +4,7 @@
 set -eu
 src=gpurun_out/$1; dst=profiles; name=$2
 hdr='`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --steps 50 --warmup 5 --workload <w>` (tools/gpu_profile_round.sh)'
-for w in c1 c2 c3 c5 c5b dft; do { echo "# $name — $hdr"; echo; cat $src/trace_$w.md; } > $dst/${name}_trace_$w.md; done
+for w in c1 c1_batch c2 c3 c5 c5b dft; do { echo "# $name — $hdr"; echo; cat $src/trace_$w.md; } > $dst/${name}_trace_$w.md; done
 for w in c2 c5; do cp $src/pmc_$w.md $dst/${name}_pmc_$w.md; done
 tail -1 $src/bench_default.json > $dst/${name}_bench_default.json
 tail -1 $src/bench_f16x3.json > $dst/${name}_bench_f16x3.json

@@ -9,7 +9,7 @@ cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 B="python3 bench.py --no-cpu-baseline --no-secondary"
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --no-cpu-baseline --no-secondary --edge-dtype f16x3 > $out/bench_f16x3.json 2>> $out/bench_default.err
-for w in c2 c3 c5 c5b c1 dft; do
+for w in c2 c3 c5 c5b c1 c1_batch dft; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -- $B --steps 50 --warmup 5 --workload $w > $out/trace_$w.log 2>&1
   python3 tools/profile_summary.py stats $out/trace_$w > $out/trace_$w.md
 done
