@@ -5,7 +5,10 @@
      bit-identical (the conv kernel's counted waits and register hand-offs are what a race would break), finite, and the
      skin engine's forces must match an exact-rebuild engine on the final positions;
   2. C3 rigid water, 3 000 steps: finite, bond lengths kept by SETTLE;
-  3. C5 bf16, 3 000 steps: finite, forces within the restated tolerance of the fp32 path on the final positions."""
+  3. C5 bf16, 3 000 steps: finite, forces within the restated tolerance of the fp32 path on the final positions;
+  4. C2 split-fp16 (f16x3), 2 000 steps run TWICE: bit-identical (its weight copies are issued from inline assembly and
+     waited for by hand: a missing wait shows as a run-to-run difference), forces within 1e-5 of the fp32 path at the end;
+  5. a batch of 38 x 258-atom boxes, 2 000 steps run TWICE: bit-identical, every box finite, COM drift removed when asked."""
 import hashlib
 import os
 import sys
@@ -79,3 +82,43 @@ fb = engb.forward(x, species=species, denormalize=True)
 err = float((f32 - fb).abs().max() / f32.abs().max())
 print(f"water bf16: 3000 steps finite={bool(torch.isfinite(x).all())} bf16-vs-f32 force err on the final positions={err:.2e}")
 assert torch.isfinite(x).all() and err < 1e-2
+
+
+# ---- 4. split-fp16 determinism ---------------------------------------------------------------------------------------
+runs = []
+for rep in range(2):
+    eng = GamdForce(sd, 10000, box, 10.2, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=1.7, edge_dtype="f16x3")
+    x = torch.from_numpy(pos).float().cuda()
+    v = torch.from_numpy(wk.maxwell_boltzmann(10000, 300.0)).float().cuda()
+    f = eng.forward(x, denormalize=True).clone()
+    for chunk in range(4):
+        eng.md_run(x, v, f, 500, temperature_k=300.0, first_step=chunk * 500)
+    runs.append((sha(x), sha(v), sha(f)))
+    if rep == 0:
+        ref = GamdForce(sd, 10000, box, 10.2, scaler=SHIPPED_SCALERS["lj"])
+        f32 = ref.forward(x, denormalize=True)
+        err = float((f32 - eng.forward(x, denormalize=True)).abs().max() / f32.abs().max())
+        ref.close()
+    eng.close()
+print(f"LJ f16x3: two 2000-step runs bit-identical: {runs[0] == runs[1]}; f16x3-vs-f32 force err on the final positions={err:.2e}")
+assert runs[0] == runs[1] and err < 1e-5
+
+# ---- 5. batched boxes --------------------------------------------------------------------------------------------------
+nb = 38
+snap = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lj258_seed0.npz"))["pos"]
+rng = np.random.default_rng(3)
+posb = np.concatenate([np.mod(snap + (rng.normal(0, 0.17, snap.shape) if b else 0.0), 27.27) for b in range(nb)])
+runs = []
+for rep in range(2):
+    eng = GamdForce(sd, 258, 27.27, 7.5, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=1.25, n_boxes=nb)
+    x = torch.from_numpy(posb).float().cuda()
+    v = torch.from_numpy(wk.maxwell_boltzmann(nb * 258, 300.0)).float().cuda()
+    f = eng.forward(x, denormalize=True).clone()
+    for chunk in range(4):
+        eng.md_run(x, v, f, 500, temperature_k=300.0, first_step=chunk * 500, seed=9, remove_cm_motion=True)
+    runs.append((sha(x), sha(v), sha(f)))
+    vcom = v.view(nb, 258, 3).mean(dim=1).abs().max().item()
+    eng.close()
+print(f"LJ batch {nb} x 258: two 2000-step runs bit-identical: {runs[0] == runs[1]}; finite={bool(torch.isfinite(x).all())}; "
+      f"largest per-box COM speed {vcom:.3e} A/ps")
+assert runs[0] == runs[1] and torch.isfinite(x).all() and vcom < 0.1
