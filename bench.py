@@ -159,9 +159,10 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         cfg = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
         w.sd = make_state_dict(cfg, 5, 3.1 * bohr, 1.2 * bohr)
         mean, var = SHIPPED_SCALERS["dft"]
-        w.eng = GamdForce(w.sd, pos.shape[0], box, 9.5, nbr_flavour="torch", cfg=cfg, device=dev,
+        w.eng = GamdForce(w.sd, pos.shape[0], box, 9.5, nbr_flavour="torch", cfg=cfg, device=dev, neighbor_skin=skin * 9.5,
                           scaler=(mean * CONV, var * CONV ** 2))        # hartree/bohr -> kJ/mol/nm folded into the scaler
         w.cutoff = 9.5
+        w.uses_skin = skin > 0
         w.mass = wk.MASS_O
         w.md_extra = dict(mass_h_amu=wk.MASS_H, length_per_nm=wk.BOHR_PER_NM, rigid_water=True,
                           r_oh=wk.TIP3P_R_OH * bohr, r_hh=wk.TIP3P_R_HH * bohr)
@@ -383,7 +384,9 @@ def main():
         print(f"bench.py: rank {ctx.rank} failing on purpose (GAMD_BENCH_FAIL_RANK)", file=sys.stderr)
         os._exit(3)
 
-    skin = args.skin if args.workload != "dft" else 0.0          # md_module.get_neighbor searches from scratch every call
+    # (the dft workload's reference, md_module.get_neighbor, searches from scratch every call; the Verlet-skin path yields
+    # the same edge SET — tests/test_gpu_round4.py — so the MD loop uses it there too)
+    skin = args.skin
     w = build_workload(args.workload, ctx, dev, skin, args.edge_dtype)
     dt, dt_max, conv_ms, conv_n = timed_run(w, args.steps, args.warmup, ctx, dev, ddev)
     n_edges = w.eng.counts()[0]
@@ -493,7 +496,7 @@ def main():
         # C2 and the DFT-water configuration, 20 timed steps each
         for name, wname, dt_name in (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c3", "c3", "f32"), ("c5", "c5", "f32"),
                                      ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("dft", "dft", "f32")):
-            s = build_workload(wname, ctx, dev, args.skin if wname != "dft" else 0.0, dt_name)
+            s = build_workload(wname, ctx, dev, args.skin, dt_name)
             sdt, _, sconv_ms, sconv_n = timed_run(s, 20, 5, ctx, dev, ddev)
             se = s.eng.counts()[0]
             ok = bool(torch.isfinite(s.x).all().item() and torch.isfinite(s.f).all().item())

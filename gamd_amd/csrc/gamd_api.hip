@@ -97,6 +97,7 @@ struct gamd_handle {
     int dev = 0;
     int n = 0, L = 0, n_feat = 44, n_cu = 256;   // n: atoms of ALL boxes together (n_boxes * n_per_box)
     int n_boxes = 1, n_per_box = 0;              // gamd_config.n_boxes: independent boxes evaluated in one set of launches
+    bool use_small = false;                      // skin mode: the single-workgroup small-system path of neighbor.hip (decided once)
     DevBuf boxes_dev, box_shift;                 // n_boxes > 1: per-box dimensions (BoxRef::boxes), scratch of the row scan
     std::vector<float> boxes_host;               // [n_boxes][3] as last set
     int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width (PADDED to 128-blocks) and their block counts
@@ -160,7 +161,7 @@ struct gamd_handle {
 namespace {
 
 // batches never take the single-workgroup small-system path of neighbor.hip (k_step_small / k_filter_fill_small)
-bool small_path(const gamd_handle* h) { return h->n <= 1024 && h->n_boxes <= 1; }
+bool small_path(const gamd_handle* h) { return h->use_small; }
 
 BoxRef box_ref(const gamd_handle* h) {
     BoxRef r{};
@@ -831,6 +832,15 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         for (int b = 0; b < n_boxes; ++b)
             for (int d = 0; d < 3; ++d) all[(size_t)3 * b + d] = cfg->box[d];
         if ((r = set_box(h, all.data()))) { gamd_destroy(h); return r; }
+    }
+    {
+        // Small-system path (k_step_small: skin check, integrator halves and — on the steps that need it — the whole candidate
+        // rebuild in ONE workgroup): worth it while a rebuild is cheap.  The in-kernel rebuild tests every atom against the
+        // atoms of its 27 cells on a single CU: ~n x min(n, 27 n / cells) pair tests, 0.17 ms for the 258-atom LJ box but 1.5 ms
+        // for 774 atoms in a box of 3 cells per axis (the DFT-water configuration, which rebuilds every ~5 steps).  Beyond
+        // ~3e5 pair tests the grid-wide kernels take over (three more launches per step, rebuilds spread over the chip).
+        const double per_atom = std::min<double>(h->n, 27.0 * h->n / std::max(1, h->ncell));
+        h->use_small = h->n <= 1024 && n_boxes <= 1 && (double)h->n * per_atom <= 3.0e5;
     }
     long long ecap = cfg->edge_capacity;
     if (ecap <= 0) {

@@ -511,6 +511,8 @@ __global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) 
 //   wrap + displacement check, positions into the sorted order, clear of the other counter block
 //   the seven phases of the candidate rebuild, behind a workgroup-wide OR of the check (runs once in 50-100 steps),
 // with workgroup barriers where the large-system path has kernel boundaries: 1 launch instead of 11.
+constexpr int SMALL_CELLS_LDS = 2047;      // cell bounds of the small-system rebuild kept in LDS up to this many cells
+
 __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int do_second, int do_first) {
     const int tid = threadIdx.x;
     if (do_second | do_first) {
@@ -555,11 +557,25 @@ __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int d
     __syncthreads();
     for (int k = tid >> 6; k < c.ncell; k += 16) d_sort_gather(c, k, tid & 63);
     __syncthreads();
-    for (int base = 0; base < c.n; base += 32) d_count(c, base + (tid >> 5), tid & 31);
+    // The two sweeps below visit 27 cells per atom, 32 atoms at a time, and every visit is two dependent loads (cell bounds ->
+    // positions): ~1 350 serialized L2 round trips for 774 atoms = 1.5 ms per rebuild when they go to global memory (the
+    // DFT-water box rebuilds every ~5 steps).  From an LDS copy of the sorted positions and the cell bounds a visit costs an
+    // LDS round trip instead.  (Flat pointers into LDS: the sweep code is shared with the grid-wide kernels.)
+    __shared__ float4 s_pos[1024];
+    __shared__ int s_cell_start[SMALL_CELLS_LDS + 1];
+    NbrArgs cl = c;
+    if (c.ncell <= SMALL_CELLS_LDS) {
+        if (tid < c.n) s_pos[tid] = c.pos_s[tid];
+        for (int k = tid; k <= c.ncell; k += 1024) s_cell_start[k] = c.cell_start[k];
+        __syncthreads();
+        cl.pos_s = s_pos;
+        cl.cell_start = s_cell_start;
+    }
+    for (int base = 0; base < c.n; base += 32) d_count(cl, base + (tid >> 5), tid & 31);
     __syncthreads();
     d_scan_deg(c);
     __syncthreads();
-    for (int base = 0; base < c.n; base += 32) d_fill(c, base + (tid >> 5), tid & 31);
+    for (int base = 0; base < c.n; base += 32) d_fill(cl, base + (tid >> 5), tid & 31);
 }
 
 // exact cutoff on the candidate rows: one half-wave per centre atom, candidates keep their order
@@ -892,7 +908,7 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
 int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     hipError_t e;
     const int tb = 256, gb = (a.n + tb - 1) / tb, ga = (a.n + 7) / 8;
-    if (a.counters_next && a.n <= 1024 && a.bx.n_boxes <= 1) {
+    if (a.counters_next && a.cand_stride == 0) {           // the host's choice (gamd_api.hip: small_path)
         // small system (n <= 1024): 3 launches and no memset node instead of 13 + 1 (+ 2 integrator launches): counters
         // ping-pong, cell arrays cleared inside the rebuild, integrator halves folded in
         MdArgs md{};

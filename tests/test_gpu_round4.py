@@ -296,3 +296,28 @@ def test_odd_widths_against_the_oracle(enc, hid, emb, kind):
     med, p99, worst, cnt = per_atom_err(out, ref)
     assert p99 < P99_TOL, (med, p99, worst)
     eng.close()
+
+
+def test_dft_configuration_with_skin_reuse_in_the_md_loop():
+    """The DFT-water model's reference searches neighbours from scratch every call (md_module.get_neighbor: <=, no self
+    edges); the Verlet-skin path applies the same test to a candidate list, so the edge set is the same — checked along a
+    rigid-water MD run of the shipped DFT widths against the exact engine and the reference-pinned oracle search."""
+    g, cfg, sd = load_golden("dynbox384_dftcfg_seed5")
+    n, rc, box = g["pos"].shape[0], float(g["cutoff"]), g["box"]
+    species = g["node_feat"].reshape(-1) != 0
+    skin = _engine(sd, n, box, rc, nbr_flavour="torch", cfg=cfg, neighbor_skin=rc / 6.0, scaler=(0.0, 25.0))
+    exact = _engine(sd, n, box, rc, nbr_flavour="torch", cfg=cfg, scaler=(0.0, 25.0))
+    x = torch.from_numpy(g["pos"]).float().cuda()
+    assert rel_err(skin.forward(x, box=box, species=species).cpu().numpy(), g["out_norm"]) < TOL
+    v = torch.from_numpy(np.random.default_rng(0).normal(0, 3.0, (n, 3))).float().cuda()
+    f = skin.forward(x, box=box, species=species, denormalize=True).clone()
+    for chunk in range(6):
+        skin.md_run(x, v, f, 20, dt_ps=0.001, mass_amu=workloads.MASS_O, mass_h_amu=workloads.MASS_H, temperature_k=300.0,
+                    seed=2, first_step=20 * chunk, species=species, box=box)
+        ref_f = exact.forward(x, box=box, species=species, denormalize=True).cpu().numpy()
+        assert np.array_equal(edge_set(skin.debug_edges()), edge_set(exact.debug_edges())), chunk
+        ref_edges = orc.neighbor_edges(torch.remainder(x.cpu(), torch.from_numpy(box)), box, rc, "torch").numpy()
+        assert np.array_equal(edge_set(skin.debug_edges()), edge_set(ref_edges)), chunk
+        assert rel_err(f.cpu().numpy(), ref_f) < TOL, chunk
+    assert skin.skin_stats()[0] >= 2
+    skin.close(); exact.close()
