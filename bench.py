@@ -71,7 +71,7 @@ def parse_args():
                          "list uses 1/6, graph_utils.py:24, and so does the default here); 0 = exact cell-list rebuild "
                          "every step.  The edge set is identical either way (not used by the dft workload, whose reference "
                          "searches from scratch every call)")
-    ap.add_argument("--edge-dtype", default="f32", choices=["f32", "f16x3"],
+    ap.add_argument("--edge-dtype", default="f32", choices=["f32", "f16x3", "bf16"],
                     help="c2 / c3. f32 (default, the headline): fp32 MFMA, bit-exact fp32 FMAs.  f16x3: the same GEMMs on the "
                          "fp16 matrix pipe with every operand split into hi + lo fp16 (3 MFMAs per product term, fp32 "
                          "accumulate): fp32-grade results (same 1e-5 parity bar), 3/16 of the fp32 matrix time")
@@ -191,6 +191,8 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         w.uses_skin = skin > 0
         if edge_dtype == "f16x3":
             w.dtype_name, w.kernel_name = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)", "k_conv_edge_f16x3"
+        elif edge_dtype == "bf16":
+            w.dtype_name, w.kernel_name = "bf16", "k_conv_edge_bf16"
         w.dt_ps = 0.002
         w.label = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
                    "random-init weights (seed 0), 1 box per GPU") if name == "c2" else \
@@ -492,10 +494,11 @@ def main():
     if single and not args.no_secondary and args.workload == "c2":
         sec = {}
         w.eng.close()
-        # (entry, workload, edge dtype): the other single-GPU BASELINE configs, the batched C1, the opt-in split-fp16 run of
-        # C2 and the DFT-water configuration, 20 timed steps each
+        # (entry, workload, edge dtype): the other single-GPU BASELINE configs, the batched C1, the opt-in split-fp16 and bf16
+        # runs of C2 (c2_bf16: the north star's neighbour-gather figure on the 10k-atom LJ box itself, tolerance restated as
+        # for config 5) and the DFT-water configuration, 20 timed steps each
         for name, wname, dt_name in (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c3", "c3", "f32"), ("c5", "c5", "f32"),
-                                     ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("dft", "dft", "f32")):
+                                     ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("c2_bf16", "c2", "bf16"), ("dft", "dft", "f32")):
             s = build_workload(wname, ctx, dev, args.skin, dt_name)
             sdt, _, sconv_ms, sconv_n = timed_run(s, 20, 5, ctx, dev, ddev)
             se = s.eng.counts()[0]

@@ -286,8 +286,50 @@ __device__ void d_scan_deg_fast(const NbrArgs& a) {
     int f[IPT], rp[IPT], mine2 = 0;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) { rp[k] = run; run += v[k]; }
-    if (a.cand_pass == 0 && a.bx.n_boxes > 1) {
-        // publish the plain offsets, align the boxes' first rows in global memory (d_box_align), take the result back
+    if (a.cand_pass == 0 && a.bx.n_boxes > 1 && a.bx.n_boxes <= 1024) {
+        // box alignment (see d_box_align) without leaving the workgroup: box starts -> LDS, thread b owns box b's padding,
+        // one more block scan over the boxes, the shifts applied to the rows still in registers
+        __shared__ int s_bstart[1025], s_bshift[1025];
+        __shared__ int s_ptot[16];
+        const int nb = a.bx.n_boxes, npb = a.bx.n_per_box;
+        int bk = i0 < a.n ? gamd_box_of(a.bx, i0) : nb;          // box of row i0; rows are consecutive, boxes follow
+        int nextb = (bk + 1) * npb;
+        {
+            int b = bk, nx = nextb;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const int i = i0 + k;
+                if (i < a.n) { if (i == nx) { ++b; nx += npb; } if (i == b * npb) s_bstart[b] = rp[k]; }
+            }
+        }
+        if (tid == 0) s_bstart[nb] = E_all;
+        __syncthreads();
+        const int pad = (tid + 1 < nb) ? ((-(s_bstart[tid + 1] - s_bstart[tid])) & (GAMD_CHUNK - 1)) : 0;
+        int px = pad;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(px, d, 64); if (lane >= d) px += y; }
+        if (lane == 63) s_ptot[wv] = px;
+        __syncthreads();
+        int pbase = px - pad, ptotal = 0;
+        for (int w = 0; w < 16; ++w) { const int t = s_ptot[w]; if (w < wv) pbase += t; ptotal += t; }
+        if (tid < nb) s_bshift[tid] = pbase;
+        if (tid == 0) s_bshift[nb] = ptotal;
+        __syncthreads();
+        {
+            int b = bk, nx = nextb;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const int i = i0 + k;
+                if (i < a.n) {
+                    if (i == nx) { ++b; nx += npb; }
+                    rp[k] += s_bshift[b];
+                    if (i == nx - 1) { v[k] += s_bshift[b + 1] - s_bshift[b]; a.deg[i] = v[k]; }
+                }
+            }
+        }
+        E_all += ptotal;
+    } else if (a.cand_pass == 0 && a.bx.n_boxes > 1) {
+        // (more than 1 024 boxes) publish the plain offsets, align the boxes' first rows in global memory, take the result back
 #pragma unroll
         for (int k = 0; k < IPT; ++k) if (i0 + k < a.n) a.row_ptr[i0 + k] = rp[k];
         if (tid == 0) a.row_ptr[a.n] = E_all;
