@@ -28,6 +28,7 @@
 // (pack16 in gamd_api.hip):  Wp[((ob * 8 + blk) * 64 + lane)][r] = W[16 ob + (lane & 15)][16 blk + 4 (lane >> 4) + r].
 #include "gamd_common.h"
 #include "gamd_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -54,7 +55,8 @@ __device__ __forceinline__ void load_whalf(const float* __restrict__ Wp, int w, 
 
 // acc[o] (features 16 (2 w + o) + 4 g + r of atom a) += W[quarter w][:, K half] * X^T; the two row blocks alternate so that
 // the two dependent accumulator chains (40-cycle latency, 32-cycle issue) keep the pipe full
-__device__ __forceinline__ void gemm16_half(const WHalf& h, int half, const f32x4 (&XB)[8], f32x4 (&acc)[2]) {
+__device__ __forceinline__ void gemm16_half(const WHalf& h, int half, const f32x4 (&XB)[8], f32x4 (&acc)[2], bool skip = false) {
+    if (skip) { asm volatile("" ::"v"(h.w[0]), "v"(h.w[7]), "v"(XB[0])); return; }
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -67,13 +69,13 @@ __device__ __forceinline__ void gemm16_half(const WHalf& h, int half, const f32x
 // One 128x128 GEMM.  On entry `wn` holds (or has in flight) the FIRST K half of this GEMM's weights W; on exit it holds the
 // first half of `next` (the matrix of the GEMM that follows; NEXT = false: none).  The compiler barriers pin the fetches
 // where they are written: hipcc otherwise hoists every load to the top of the kernel and pays with 50 more registers.
-template <bool NEXT>
+template <bool NEXT, bool SKIP = false>
 __device__ __forceinline__ void gemm16(const float* W, const float* next, WHalf& wn, const f32x4 (&XB)[8], f32x4 (&acc)[2], int w, int lane) {
     WHalf cur = wn;
     asm volatile("" ::: "memory");
     load_whalf(W, w, lane, 1, wn);                          // second half: lands during the first half's 32 MFMAs
     asm volatile("" ::: "memory");
-    gemm16_half(cur, 0, XB, acc);
+    gemm16_half(cur, 0, XB, acc, SKIP);
     __builtin_amdgcn_sched_barrier(0);
     cur = wn;
     if (NEXT) {
@@ -81,7 +83,7 @@ __device__ __forceinline__ void gemm16(const float* W, const float* next, WHalf&
         load_whalf(next, w, lane, 0, wn);                   // next GEMM's first half: lands during the second half + exchange
         asm volatile("" ::: "memory");
     }
-    gemm16_half(cur, 1, XB, acc);
+    gemm16_half(cur, 1, XB, acc, SKIP);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -110,6 +112,9 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// NABL (profiling build only, GAMD_NODE_VARIANT; wrong results): 1 = no piece loads (agg = 0: the bound of letting the conv kernels
+// write agg), 2 = every weight fragment from one cache-hot kilobyte (the bound of any better weight prefetch), 4 = no GEMMs
+template <int NABL>
 __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) float xbuf[NT * XLD];
     __shared__ float obuf[4][NT][3];
@@ -132,6 +137,10 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
 #define NMARK(I) do { } while (0)
 #endif
     NMARK(0);                                                      // 0: start
+    if (NABL & 2) {       // one hot kilobyte for every weight fragment
+        const float* hot = a.pre.wsp;
+        a.post.wpep = a.post.wphip = a.pre.wsp = a.pre.wdp = a.pre.wpdp = a.dec_w1p = hot;
+    }
     f32x4 XB[8];          // full activation rows (chain16 layout)
     f32x4 mine[2];        // this wave's 32 output features
     WHalf wn;             // the weight half that the next 32 MFMAs need (fetched one half ahead)
@@ -162,7 +171,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         f32x4 p_in[2], h_res[2];
         load16(a.P_in + row, w, g, p_in);                          // in flight during the aggregation
         // pieces are fetched in batches of 8 (one memory round trip for the usual 4-6 pieces per atom), summed in piece order
-        for (int k0 = 0; __any(k0 < np); k0 += 8) {
+        for (int k0 = 0; !(NABL & 1) && __any(k0 < np); k0 += 8) {
             f32x4 pc[8][2];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = agg
         NMARK(2);                                                  // 2: exchange 1
         mine[0] = p_in[0]; mine[1] = p_in[1];
-        gemm16<true>(a.post.wpep, a.post.wphip, wn, XB, mine, w, lane);
+        gemm16<true, (NABL & 4) != 0>(a.post.wpep, a.post.wphip, wn, XB, mine, w, lane);
         NMARK(3);                                                  // 3: GEMM phi_edge
 #pragma unroll
         for (int o = 0; o < 2; ++o)
@@ -189,7 +198,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         NMARK(4);                                                  // 4: SiLU + exchange 2
         load16(a.post.bphi, w, g, mine);
         load16(a.h_in + row, w, g, h_res);                        // residual: lands during the GEMM
-        gemm16<true>(a.post.wphip, a.mode != 2 ? a.pre.wsp : a.dec_w1p, wn, XB, mine, w, lane);
+        gemm16<true, (NABL & 4) != 0>(a.post.wphip, a.mode != 2 ? a.pre.wsp : a.dec_w1p, wn, XB, mine, w, lane);
         mine[0] += h_res[0]; mine[1] += h_res[1];                 // residual
         if (valid) store16(a.h_out + row, w, g, mine);
         NMARK(5);                                                  // 5: GEMM phi + residual
@@ -242,16 +251,16 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
             }
         }
         load16(a.pre.bS, w, g, mine);
-        gemm16<true>(a.pre.wsp, a.pre.wdp, wn, XB, mine, w, lane);
+        gemm16<true, (NABL & 4) != 0>(a.pre.wsp, a.pre.wdp, wn, XB, mine, w, lane);
         if (valid) store16(a.S_out + row, w, g, mine);
         NMARK(7);                                                  // 7: GEMM S
         mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         mine[1] = mine[0];
-        gemm16<true>(a.pre.wdp, a.pre.wpdp, wn, XB, mine, w, lane);
+        gemm16<true, (NABL & 4) != 0>(a.pre.wdp, a.pre.wpdp, wn, XB, mine, w, lane);
         if (valid) store16(a.D_out + row, w, g, mine);
         NMARK(8);                                                  // 8: GEMM D
         load16(a.pre.bP, w, g, mine);
-        gemm16<false>(a.pre.wpdp, nullptr, wn, XB, mine, w, lane);
+        gemm16<false, (NABL & 4) != 0>(a.pre.wpdp, nullptr, wn, XB, mine, w, lane);
         if (valid) store16(a.P_out + row, w, g, mine);
         NMARK(9);                                                  // 9: GEMM P
 #ifdef GAMD_PROFILING
@@ -264,7 +273,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         // ---- decoder: Lin(128,128) GELU Lin(128,3); denormalise -------------------------------
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = h'
         load16(a.dec_b1, w, g, mine);
-        gemm16<false>(a.dec_w1p, nullptr, wn, XB, mine, w, lane);
+        gemm16<false, (NABL & 4) != 0>(a.dec_w1p, nullptr, wn, XB, mine, w, lane);
         float o3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
@@ -305,7 +314,19 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
 
 int launch_node(const NodeArgs& a, hipStream_t st) {
     const int nb = (a.n + NT - 1) / NT;
-    hipLaunchKernelGGL(k_node, dim3(nb), dim3(256), 0, st, a);
+#ifdef GAMD_PROFILING
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GAMD_NODE_VARIANT"); v = e ? atoi(e) : 0; }
+    switch (v) {
+        case 1: hipLaunchKernelGGL(k_node<1>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 2: hipLaunchKernelGGL(k_node<2>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 3: hipLaunchKernelGGL(k_node<3>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 4: hipLaunchKernelGGL(k_node<4>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 7: hipLaunchKernelGGL(k_node<7>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        default: break;
+    }
+#endif
+    hipLaunchKernelGGL(k_node<0>, dim3(nb), dim3(256), 0, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -28,7 +28,7 @@ def resources():
 def test_every_kernel_family_is_present(resources):
     names = " ".join(resources)
     for k in ("k_conv_edge<", "k_conv_edge_small<", "k_conv_edge_bf16", "k_conv_edge_f16x3", "k_conv_edge_wide<2, 2>",
-              "k_edge_encode<44", "k_edge_encode_small<45", "k_edge_encode_wide<44, 2>", "k_edge_encode_wide<4, 2>", "k_node(",
+              "k_edge_encode<44", "k_edge_encode_small<45", "k_edge_encode_wide<44, 2>", "k_edge_encode_wide<4, 2>", "k_node<0>",
               "k_node_wide<2>", "k_skin_check", "k_filter<true>", "k_com_partial"):
         assert k in names, k
     assert len(resources) >= 55
@@ -47,5 +47,5 @@ def test_register_budgets_match_the_occupancy_the_kernels_are_written_for(resour
         assert hit, prefix
         return max(v["vgpr_count"] + v.get("agpr_count", 0) for v in hit)
     assert regs("k_conv_edge<") <= 256 and regs("k_edge_encode<") <= 256 and regs("k_conv_edge_bf16") <= 256
-    assert regs("k_node(") <= 168
+    assert regs("k_node<") <= 168
     assert regs("k_conv_edge_f16x3") <= 512
