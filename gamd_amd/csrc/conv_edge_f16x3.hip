@@ -8,6 +8,7 @@
 // itself at ~7 000 cycles per 4-tile round (LDS operand feed + SiLU/split VALU), memory-instruction issue comes next.
 #include "gamd_f16x3.h"
 #include "gamd_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -121,6 +122,8 @@ __device__ __forceinline__ void load_e_piece(const float* __restrict__ e_frag, i
 // One wave per SIMD (256-thread workgroups, the whole 512-entry register file per wave): the operand sets, the
 // accumulators and all gathered rows of a tile stay in registers without spilling, and every gather is issued a full
 // GEMM ahead of its use.  (Two waves per SIMD at 256 registers each spill ~100 registers and are slower.)
+// TIME (profiling build, GAMD_F16X3_TIME=1): s_memtime between the segments of a tile, summed per wave -> a.tdbg[block][wave][16]
+template <bool TIME>
 __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
     if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     constexpr int NW = 4;
@@ -172,6 +175,10 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
     __syncthreads();
     unsigned pend_ends = 0;           // piece stores of the tile just finished (issued after its last barrier)
     int pend_p = 0;
+    long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = 0;
+#define FT(I) do { if (TIME) { __builtin_amdgcn_sched_barrier(0); const long long now__ = (long long)__builtin_readcyclecounter(); \
+                               tacc[I] += now__ - tprev; tprev = now__; __builtin_amdgcn_sched_barrier(0); } } while (0)
 
     for (int it = 0; it < n_iter; ++it) {
         const int x0 = tile * GAMD_TILE + 16 * half;            // this half's 16 CSR edges: x0 + r
@@ -181,6 +188,7 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         const bool active_n = tile_n < n_tiles;
         int src_n = 0, dst_n = 0;
 
+        if (TIME) tprev = (long long)__builtin_readcyclecounter();
         // ===== phase 1: T1 = SiLU(W1 e + b1) =====
         unsigned mask = 0;
         int p0 = 0;
@@ -201,7 +209,9 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
         } else {
             gamd_stage_weight_raw_contig<NW>(a.w2p, buf1, wave, lane16);
         }
+        FT(0);                                                        // phase 1 (GEMM + SiLU/split, DMA + gather issue inside)
         if (active) phase_barrier<32>(); else phase_barrier<0>();     // S/D gathers (issued after the DMA) stay in flight
+        FT(1);                                                        // barrier 1
         // ===== phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]) =====
         if (!active) gamd_stage_weight_raw_contig<NW>(a.w3p, buf0, wave, lane16);
         if (active) {
@@ -220,7 +230,9 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
                 HN[r] = *reinterpret_cast<const f32x4*>(a.hn + (size_t)sr * GAMD_H + 4 * slot);
             });
         }
+        FT(2);                                                        // phase 2
         if (active) phase_barrier<16>(); else phase_barrier<0>();     // hn gathers stay in flight
+        FT(3);                                                        // barrier 2
         // ===== phase 3: T4 = SiLU(W3 T3 + b3) =====
         if (!active) gamd_stage_weight_raw_contig<NW>(a.w4p, buf1, wave, lane16);
         if (active_n) {
@@ -233,7 +245,9 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
                 put_pair(PB, tp, r0, gamd_silu_hw(ACC[tp][r0]), gamd_silu_hw(ACC[tp][r0 + 1]));
             }, [&](int i) { if (i < 16) stage_chunk<NW>(a.w4p, buf1, wave, lane16, i); });
         }
+        FT(4);                                                        // idx loads + phase 3
         phase_barrier<0>();
+        FT(5);                                                        // barrier 3
         // ===== phase 4: e_emb = T4 W4^T + b4 (F2: 16 edges x 4 features per lane), message, segment sum =====
         if (!active) gamd_stage_weight_raw_contig<NW>(a.w1p, buf0, wave, lane16);       // next tile's W1 (harmless on the last iteration)
         if (active) {
@@ -264,7 +278,9 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
             if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) pend_ends |= 1u << (nvalid - 1);
             pend_p = p0;
         }
+        FT(6);                                                        // phase 4 (GEMM + message + segment sum)
         if (active && active_n) phase_barrier<16>(); else phase_barrier<0>();   // next e tile stays in flight
+        FT(7);                                                        // barrier 4
         // one store per finished piece: closing edges (mask bits) and, if the chunk's last valid edge does not close a
         // segment, that edge too (the run continues in the next chunk as its own piece)
         while (__any(pend_ends != 0)) {
@@ -281,21 +297,37 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_f16x3(ConvEdgeArgs a) {
                 ++pend_p;
             }
         }
+        FT(8);                                                        // piece stores
+        if (TIME && active) tacc[15] += 1;
         tile = tile_n; active = active_n; src = src_n; dst = dst_n;
     }
+#ifdef GAMD_PROFILING
+    if (TIME && a.tdbg && lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 16; ++i) a.tdbg[((size_t)blockIdx.x * 8 + wave) * 16 + i] = tacc[i];
+#endif
+#undef FT
 }
 
 }  // namespace
 
-int launch_conv_edge_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
+template <bool TIME>
+static int launch_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * CONV_LDS_FLOATS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge_f16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge_f16x3<TIME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return (int)e1;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_conv_edge_f16x3, dim3(n_blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_conv_edge_f16x3<TIME>, dim3(n_blocks), dim3(256), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
+}
+
+int launch_conv_edge_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
+#ifdef GAMD_PROFILING
+    static const bool timed = getenv("GAMD_F16X3_TIME") != nullptr;
+    if (timed) return launch_f16x3<true>(a, n_blocks, st);
+#endif
+    return launch_f16x3<false>(a, n_blocks, st);
 }
