@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         if (a.self_loop) {
             // self_loop_mode 1: the last edge of every row is the loop an in-place add_self_loop would have appended AFTER
             // edata['e'] was set (nn_module.py:649-652): its embedding is DGL's zero fill, not an encoded feature row
-            if (valid && x == (long long)a.row_ptr[dst + 1] - 1) {
+            if (valid && gamd_is_appended_loop(a, x, src, dst)) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_edge_encode_small(EncArgs a) {
         const float var = gamd_xhalf_sum((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * a.ln_inv_width;
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         const f32x16 g = load_slice(a.ln_g, quarter, half), b = load_slice(a.ln_b, quarter, half);
-        const bool zero_row = a.self_loop && valid && x == (long long)a.row_ptr[dst + 1] - 1;      // appended loop: e = 0
+        const bool zero_row = valid && gamd_is_appended_loop(a, x, src, dst);      // appended loop: e = 0
         f32x4* out = (f32x4*)a.e_frag + (size_t)tile * 16 * 64;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

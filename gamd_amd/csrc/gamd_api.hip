@@ -494,6 +494,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.perm = h->perm.as<int>();
     ea.row_ptr = h->row_ptr.as<int>();
     ea.self_loop = na.self_loop;
+    ea.zero_row = h->n;
     for (int d = 0; d < 3; ++d) { ea.box[d] = h->box[d]; ea.half[d] = 0.5f * h->box[d]; }
     ea.bx = box_ref(h);
     ea.length_mean = h->length_mean;

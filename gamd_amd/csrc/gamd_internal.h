@@ -122,6 +122,7 @@ struct EncArgs {
     const int* perm;           // sorted -> original (bond lookup)
     const int* row_ptr;        // CSR rows (self_loop: the last edge of a row is the appended zero-feature loop)
     int self_loop;             // gamd_config.self_loop_mode
+    int zero_row;              // = n (all boxes): the source index of the padding slots behind a box's last row
     float box[3], half[3];
     BoxRef bx;                 // n_boxes > 1: the box of an edge is the box of its destination atom
     float length_mean, length_std, gamma;
@@ -141,6 +142,14 @@ struct EncArgs {
     long long e_cap;
     float* feat_dbg;           // optional [e_cap][48] raw features (debug/parity), or null
 };
+// self_loop_mode 1: is CSR slot x (source src, destination dst) the loop that was appended behind the row's real edges?  It is the
+// last slot of its row that is not a padding slot (padding follows only in the row of a box's last atom, n_boxes > 1).
+__device__ __forceinline__ bool gamd_is_appended_loop(const EncArgs& a, long long x, int src, int dst) {
+    if (!a.self_loop || src == a.zero_row) return false;
+    const long long row_end = a.row_ptr[dst + 1];
+    return x == row_end - 1 || (x + 1 < row_end && a.col[x + 1] == a.zero_row);
+}
+
 // dimensions of the box an edge lives in (the box of its destination atom, sorted index)
 __device__ __forceinline__ BoxDims gamd_edge_box(const EncArgs& a, int dst) {
     return gamd_box_dims(a.bx, a.box, a.half, a.bx.n_boxes > 1 ? gamd_box_of(a.bx, dst) : 0);

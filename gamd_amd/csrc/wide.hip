@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
         // (zero-padded features each added mean^2 to s2: taken out again)
         const float rstd = 1.0f / sqrtf((gamd_xhalf_sum(s2) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width + 1e-5f);
         // self_loop_mode 1: the appended loop (last edge of its row) carries DGL's zero-filled embedding (nn_module.py:364)
-        const bool zero_row = a.self_loop && valid && x == (long long)a.row_ptr[dst + 1] - 1;
+        const bool zero_row = valid && gamd_is_appended_loop(a, x, src, dst);
         if (active) {
             f32x4* out = (f32x4*)a.e_frag + (size_t)tile * EHT * 16 * 64;
 #pragma unroll

@@ -265,3 +265,60 @@ def test_batch_argument_checks():
     eng.close()
     with pytest.raises(GamdError, match="at most"):
         _engine(sd, 1 << 20, 1.0e3, 7.5, n_boxes=8)
+
+
+def test_batch_on_the_generic_width_kernels_and_with_appended_self_loops():
+    """The trainers' default widths (256 / 128 / 256, wide.hip) and self_loop_mode 1 (one zero-embedding loop appended per
+    atom) on a batch: bit-identical to the boxes one by one; box 0 reproduces the reference goldens."""
+    g, cfg, sd = load_golden("lj258_w256_seed9")
+    box, rc, n = float(g["box"]), float(g["cutoff"]), 258
+    rng = np.random.default_rng(12)
+    pos = [np.mod(g["pos"], box) + (rng.normal(0, 0.2, (n, 3)) if b else 0.0) for b in range(3)]
+    batch = _engine(sd, n, box, rc, n_boxes=3, neighbor_skin=rc / 6.0)
+    single = _engine(sd, n, box, rc, neighbor_skin=rc / 6.0)
+    out = batch.forward(torch.from_numpy(np.concatenate(pos)).float()).cpu().numpy()
+    assert rel_err(out[:n], g["out_norm"]) < TOL
+    for b in range(3):
+        assert np.array_equal(out[b * n:(b + 1) * n], single.forward(torch.from_numpy(pos[b]).float()).cpu().numpy()), b
+    batch.close(); single.close()
+
+    g, cfg, sd = load_golden("lj258_selfloop_inplace_seed0")
+    pos = [np.mod(g["pos"], box) + (rng.normal(0, 0.2, (n, 3)) if b else 0.0) for b in range(3)]
+    kw = dict(self_loop_mode="append_zero_feature_loops", keep_stages=True)
+    batch = _engine(sd, n, box, rc, n_boxes=3, **kw)
+    single = _engine(sd, n, box, rc, **kw)
+    out = batch.forward(torch.from_numpy(np.concatenate(pos)).float()).cpu().numpy()
+    assert rel_err(out[:n], g["out_norm"]) < TOL
+    # stage getters on a batch: the padding slots are not edges (debug_edge_rows masks them out of debug_e / debug_feat)
+    rows = batch.debug_edge_rows()
+    eb, fb = batch.debug_e()[rows], batch.debug_feat(44)[rows]
+    edges = batch.debug_edges()
+    assert eb.shape[0] == edges.shape[1] == fb.shape[0]
+    off = 0
+    for b in range(3):
+        one = single.forward(torch.from_numpy(pos[b]).float()).cpu().numpy()
+        assert np.array_equal(out[b * n:(b + 1) * n], one), b
+        e1 = single.debug_e()
+        assert np.array_equal(eb[off:off + e1.shape[0]], e1), b
+        assert np.array_equal(edges[:, off:off + e1.shape[0]] - b * n, single.debug_edges()), b
+        hb = batch.debug_h(4)[b * n:(b + 1) * n]
+        assert np.array_equal(hb, single.debug_h(4)), b
+        off += e1.shape[0]
+    batch.close(); single.close()
+
+
+def test_model_level_batch_with_the_in_place_self_loop_reading():
+    """pnet_model(pos_lst, edge_lst) on the caller's edge lists with self_loop_mode 1: the CSR rows of a batch are
+    [the caller's edges][the appended loop][padding slots]; both graphs reproduce the reference's in-place-add_self_loop output."""
+    from gamd_amd.compat import ParticleNetLightningLJ
+    g, cfg, sd = load_golden("lj258_selfloop_inplace_seed0")
+    box = float(g["box"])
+    m = ParticleNetLightningLJ(state_dict=sd, num_atoms=258, box_size=box, cutoff=float(g["cutoff"]),
+                               self_loop_mode="append_zero_feature_loops")
+    posw = torch.from_numpy(np.mod(g["pos"], box)).float().cuda()
+    e = torch.from_numpy(g["edge_idx"]).long().cuda()
+    one = m.pnet_model([posw], [e]).cpu().numpy()
+    three = m.pnet_model([posw, posw, posw], [e, e, e]).cpu().numpy()
+    assert rel_err(one, g["out_norm"]) < TOL
+    for b in range(3):
+        assert np.array_equal(three[b * 258:(b + 1) * 258], one), b
