@@ -322,3 +322,34 @@ def test_model_level_batch_with_the_in_place_self_loop_reading():
     assert rel_err(one, g["out_norm"]) < TOL
     for b in range(3):
         assert np.array_equal(three[b * 258:(b + 1) * 258], one), b
+
+
+def test_batch_with_isolated_atoms_at_box_boundaries():
+    """Sparse boxes in the torch flavour (no self edges): atoms without neighbours, also as the LAST atom of a box, whose CSR
+    row then consists of padding slots only.  Batch == boxes one by one, isolated atoms aggregate to zero."""
+    rng = np.random.default_rng(5)
+    n, box, rc, nb = 97, 11.0, 2.0, 4
+    cfg = ModelConfig(kind="water")
+    sd = make_state_dict(cfg, 9, 2.0, 0.7)
+    species = (np.arange(n) % 3 == 0)
+    # atoms are renumbered in cell order: the atom with the highest id in the highest cell is the last of its box's sorted
+    # order — put it there, away from everything (all other atoms keep >= 2 A from that corner and its periodic images)
+    pos = [rng.uniform(1.5, box - 3.0, (n, 3)) for _ in range(nb)]
+    for p in pos:
+        p[-1] = box - 0.5
+    batch = _engine(sd, n, box, rc, nbr_flavour="torch", n_boxes=nb)
+    single = _engine(sd, n, box, rc, nbr_flavour="torch")
+    out = batch.forward(torch.from_numpy(np.concatenate(pos)).float(), species=species).cpu().numpy()
+    edges = batch.debug_edges()
+    deg = np.bincount(edges[0], minlength=nb * n)
+    assert (deg == 0).sum() >= nb
+    seen_isolated_last = 0
+    for b in range(nb):
+        one = single.forward(torch.from_numpy(pos[b]).float(), species=species).cpu().numpy()
+        assert np.array_equal(out[b * n:(b + 1) * n], one), b
+        seen_isolated_last += int(deg[(b + 1) * n - 1] == 0 and batch.debug_perm()[(b + 1) * n - 1] == (b + 1) * n - 1)
+        ref = orc.forward(sd, torch.from_numpy(pos[b]).float(), torch.from_numpy(single.debug_edges()).long(), box,
+                          feat=torch.from_numpy(species.astype(np.float32)).view(-1, 1)).numpy()
+        assert rel_err(one, ref) < TOL
+    assert seen_isolated_last == nb
+    batch.close(); single.close()
