@@ -102,6 +102,7 @@ struct gamd_handle {
     std::vector<float> boxes_host;               // [n_boxes][3] as last set
     int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width (PADDED to 128-blocks) and their block counts
     int H_true = 128, Eh_true = 128, D_true = 128;   // encoding_size, edge_embedding_dim, hidden_dim as given (<= the padded ones)
+    int norm_bn = 0;                             // graph_conv.norm_layers are BatchNorm1d (running statistics in the state_dict)
     bool wide_enc = false, wide_conv = false;    // generic-width kernels of wide.hip
     long long small_tile_limit = 512;            // fp32 path: at most this many 32-edge tiles -> conv_edge_small.hip
     std::map<std::string, HostTensor> host_w;
@@ -567,6 +568,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     no.dec_w1p = h->dec_w1p; no.dec_b1 = h->dec_b1; no.dec_w2 = h->dec_w2; no.dec_b2 = h->dec_b2;
     no.ln_inv_width = 1.0f / (float)h->H_true;
     no.ln_n_pad = (float)(h->H - h->H_true);
+    no.norm_bn = h->norm_bn;
     no.scale = (float)std::sqrt(h->scaler_var);
     no.shift = (float)h->scaler_mean;
     no.perm = h->perm.as<int>();
@@ -942,6 +944,9 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         return o;
     };
 
+    // BatchNorm checkpoints carry running statistics next to norm_layers' weight and bias
+    const bool norm_bn = h->host_w.count("graph_conv.norm_layers.0.running_mean") != 0;
+    h->norm_bn = norm_bn ? 1 : 0;
     for (int l = 0; l < L; ++l) {
         const std::string p = "graph_conv.conv." + std::to_string(l);
         // edge_affine = MLP(Eh, hidden_dim, hidden_layer=2): its inner width is MLP's default 128 (nn_module.py:25,95)
@@ -959,6 +964,26 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         if (!ea0w || !ea0b || !ea2w || !ea2b || !sw || !sb || !dw || !db || !t1w || !t1b || !t3w || !t3b || !pdw ||
             !pdb || !pew || !peb || !phw || !phb || !ng || !nb)
             return -2;
+        if (norm_bn) {
+            // use_layer_norm=False (the constructors' default, nn_module.py:171-196,579): norm_layers are nn.BatchNorm1d; the
+            // rollout runs the model in eval mode, where it is the per-feature affine map torch's CPU kernel evaluates as
+            // x * alpha + beta with alpha = weight / sqrt(running_var + eps), beta = bias - running_mean * alpha (float).
+            // Folded here into the ln_g / ln_b slots; padded features keep alpha = beta = 0.
+            const std::string np_ = "graph_conv.norm_layers." + std::to_string(l);
+            const HostTensor *rm = get(np_ + ".running_mean", {Ht}, {H}), *rv = get(np_ + ".running_var", {Ht}, {H});
+            if (!rm || !rv) return -2;
+            HostTensor al, be;
+            al.shape = be.shape = {H};
+            al.data.assign((size_t)H, 0.f);
+            be.data.assign((size_t)H, 0.f);
+            for (int64_t i = 0; i < Ht; ++i) {
+                const float invstd = 1.0f / std::sqrt(rv->data[i] + 1e-5f);
+                al.data[i] = ng->data[i] * invstd;
+                be.data[i] = nb->data[i] - rm->data[i] * al.data[i];
+            }
+            padded.push_back(std::move(al)); ng = &padded.back();
+            padded.push_back(std::move(be)); nb = &padded.back();
+        }
         Off& o = lo[l];
         HostTensor b4_perm;
         // 128-wide fp32 and bf16 kernels (conv_edge.hip, conv_edge_small.hip, conv_edge_bf16.hip): output row 32 q + s of the

@@ -224,6 +224,7 @@ struct NodeArgs {
     const float* dec_w1p; const float* dec_b1; const float* dec_w2; const float* dec_b2;   // w2: [3][128] plain
     float scale, shift;        // sqrt(var), mean of the force scaler (fp32 copy for the device path)
     float ln_inv_width, ln_n_pad;   // graph_conv.norm_layers over the TRUE node width (zero-padded to the 128-blocks): 1 / width, #pad
+    int norm_bn;                    // 1: norm_layers are eval-mode BatchNorm1d (use_layer_norm=False), folded into ln_g / ln_b
     const int* perm;
     // outputs
     float* h_out;              // [n][128]

@@ -206,26 +206,31 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
 
     if (a.mode != 2) {
         // ---- pre(l): LayerNorm over the row = reductions over the 4 lane groups and the 4 waves ----
-        float ps = 0.f;
+        // (use_layer_norm=False checkpoints: eval-mode BatchNorm1d is a per-feature affine map; the host folded the running
+        //  statistics into ln_g = w / sqrt(var + eps), ln_b = b - mean * ln_g, and the row statistics are not needed)
+        float mean = 0.f, rstd = 1.0f;
+        if (!a.norm_bn) {
+            float ps = 0.f;
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ps += mine[o][r];
-        ps = group_sum(ps);
-        if (g == 0) red[0][w][la] = ps;
-        __syncthreads();
-        const float mean = ((red[0][0][la] + red[0][1][la]) + (red[0][2][la] + red[0][3][la])) * a.ln_inv_width;
-        float pv = 0.f;
+                for (int r = 0; r < 4; ++r) ps += mine[o][r];
+            ps = group_sum(ps);
+            if (g == 0) red[0][w][la] = ps;
+            __syncthreads();
+            mean = ((red[0][0][la] + red[0][1][la]) + (red[0][2][la] + red[0][3][la])) * a.ln_inv_width;
+            float pv = 0.f;
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = mine[o][r] - mean; pv += d * d; }
-        pv = group_sum(pv);
-        if (g == 0) red[1][w][la] = pv;
-        __syncthreads();
-        // zero-padded features (width < 128) each added mean^2 to the sum of squared deviations: taken out again (n_pad = 0: x - 0)
-        const float var = (((red[1][0][la] + red[1][1][la]) + (red[1][2][la] + red[1][3][la])) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width;
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                for (int r = 0; r < 4; ++r) { const float d = mine[o][r] - mean; pv += d * d; }
+            pv = group_sum(pv);
+            if (g == 0) red[1][w][la] = pv;
+            __syncthreads();
+            // zero-padded features (width < 128) each added mean^2 to the sum of squared deviations: taken out again (n_pad = 0: x - 0)
+            const float var = (((red[1][0][la] + red[1][1][la]) + (red[1][2][la] + red[1][3][la])) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width;
+            rstd = 1.0f / sqrtf(var + 1e-5f);
+        }
         {
             f32x4 gg[2], bb[2];
             load16(a.pre.ln_g, w, g, gg);

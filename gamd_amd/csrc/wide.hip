@@ -491,25 +491,29 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
 
     if (a.mode != 2) {
         // ---- pre(l): LayerNorm over H, then S, D, P (H -> 128 each) ------------------------------
-        float ps = 0.f;
+        // (norm_bn: eval-mode BatchNorm1d folded by the host into ln_g / ln_b, no row statistics -- see node.hip)
+        float mean = 0.f, rstd = 1.0f;
+        if (!a.norm_bn) {
+            float ps = 0.f;
 #pragma unroll
-        for (int b = 0; b < HT; ++b)
+            for (int b = 0; b < HT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ps += mine[b][r];
-        ps = gamd_xhalf_sum(ps);
-        if (half == 0) red[0][quarter][slot] = ps;
-        __syncthreads();
-        const float mean = ((red[0][0][slot] + red[0][1][slot]) + (red[0][2][slot] + red[0][3][slot])) * a.ln_inv_width;
-        float pv = 0.f;
+                for (int r = 0; r < 16; ++r) ps += mine[b][r];
+            ps = gamd_xhalf_sum(ps);
+            if (half == 0) red[0][quarter][slot] = ps;
+            __syncthreads();
+            mean = ((red[0][0][slot] + red[0][1][slot]) + (red[0][2][slot] + red[0][3][slot])) * a.ln_inv_width;
+            float pv = 0.f;
 #pragma unroll
-        for (int b = 0; b < HT; ++b)
+            for (int b = 0; b < HT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float d = mine[b][r] - mean; pv += d * d; }
-        pv = gamd_xhalf_sum(pv);
-        if (half == 0) red[1][quarter][slot] = pv;
-        __syncthreads();
-        const float var = (((red[1][0][slot] + red[1][1][slot]) + (red[1][2][slot] + red[1][3][slot])) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width;
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                for (int r = 0; r < 16; ++r) { const float d = mine[b][r] - mean; pv += d * d; }
+            pv = gamd_xhalf_sum(pv);
+            if (half == 0) red[1][quarter][slot] = pv;
+            __syncthreads();
+            const float var = (((red[1][0][slot] + red[1][1][slot]) + (red[1][2][slot] + red[1][3][slot])) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width;
+            rstd = 1.0f / sqrtf(var + 1e-5f);
+        }
 #pragma unroll
         for (int b = 0; b < HT; ++b) {
             const f32x16 g = load_slice(a.pre.ln_g + 128 * b, quarter, half), be = load_slice(a.pre.ln_b + 128 * b, quarter, half);

@@ -113,6 +113,8 @@ class GamdForce:
         check(self._lib.gamd_create(C.byref(c), C.byref(self._h)), "gamd_create")
         self.keep_stages = keep_stages
         for name, t in state_dict.items():
+            if name.endswith("num_batches_tracked"):      # BatchNorm's step counter: not used at inference
+                continue
             a = np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
             shape = (C.c_int64 * a.ndim)(*a.shape)
             check(self._lib.gamd_load_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),

@@ -39,6 +39,9 @@ class ModelConfig:
     use_bond: bool = False        # water: 45th edge feature (bond flag)
     n_rbf: int = 40               # RBFExpansion(high=1, gap=0.025) -> ceil(1/0.025) = 40; 0 = expand_edge=False
                                   # (WaterMDDynamicBoxNet only, nn_module.py:278,296-297,329-336)
+    use_layer_norm: bool = True   # build_model's args.use_layer_norm (True in every rollout driver).  False = the constructors'
+                                  # default: BatchNorm1d between the conv layers (nn_module.py:171-196, use_batch_norm = not
+                                  # use_layer_norm :579), which at inference is a per-feature affine map of the running statistics
 
     @property
     def edge_in(self) -> int:
@@ -74,6 +77,10 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     for l in range(cfg.conv_layer):
         spec[f"graph_conv.norm_layers.{l}.weight"] = (H,)
         spec[f"graph_conv.norm_layers.{l}.bias"] = (H,)
+        if not cfg.use_layer_norm:                   # nn.BatchNorm1d buffers, in the order torch registers them
+            spec[f"graph_conv.norm_layers.{l}.running_mean"] = (H,)
+            spec[f"graph_conv.norm_layers.{l}.running_var"] = (H,)
+            spec[f"graph_conv.norm_layers.{l}.num_batches_tracked"] = ()
     if cfg.n_rbf > 0:
         spec["edge_expand.centers"] = (cfg.n_rbf,)
     if cfg.kind != "lj":
@@ -110,6 +117,13 @@ def make_state_dict(cfg: ModelConfig, seed: int = 0, length_mean: float = 4.0,
             t = torch.tensor(np.linspace(0.0, 1.0, cfg.n_rbf)).float()
         elif name == "node_emb":
             t = torch.randn(shape, generator=g)
+        elif name.endswith(".num_batches_tracked"):
+            sd[name] = torch.tensor(1000, dtype=torch.int64)
+            continue
+        elif name.endswith(".running_mean"):
+            t = 0.3 * torch.randn(shape, generator=g)
+        elif name.endswith(".running_var"):
+            t = 0.5 + torch.rand(shape, generator=g)
         elif "norm" in name and name.endswith(".weight"):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
         elif "norm" in name and name.endswith(".bias"):
@@ -145,7 +159,8 @@ def infer_config(sd: Dict[str, torch.Tensor]) -> ModelConfig:
     return ModelConfig(kind=kind, encoding_size=H, hidden_dim=D, edge_embedding_dim=Eh,
                        conv_layer=n_layers, in_feats=in_feats,
                        out_feats=sd["graph_decoder.mlp_layer.2.weight"].shape[0],
-                       use_bond=use_bond, n_rbf=n_rbf)
+                       use_bond=use_bond, n_rbf=n_rbf,
+                       use_layer_norm="graph_conv.norm_layers.0.running_mean" not in sd)
 
 
 def validate_state_dict(sd: Dict[str, torch.Tensor], cfg: ModelConfig) -> None:
@@ -191,8 +206,8 @@ def load_checkpoint(path: str, allow_pickle: bool = False) -> "OrderedDict[str, 
     if isinstance(obj, dict) and "state_dict" in obj:
         obj = obj["state_dict"]
     sd = strip_prefix(obj)
-    return OrderedDict((k, v.detach().to(torch.float32).contiguous()) for k, v in sd.items()
-                       if isinstance(v, torch.Tensor))
+    return OrderedDict((k, v.detach().contiguous() if k.endswith("num_batches_tracked") else v.detach().to(torch.float32).contiguous())
+                       for k, v in sd.items() if isinstance(v, torch.Tensor))
 
 
 def load_scaler(path: str) -> Tuple[np.ndarray, np.ndarray]:

@@ -43,7 +43,10 @@ enum { GAMD_NBR_JAXMD = 0, GAMD_NBR_TORCH = 1 };        /* dr^2 < rc^2 + self pa
  * [1, 128].  The kernels work in 128-wide blocks; other widths are zero-padded when the weights are packed (padded features
  * are exact zeros through every layer, the two LayerNorms divide by the true width).  128 / 128 / 128 (every shipped LJ / TIP
  * config, LJ/test_script/test_langevin.py:63-73) runs the specialised kernels, anything wider than 128 the generic-width
- * ones (the DFT-water config 256 / 128 / 256, water/test_script/test_nosehoover_hb.py:69-81; the trainers' defaults). */
+ * ones (the DFT-water config 256 / 128 / 256, water/test_script/test_nosehoover_hb.py:69-81; the trainers' defaults).
+ * Normalisation between the conv layers (nn_module.py:171-196): LayerNorm (use_layer_norm=True, every rollout driver) or
+ * eval-mode BatchNorm1d (use_layer_norm=False, the constructors' default) -- chosen by the weights: a state_dict that carries
+ * graph_conv.norm_layers.<l>.running_mean / running_var is a BatchNorm checkpoint (num_batches_tracked is not needed). */
 typedef struct gamd_config {
     int32_t n_atoms;
     int32_t kind;            /* GAMD_KIND_*  */

@@ -128,6 +128,16 @@ def layer_norm(sd, prefix, x):
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
 
 
+def node_norm(sd, prefix, x):
+    """graph_conv.norm_layers[l] (nn_module.py:193-196, applied at :202): LayerNorm when the model was built with
+    use_layer_norm=True (every rollout driver), else nn.BatchNorm1d (use_batch_norm = not use_layer_norm, :579) — in eval mode
+    the affine map of its running statistics."""
+    if prefix + ".running_mean" in sd:
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                            sd[prefix + ".bias"], training=False, eps=1e-5)
+    return layer_norm(sd, prefix, x)
+
+
 def edge_features(sd: Dict[str, Tensor], pos: Tensor, center: Tensor, neigh: Tensor, box) -> Tensor:
     """nn_module.py:603-634 (= :462-493): rel = pos[neigh]-pos[center], min-image,
     norm, unit vector r/(n+1e-8), standardised length, RBF of the standardised
@@ -227,7 +237,7 @@ def forward(sd: Dict[str, Tensor], pos: Tensor, edge_idx: Tensor, box,
         stages["feat"], stages["e"], stages["h"] = f, e, [h]
     e, src, dst = apply_self_loop_mode(e, src, dst, n, self_loop_mode)         # :650-652
     for l in range(n_conv_layers(sd)):                                         # :200-202
-        hn = layer_norm(sd, f"graph_conv.norm_layers.{l}", h)
+        hn = node_norm(sd, f"graph_conv.norm_layers.{l}", h)
         h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst) + h
         if stages is not None:
             stages["h"].append(h)
@@ -251,7 +261,7 @@ def forward_dynamic_box(sd, pos: Tensor, feat: Tensor, box, cutoff: float,
         stages["feat"], stages["e"], stages["h"], stages["edge_idx"] = f, e, [h], edge_idx
     e, src, dst = apply_self_loop_mode(e, src, dst, pos.shape[0], self_loop_mode)   # :364
     for l in range(n_conv_layers(sd)):
-        hn = layer_norm(sd, f"graph_conv.norm_layers.{l}", h)
+        hn = node_norm(sd, f"graph_conv.norm_layers.{l}", h)
         h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst) + h
         if stages is not None:
             stages["h"].append(h)

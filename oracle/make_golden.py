@@ -61,13 +61,13 @@ def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=Non
         m = nn_module.SimpleMDNetNew(encoding_size=cfg.encoding_size, out_feats=3, box_size=box,
                                      hidden_dim=cfg.hidden_dim, conv_layer=cfg.conv_layer,
                                      edge_embedding_dim=cfg.edge_embedding_dim, drop_edge=False,
-                                     use_layer_norm=True)
+                                     use_layer_norm=cfg.use_layer_norm)
     else:
         m = nn_module.WaterMDNetNew(in_feats=1, encoding_size=cfg.encoding_size, out_feats=3,
                                     box_size=box, bond=torch.as_tensor(bond) if bond is not None else None,
                                     hidden_dim=cfg.hidden_dim, conv_layer=cfg.conv_layer,
                                     edge_embedding_dim=cfg.edge_embedding_dim, drop_edge=False,
-                                    use_layer_norm=True)
+                                    use_layer_norm=cfg.use_layer_norm)
     m.load_state_dict(sd, strict=True)
     m.eval()
     # predict_forces front end (LJ/train_network_lj.py:135-142), restated
@@ -110,6 +110,8 @@ def run_fixed_box(nn_module, name, cfg, seed, pos, box, cutoff, scaler, feat=Non
                              str(cfg.edge_embedding_dim), str(cfg.conv_layer), str(int(cfg.use_bond))]))
     if h_stride > 1:
         rec["h_stride"] = np.int64(h_stride)
+    if not cfg.use_layer_norm:
+        rec["use_layer_norm"] = np.int64(0)
     if inplace_self_loop:
         rec["self_loop_inplace"] = np.int64(1)
     if keep_h:
@@ -210,6 +212,23 @@ def main():
                       w_pos, 20.0, 4.2, SHIPPED_SCALERS["tip3p"], feat=featw, bond=water_bond(nw),
                       lmean=2.9, lstd=1.1, edge_stride=211, h_stride=9)
     if "--only-wide" in sys.argv:
+        return
+
+    # use_layer_norm=False: the constructors' and the trainers' DEFAULT (--use_layer_norm is a store_true flag,
+    # LJ/train_network_lj.py:398): nn.BatchNorm1d between the conv layers (nn_module.py:171-196, :579), in eval mode with
+    # non-trivial running statistics.  `--only-bn` writes just these two.
+    if "--only-bn" in sys.argv or len(sys.argv) == 1:
+        run_fixed_box(nn_module, "lj258_bn_seed11", ModelConfig(kind="lj", use_layer_norm=False, **full), 11, lj_pos, 27.27, 7.5,
+                      SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, edge_stride=211, h_stride=3)
+        nb_ = w_pos.shape[0]
+        featb = torch.zeros(nb_, 1)
+        featb[::3] = 1.0
+        run_fixed_box(nn_module, "tip3p774_bn_w256_seed12",
+                      ModelConfig(kind="water", use_bond=True, use_layer_norm=False, encoding_size=256, hidden_dim=128,
+                                  edge_embedding_dim=256, conv_layer=4), 12,
+                      w_pos, 20.0, 4.2, SHIPPED_SCALERS["tip3p"], feat=featb, bond=water_bond(nb_),
+                      lmean=2.9, lstd=1.1, edge_stride=211, h_stride=9)
+    if "--only-bn" in sys.argv:
         return
 
     # model-level call with two graphs (`--only-batch` writes just this one)

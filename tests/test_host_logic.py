@@ -147,6 +147,29 @@ def test_wide_and_unexpanded_specs_roundtrip():
     assert wide["graph_conv.conv.0.theta_edge.mlp_layer.3.weight"] == (256, 128)
 
 
+def test_batchnorm_checkpoints_spec_oracle_and_loader(tmp_path):
+    """use_layer_norm=False (the constructors' default, nn_module.py:171-196): BatchNorm1d buffers in the spec in torch's
+    registration order, recognised by infer_config, kept through the checkpoint loader (int64 step counter included), and
+    the oracle's eval-mode branch is the running-statistics affine map."""
+    from oracle import gamd_oracle as orc
+    cfg = ModelConfig(kind="lj", use_layer_norm=False, conv_layer=2)
+    sd = make_state_dict(cfg, 5)
+    keys = [k for k in sd if k.startswith("graph_conv.norm_layers.0.")]
+    assert [k.rsplit(".", 1)[1] for k in keys] == ["weight", "bias", "running_mean", "running_var", "num_batches_tracked"]
+    assert sd["graph_conv.norm_layers.0.num_batches_tracked"].dtype == torch.int64
+    assert not infer_config(sd).use_layer_norm and infer_config(make_state_dict(ModelConfig(), 5)).use_layer_norm
+    validate_state_dict(sd, cfg)
+    bn = torch.nn.BatchNorm1d(cfg.encoding_size)
+    bn.load_state_dict({k.rsplit(".", 1)[1]: sd[k] for k in keys}, strict=True)      # the keys torch itself expects
+    bn.eval()
+    x = torch.randn(7, cfg.encoding_size)
+    assert torch.equal(orc.node_norm(sd, "graph_conv.norm_layers.0", x), bn(x))
+    torch.save({"state_dict": {"pnet_model." + k: v for k, v in sd.items()}}, tmp_path / "bn.ckpt")
+    got = load_checkpoint(str(tmp_path / "bn.ckpt"))
+    assert list(got) == list(sd) and got["graph_conv.norm_layers.1.num_batches_tracked"].dtype == torch.int64
+    assert torch.equal(got["graph_conv.norm_layers.1.running_var"], sd["graph_conv.norm_layers.1.running_var"])
+
+
 def test_compat_wrappers_are_lazy_and_mirror_the_reference_signatures():
     """Constructing the Lightning-shaped wrappers needs no GPU; the engine is created on first use."""
     import inspect

@@ -8,7 +8,9 @@ import gamd_oracle as orc
 from helpers import load_golden, rel_err, edge_set
 
 # the *_w256_* cases: the trainers' default widths 256 / 128 / 256 (LJ/train_network_lj.py:394-396) on the fixed-box models
-FIXED = ["lj258_seed0", "lj258_pert_seed1", "lj64_h32", "tip3p774_seed3", "lj258_w256_seed9", "tip3p774_w256_seed10"]
+# the *_bn_* cases: use_layer_norm=False, the constructors' / trainers' default (BatchNorm1d between the conv layers, eval mode)
+FIXED = ["lj258_seed0", "lj258_pert_seed1", "lj64_h32", "tip3p774_seed3", "lj258_w256_seed9", "tip3p774_w256_seed10",
+         "lj258_bn_seed11", "tip3p774_bn_w256_seed12"]
 
 
 @pytest.mark.parametrize("name", FIXED)
