@@ -114,6 +114,10 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = b;
             gemm_quarter<true>(cur, X, acc);
+            if (WIDE && a.emb_out) {                         // update_edge_emb: e_emb rows for launch_edge_update (wide.hip)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a.emb_out[(size_t)(x0 + r) * H + feat4(ob)] = acc[r];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[r] = gamd_msg_acc((r < nvalid) ? hn_q[ob][r] : 0.f, acc[r], (r > 0 && ((keep_bits >> r) & 1u)) ? acc[r - 1] : 0.f);

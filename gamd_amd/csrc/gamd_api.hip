@@ -57,6 +57,7 @@ struct DevBuf {
 struct LayerDev {
     // edge side
     const float *w1p, *w2p, *w3p, *w4p, *b1, *b3, *b4;
+    const float *e_ln_g = nullptr, *e_ln_b = nullptr;   // update_edge_emb: this layer's edge_layer_norm
     NodeLayerW node;
 };
 
@@ -103,6 +104,7 @@ struct gamd_handle {
     int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width (PADDED to 128-blocks) and their block counts
     int H_true = 128, Eh_true = 128, D_true = 128;   // encoding_size, edge_embedding_dim, hidden_dim as given (<= the padded ones)
     int norm_bn = 0;                             // graph_conv.norm_layers are BatchNorm1d (running statistics in the state_dict)
+    bool update_edge = false;                    // update_edge_emb=True: conv.<l>.edge_layer_norm keys in the state_dict
     bool wide_enc = false, wide_conv = false;    // generic-width kernels of wide.hip
     long long small_tile_limit = 512;            // fp32 path: at most this many 32-edge tiles -> conv_edge_small.hip
     std::map<std::string, HostTensor> host_w;
@@ -127,7 +129,7 @@ struct gamd_handle {
     int ncell_cap = 0;
     // edges
     long long e_cap = 0;
-    DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg;
+    DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg, e_emb, e_frag2;
     DevBuf counters, tdbg, tmp_eid, ke_partial, com_partial;
     DevBuf cnt2;                    // small systems in skin mode: two counter blocks used alternately (no per-call memset)
     int cnt_parity = 0;
@@ -200,6 +202,10 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
     r |= h->chunk_mask.ensure(sizeof(unsigned) * (ec / GAMD_CHUNK + 2), true);
     r |= h->e_frag.ensure(sizeof(float) * 4096 * (size_t)h->EHT * (ec / GAMD_TILE + 1), false);
     r |= h->partial.ensure(sizeof(float) * (size_t)h->H * (ec / GAMD_CHUNK + (size_t)h->n + 2), false);
+    if (h->update_edge) {                        // e_emb rows of one layer and the updated embedding tiles (H == Eh)
+        r |= h->e_emb.ensure(sizeof(float) * (size_t)h->H * ec, false);
+        r |= h->e_frag2.ensure(sizeof(float) * 4096 * (size_t)h->EHT * (ec / GAMD_TILE + 1), false);
+    }
     if (h->cfg.keep_stages) r |= h->feat_dbg.ensure(sizeof(float) * 48 * ec, true);
     if (r) return fail(-12, "edge buffer allocation failed for capacity %lld", e_cap);
     h->e_cap = e_cap;
@@ -588,7 +594,9 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.devflags = h->devflags.as<int>();
         ca.col = h->col.as<int>(); ca.erow = h->erow.as<int>();
         ca.chunk_piece = h->chunk_piece.as<int>(); ca.chunk_mask = h->chunk_mask.as<unsigned>();
-        ca.e_frag = h->e_frag.as<float>();
+        // update_edge_emb: layers after the first read the previous layer's LayerNorm(e_emb) (nn_module.py:145-146)
+        ca.e_frag = (h->update_edge && l > 0) ? h->e_frag2.as<float>() : h->e_frag.as<float>();
+        ca.emb_out = (h->update_edge && l + 1 < h->L) ? h->e_emb.as<float>() : nullptr;
         ca.hn = h->hn.as<float>(); ca.S = h->S.as<float>(); ca.D = h->D.as<float>();
         const LayerDev& ld = h->layers[l];
         ca.w1p = ld.w1p; ca.w2p = ld.w2p; ca.w3p = ld.w3p; ca.w4p = ld.w4p;
@@ -606,6 +614,17 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         if (r) return fail(-1, "conv edge launch failed (%d)", r);
         if ((r = tev_end())) return r;
         mark("conv_edge");
+        if (ca.emb_out) {
+            EdgeUpdateArgs ua{};
+            ua.counters = h->cur_counters; ua.devflags = h->devflags.as<int>(); ua.e_cap = h->e_cap;
+            ua.emb = ca.emb_out; ua.ln_g = ld.e_ln_g; ua.ln_b = ld.e_ln_b;
+            ua.ln_inv_width = 1.0f / (float)h->Eh_true;
+            ua.ln_n_pad = (float)(h->Eh - h->Eh_true);
+            ua.e_frag_out = h->e_frag2.as<float>();
+            if ((r = launch_edge_update(ua, h->HT, small_tiles > 0 ? std::max(1, small_tiles / 4) : 2 * h->n_cu, st)))
+                return fail(-1, "edge update launch failed (%d)", r);
+            mark("edge_update");
+        }
 
         no.mode = (l == h->L - 1) ? 2 : 1;
         no.post = ld.node;
@@ -865,7 +884,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     DevBuf* bufs[] = {&h->boxes_dev, &h->box_shift, &h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
                       &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
-                      &h->chunk_mask, &h->e_frag, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial, &h->com_partial,
+                      &h->chunk_mask, &h->e_frag, &h->e_emb, &h->e_frag2, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial, &h->com_partial,
                       &h->ref_pos, &h->cand_deg, &h->cand_ptr, &h->cand_col};
     for (DevBuf* b : bufs) b->release();
     if (h->counters_host) (void)hipHostFree(h->counters_host);
@@ -894,7 +913,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     const int64_t Ht = h->H_true, Et = h->Eh_true, Dt = h->D_true;        // the state_dict's widths
     const bool expand = !h->cfg.no_expand_edge;
     BlobBuilder bb;
-    struct Off { size_t w1p, w2p, w3p, w4p, b1, b3, b4, lng, lnb, wsp, wdp, wpdp, bS, bP, wpep, wphip, bphi; };
+    struct Off { size_t w1p, w2p, w3p, w4p, b1, b3, b4, elng = 0, elnb = 0, lng, lnb, wsp, wdp, wpdp, bS, bP, wpep, wphip, bphi; };
     std::vector<Off> lo(L);
     // get(name, true shape, padded shape): the tensor as the reference stores it, zero-padded to the kernels' block widths.
     // Padded output rows / input columns are zeros, so padded features are exact zeros through every layer.
@@ -944,6 +963,21 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         return o;
     };
 
+    // update_edge_emb=True checkpoints (WaterMDDynamicBoxNet(update_edge=True), nn_module.py:91-92): every conv layer owns an
+    // edge_layer_norm; LayerNorm(in_edge_feats) is applied to e_emb of width in_node_feats (:141), so the two must agree.
+    // Served by the generic-width kernels (wide.hip) for any width.
+    const bool update_edge = h->host_w.count("graph_conv.conv.0.edge_layer_norm.weight") != 0;
+    if (update_edge) {
+        if (Ht != Et)
+            return fail(-22, "update_edge_emb needs encoding_size == edge_embedding_dim (got %d, %d)", (int)Ht, (int)Et);
+        if (h->cfg.edge_dtype != GAMD_EDGE_F32 || h->cfg.self_loop_mode)
+            return fail(-22, "update_edge_emb is built for the fp32 edge MLP without appended self loops");
+        h->wide_enc = h->wide_conv = true;
+    }
+    if (update_edge != h->update_edge) {
+        h->update_edge = update_edge;
+        if (alloc_edges(h, h->e_cap)) return -12;
+    }
     // BatchNorm checkpoints carry running statistics next to norm_layers' weight and bias
     const bool norm_bn = h->host_w.count("graph_conv.norm_layers.0.running_mean") != 0;
     h->norm_bn = norm_bn ? 1 : 0;
@@ -1020,6 +1054,11 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         }
         o.b1 = put_vec(ea0b); o.b3 = put_vec(t1b); o.b4 = put_vec(t3b);
         o.lng = put_vec(ng); o.lnb = put_vec(nb);
+        if (update_edge) {
+            const HostTensor *eg = get(p + ".edge_layer_norm.weight", {Et}, {Eh}), *eb = get(p + ".edge_layer_norm.bias", {Et}, {Eh});
+            if (!eg || !eb) return -2;
+            o.elng = put_vec(eg); o.elnb = put_vec(eb);
+        }
         o.wsp = put_node(sw, 1, (int)HT); o.wdp = put_node(dw, 1, (int)HT); o.wpdp = put_node(pdw, 1, (int)HT);
         o.bS = bb.add(128);
         for (int i = 0; i < 128; ++i) bb.host[o.bS + i] = (sb->data[i] + db->data[i]) + ea2b->data[i];
@@ -1102,6 +1141,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         d.w1p = B + o.w1p; d.w2p = B + o.w2p; d.w3p = B + o.w3p; d.w4p = B + o.w4p;
         d.b1 = B + o.b1; d.b3 = B + o.b3; d.b4 = B + o.b4;
         d.node.ln_g = B + o.lng; d.node.ln_b = B + o.lnb;
+        if (update_edge) { d.e_ln_g = B + o.elng; d.e_ln_b = B + o.elnb; }
         d.node.wsp = B + o.wsp; d.node.wdp = B + o.wdp; d.node.wpdp = B + o.wpdp;
         d.node.bS = B + o.bS; d.node.bP = B + o.bP;
         d.node.wpep = B + o.wpep; d.node.wphip = B + o.wphip; d.node.bphi = B + o.bphi;

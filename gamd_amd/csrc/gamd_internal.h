@@ -182,6 +182,8 @@ struct ConvEdgeArgs {
     long long e_cap;
     int zero_row;              // = n: hn / S / D have one extra all-zero row for the padding slots of the last tile
     long long* tdbg;           // profiling builds only: [blocks][8 waves][16] cycle sums, or null
+    float* emb_out;            // update_edge_emb (generic-width kernels only): e_emb = theta_edge(...) of every edge, [E][H] rows
+                               // in CSR order, for launch_edge_update; null otherwise
 };
 int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);   // w*p = bf16 packed fragments, e_frag bf16
@@ -192,6 +194,20 @@ int launch_conv_edge_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 // generic widths (wide.hip): Eh = 128 eht, H = 128 ht.  w1p points at eht + 2 + ht contiguous packed blocks
 // W1[:, kb] | W2 | W3 | W4[ob, :]; b4 is [H]; hn and partial rows are H wide, S and D stay 128 wide
 int launch_conv_edge_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
+
+// update_edge_emb=True (SmoothConvLayerNew, nn_module.py:91-92, :140-146): the edge embedding the NEXT layers read is
+// edge_layer_norm(e_emb) of this layer.  emb: [E][128 ht] rows written by the conv kernel (emb_out); e_frag_out: the same
+// fragment-order tiles the edge encoder writes (Eh == H).
+struct EdgeUpdateArgs {
+    const int* counters;
+    const int* devflags;
+    long long e_cap;
+    const float* emb;
+    const float* ln_g; const float* ln_b;      // [128 ht], zero-padded
+    float ln_inv_width, ln_n_pad;              // LayerNorm over the true width
+    float* e_frag_out;
+};
+int launch_edge_update(const EdgeUpdateArgs& a, int ht, int n_blocks, hipStream_t st);
 
 // ---- node side --------------------------------------------------------------------------------
 struct NodeLayerW {            // one conv layer's node-side parameters (device pointers)

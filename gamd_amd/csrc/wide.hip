@@ -332,6 +332,13 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
                     for (int r = 0; r < 16; ++r) U[tp][r] = b;
                 }
                 gemm128<true>(W, lane, T, U);
+                if (a.emb_out) {                           // update_edge_emb: e_emb rows for launch_edge_update (edge x0 + r)
+                    float* er = a.emb_out + (size_t)x0 * H + 128 * ob + slot;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) er[(size_t)r * H + 32 * tp] = U[tp][r];
+                }
                 const unsigned keep_bits = ~(mask << 1);
 #pragma unroll
                 for (int tp = 0; tp < 4; ++tp)
@@ -358,6 +365,50 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
                 }
             }
             end_phase();
+        }
+    }
+}
+
+// ================================================================================================
+// update_edge_emb (nn_module.py:140-146): e for the next layers = edge_layer_norm(e_emb), from the conv kernel's [E][H]
+// rows back into the encoder's fragment order (lane = edge gamd_pi(slot), registers = features 4 half + j of each 8-block).
+// One wave per 32-edge tile; a lane reads the half of its edge's row it will write, the other half's sums arrive by DPP.
+// A dead branch in every shipped configuration (SURVEY a-9): written for correctness, two extra passes over E x H floats.
+// ================================================================================================
+template <int HT>
+__global__ void __launch_bounds__(256) k_edge_update(EdgeUpdateArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;
+    constexpr int H = 128 * HT;
+    const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    long long E = a.counters[CNT_E];
+    if (E > a.e_cap) E = a.e_cap;
+    const int n_tiles = (int)((E + GAMD_TILE - 1) / GAMD_TILE);
+    for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += gridDim.x * 4) {
+        const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);      // rows up to the end of the last tile exist
+        const f32x4* row = reinterpret_cast<const f32x4*>(a.emb + (size_t)x * H) + half;
+        f32x4 v[HT * 16];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < HT * 16; ++i) {                                   // i = (ob*4 + t)*4 + q: features 8 i + 4 half + j
+            v[i] = row[2 * i];
+            s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mean = gamd_xhalf_sum(s1) * a.ln_inv_width;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < HT * 16; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; s2 += d * d; }
+        const float rstd = 1.0f / sqrtf((gamd_xhalf_sum(s2) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width + 1e-5f);
+        f32x4* out = (f32x4*)a.e_frag_out + (size_t)tile * HT * 16 * 64;
+#pragma unroll
+        for (int i = 0; i < HT * 16; ++i) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(a.ln_g)[2 * i + half], b = reinterpret_cast<const f32x4*>(a.ln_b)[2 * i + half];
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+            out[i * 64 + lane] = o;
         }
     }
 }
@@ -632,6 +683,14 @@ int launch_conv_edge_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, 
     if (eht == 2 && ht == 1) return conv_launch<2, 1>(a, n_blocks, st);
     if (eht == 2 && ht == 2) return conv_launch<2, 2>(a, n_blocks, st);
     return -22;
+}
+
+int launch_edge_update(const EdgeUpdateArgs& a, int ht, int n_blocks, hipStream_t st) {
+    if (ht == 1) hipLaunchKernelGGL(k_edge_update<1>, dim3(n_blocks), dim3(256), 0, st, a);
+    else if (ht == 2) hipLaunchKernelGGL(k_edge_update<2>, dim3(n_blocks), dim3(256), 0, st, a);
+    else return -22;
+    GAMD_CHECK_LAUNCH();
+    return 0;
 }
 
 int launch_node_wide(const NodeArgs& a, int ht, hipStream_t st) {

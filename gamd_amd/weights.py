@@ -42,6 +42,9 @@ class ModelConfig:
     use_layer_norm: bool = True   # build_model's args.use_layer_norm (True in every rollout driver).  False = the constructors'
                                   # default: BatchNorm1d between the conv layers (nn_module.py:171-196, use_batch_norm = not
                                   # use_layer_norm :579), which at inference is a per-feature affine map of the running statistics
+    update_edge: bool = False     # WaterMDDynamicBoxNet(update_edge=True) (--update_edge, water/train_network_real_large.py:83,362):
+                                  # every conv layer leaves edata['e'] = edge_layer_norm(e_emb) for the layers after it
+                                  # (nn_module.py:91-92, :140-146); needs encoding_size == edge_embedding_dim
 
     @property
     def edge_in(self) -> int:
@@ -63,6 +66,9 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
 
     for l in range(cfg.conv_layer):
         p = f"graph_conv.conv.{l}"
+        if cfg.update_edge:                          # registered first (nn_module.py:91-92); LayerNorm(in_edge_feats)
+            spec[p + ".edge_layer_norm.weight"] = (Eh,)
+            spec[p + ".edge_layer_norm.bias"] = (Eh,)
         # MLP(in_edge_feats, hidden_dim, hidden_layer=2) at nn_module.py:95 does not pass
         # MLP's own hidden_dim, so its inner width is the MLP default 128 (nn_module.py:25)
         lin(p + ".edge_affine.mlp_layer.0", 128, Eh)
@@ -160,7 +166,8 @@ def infer_config(sd: Dict[str, torch.Tensor]) -> ModelConfig:
                        conv_layer=n_layers, in_feats=in_feats,
                        out_feats=sd["graph_decoder.mlp_layer.2.weight"].shape[0],
                        use_bond=use_bond, n_rbf=n_rbf,
-                       use_layer_norm="graph_conv.norm_layers.0.running_mean" not in sd)
+                       use_layer_norm="graph_conv.norm_layers.0.running_mean" not in sd,
+                       update_edge="graph_conv.conv.0.edge_layer_norm.weight" in sd)
 
 
 def validate_state_dict(sd: Dict[str, torch.Tensor], cfg: ModelConfig) -> None:

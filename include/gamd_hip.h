@@ -46,7 +46,9 @@ enum { GAMD_NBR_JAXMD = 0, GAMD_NBR_TORCH = 1 };        /* dr^2 < rc^2 + self pa
  * ones (the DFT-water config 256 / 128 / 256, water/test_script/test_nosehoover_hb.py:69-81; the trainers' defaults).
  * Normalisation between the conv layers (nn_module.py:171-196): LayerNorm (use_layer_norm=True, every rollout driver) or
  * eval-mode BatchNorm1d (use_layer_norm=False, the constructors' default) -- chosen by the weights: a state_dict that carries
- * graph_conv.norm_layers.<l>.running_mean / running_var is a BatchNorm checkpoint (num_batches_tracked is not needed). */
+ * graph_conv.norm_layers.<l>.running_mean / running_var is a BatchNorm checkpoint (num_batches_tracked is not needed).
+ * update_edge=True models (SmoothConvLayerNew.update_edge_emb, nn_module.py:91-92, :140-146) are recognised the same way, by
+ * their graph_conv.conv.<l>.edge_layer_norm.weight / .bias keys: fp32 edge MLP, encoding_size == edge_embedding_dim. */
 typedef struct gamd_config {
     int32_t n_atoms;
     int32_t kind;            /* GAMD_KIND_*  */

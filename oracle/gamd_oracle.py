@@ -178,13 +178,17 @@ def bond_flags(center: Tensor, neigh: Tensor, bond: np.ndarray) -> Tensor:
     return torch.isin(center * n + neigh, key)
 
 
-def conv_layer(sd, p: str, e: Tensor, hn: Tensor, src: Tensor, dst: Tensor) -> Tensor:
+def conv_layer(sd, p: str, e: Tensor, hn: Tensor, src: Tensor, dst: Tensor, e_next: Optional[list] = None) -> Tensor:
     """SmoothConvLayerNew.forward, nn_module.py:108-148, op for op (Linear on E
-    gathered rows, as written)."""
+    gathered rows, as written).  update_edge_emb=True (a state_dict with `<p>.edge_layer_norm.*`, :91-92): the layer
+    leaves edata['e'] = edge_layer_norm(e_emb) on the graph for the layers after it (:140-141, :145-146; the assignment is
+    made after local_scope() has closed, so it persists) — handed back through `e_next`."""
     edge_code = mlp(sd, p + ".edge_affine", e, "silu", 2)                     # :135
     src_code = linear(sd, p + ".src_affine", hn[src])                          # :136
     dst_code = linear(sd, p + ".dst_affine", hn[dst])                          # :137
     e_emb = mlp(sd, p + ".theta_edge", edge_code + src_code + dst_code, "silu", 2, True)  # :138
+    if e_next is not None and (p + ".edge_layer_norm.weight") in sd:
+        e_next.append(layer_norm(sd, p + ".edge_layer_norm", e_emb))           # :141 (width H == Eh or torch raises)
     agg = torch.zeros_like(hn)
     agg.index_add_(0, dst, hn[src] * e_emb)                                    # :142 u_mul_e -> sum
     return mlp(sd, p + ".phi", linear(sd, p + ".phi_dst", hn) + linear(sd, p + ".phi_edge", agg),
@@ -238,7 +242,10 @@ def forward(sd: Dict[str, Tensor], pos: Tensor, edge_idx: Tensor, box,
     e, src, dst = apply_self_loop_mode(e, src, dst, n, self_loop_mode)         # :650-652
     for l in range(n_conv_layers(sd)):                                         # :200-202
         hn = node_norm(sd, f"graph_conv.norm_layers.{l}", h)
-        h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst) + h
+        e_next = []
+        h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst, e_next) + h
+        if e_next:                                                             # update_edge_emb: :145-146
+            e = e_next[0]
         if stages is not None:
             stages["h"].append(h)
     return mlp(sd, "graph_decoder", h, "gelu", 2)                              # :684
@@ -262,7 +269,10 @@ def forward_dynamic_box(sd, pos: Tensor, feat: Tensor, box, cutoff: float,
     e, src, dst = apply_self_loop_mode(e, src, dst, pos.shape[0], self_loop_mode)   # :364
     for l in range(n_conv_layers(sd)):
         hn = node_norm(sd, f"graph_conv.norm_layers.{l}", h)
-        h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst) + h
+        e_next = []
+        h = conv_layer(sd, f"graph_conv.conv.{l}", e, hn, src, dst, e_next) + h
+        if e_next:                                                             # update_edge_emb: :145-146
+            e = e_next[0]
         if stages is not None:
             stages["h"].append(h)
     return mlp(sd, "graph_decoder", h, "gelu", 2)

@@ -132,7 +132,7 @@ def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, l
     m = nn_module.WaterMDDynamicBoxNet(in_feats=1, encoding_size=cfg.encoding_size, out_feats=3,
                                        bond=None, hidden_dim=cfg.hidden_dim, conv_layer=cfg.conv_layer,
                                        edge_embedding_dim=cfg.edge_embedding_dim, drop_edge=False,
-                                       use_layer_norm=True, update_edge=False, expand_edge=cfg.n_rbf > 0)
+                                       use_layer_norm=True, update_edge=cfg.update_edge, expand_edge=cfg.n_rbf > 0)
     m.load_state_dict(sd, strict=True)
     m.eval()
     pos32 = torch.from_numpy(np.asarray(pos)).float()
@@ -149,7 +149,7 @@ def run_dynbox(nn_module, md_module, name, cfg, seed, pos, box, cutoff, lmean, l
                         pos=pos32.numpy(), box=boxa, cutoff=np.float64(cutoff), seed=np.int64(seed),
                         length_mean=np.float64(lmean), length_std=np.float64(lstd),
                         edge_idx=edge_idx.numpy().astype(np.int32), dist_norm=dist_norm.numpy(),
-                        node_feat=feat.numpy(), out_norm=out,
+                        node_feat=feat.numpy(), out_norm=out, **({"update_edge": np.int64(1)} if cfg.update_edge else {}),
                         cfg=np.array([cfg.kind, str(cfg.encoding_size), str(cfg.hidden_dim),
                                       str(cfg.edge_embedding_dim), str(cfg.conv_layer), "0", str(cfg.n_rbf)]))
     print(f"{name}: N={n} E={edge_idx.shape[1]}")
@@ -229,6 +229,20 @@ def main():
                       w_pos, 20.0, 4.2, SHIPPED_SCALERS["tip3p"], feat=featb, bond=water_bond(nb_),
                       lmean=2.9, lstd=1.1, edge_stride=211, h_stride=9)
     if "--only-bn" in sys.argv:
+        return
+
+    # update_edge=True (--update_edge, water/train_network_real_large.py:83,362 -> SmoothConvLayerNew.update_edge_emb,
+    # nn_module.py:91-92, :140-146): every conv layer hands LayerNorm(e_emb) to the layers after it as their edge embedding.
+    # The DFT-water widths and a 128-wide 3-layer model.  `--only-update` writes just these two.
+    if "--only-update" in sys.argv or len(sys.argv) == 1:
+        subu = np.mod(w_pos[:384], 20.0)
+        run_dynbox(nn_module, md_module, "dynbox384_update_dftcfg_seed13",
+                   ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5,
+                               update_edge=True), 13, subu, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
+        run_dynbox(nn_module, md_module, "dynbox384_update_seed14",
+                   ModelConfig(kind="dynbox", update_edge=True, encoding_size=128, hidden_dim=128, edge_embedding_dim=128,
+                               conv_layer=3), 14, subu, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
+    if "--only-update" in sys.argv:
         return
 
     # model-level call with two graphs (`--only-batch` writes just this one)

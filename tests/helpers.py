@@ -15,7 +15,8 @@ def load_golden(name):
     n_rbf = int(g["cfg"][6]) if len(g["cfg"]) > 6 else 40
     cfg = ModelConfig(kind=kind, encoding_size=int(H), hidden_dim=int(D), edge_embedding_dim=int(Eh),
                       conv_layer=int(L), use_bond=bool(int(bond)), n_rbf=n_rbf,
-                      use_layer_norm=bool(int(g["use_layer_norm"])) if "use_layer_norm" in g else True)
+                      use_layer_norm=bool(int(g["use_layer_norm"])) if "use_layer_norm" in g else True,
+                      update_edge=bool(int(g["update_edge"])) if "update_edge" in g else False)
     sd = make_state_dict(cfg, int(g["seed"]), float(g["length_mean"]), float(g["length_std"]))
     return g, cfg, sd
 

@@ -338,3 +338,73 @@ def test_dft_configuration_with_skin_reuse_in_the_md_loop():
         assert rel_err(f.cpu().numpy(), ref_f) < TOL, chunk
     assert skin.skin_stats()[0] >= 2
     skin.close(); exact.close()
+
+
+# ---- update_edge=True (--update_edge, water/train_network_real_large.py:83,362; nn_module.py:91-92, :140-146) --------------
+UPDATE = ["dynbox384_update_dftcfg_seed13", "dynbox384_update_seed14"]
+
+
+@pytest.mark.parametrize("name", UPDATE)
+@pytest.mark.parametrize("small_tile_limit", [0, -1])
+def test_update_edge_emb_matches_the_reference_goldens(name, small_tile_limit):
+    """Every conv layer hands LayerNorm(e_emb) to the layers after it.  Outputs of WaterMDDynamicBoxNet(update_edge=True)
+    itself; both conv kernels (one tile per workgroup / one tile per wave), per-layer node states against the oracle."""
+    g, cfg, sd = load_golden(name)
+    assert cfg.update_edge and "graph_conv.conv.0.edge_layer_norm.weight" in sd
+    n = g["pos"].shape[0]
+    eng = _engine(sd, n, g["box"], float(g["cutoff"]), nbr_flavour="torch", keep_stages=True, small_tile_limit=small_tile_limit)
+    species = g["node_feat"].reshape(-1) != 0
+    out = eng.forward(torch.from_numpy(g["pos"]), box=g["box"], species=species).cpu().numpy()
+    assert np.array_equal(edge_set(eng.debug_edges()), edge_set(g["edge_idx"]))
+    st = {}
+    ref = orc.forward_dynamic_box(sd, torch.from_numpy(g["pos"]), torch.from_numpy(g["node_feat"]), g["box"],
+                                  float(g["cutoff"]), stages=st).numpy()
+    for l, h_ref in enumerate(st["h"]):
+        assert rel_err(eng.debug_h(l), h_ref.numpy()) < TOL, f"h_{l}"
+    assert rel_err(out, ref) < TOL
+    assert rel_err(out, g["out_norm"]) < TOL
+    med, p99, worst, cnt = per_atom_err(out, g["out_norm"])
+    assert p99 < P99_TOL, (med, p99, worst)
+    # the update is not a no-op: the same weights without the per-layer LayerNorms give other forces
+    plain = {k: v for k, v in sd.items() if ".edge_layer_norm." not in k or k.startswith("edge_layer_norm")}
+    other = _engine(plain, n, g["box"], float(g["cutoff"]), nbr_flavour="torch")
+    assert rel_err(other.forward(torch.from_numpy(g["pos"]), box=g["box"], species=species).cpu().numpy(), g["out_norm"]) > 1e-2
+    other.close()
+    eng.close()
+
+
+def test_update_edge_emb_with_skin_reuse_batches_and_odd_widths():
+    """Skin reuse and a batch of boxes run the same kernels: equal to the exact / one-by-one evaluation; a width that is
+    zero-padded (96) against the oracle; mismatched widths are refused as torch refuses them."""
+    g, cfg, sd = load_golden(UPDATE[0])
+    n, box, rc = g["pos"].shape[0], g["box"], float(g["cutoff"])
+    species = g["node_feat"].reshape(-1) != 0
+    exact = _engine(sd, n, box, rc, nbr_flavour="torch")
+    skin = _engine(sd, n, box, rc, nbr_flavour="torch", neighbor_skin=rc / 6)
+    rng = np.random.default_rng(4)
+    x = g["pos"].copy()
+    frames = []
+    for step in range(6):
+        x = (x + rng.normal(0, 0.05, x.shape)).astype(np.float32)
+        a = exact.forward(torch.from_numpy(x), box=box, species=species).cpu().numpy()
+        b = skin.forward(torch.from_numpy(x), box=box, species=species).cpu().numpy()
+        assert rel_err(b, a) < TOL
+        frames.append((x.copy(), a))
+    batch = _engine(sd, n, box, rc, nbr_flavour="torch", n_boxes=3)
+    xb = np.concatenate([f[0] for f in frames[:3]])
+    ob = batch.forward(torch.from_numpy(xb), box=np.tile(np.asarray(box, dtype=np.float32), (3, 1)),
+                       species=np.tile(species, 3)).cpu().numpy()
+    assert np.array_equal(ob, np.concatenate([f[1] for f in frames[:3]]))          # bit-identical to the boxes one by one
+    for e in (exact, skin, batch):
+        e.close()
+    c96 = ModelConfig(kind="dynbox", update_edge=True, encoding_size=96, hidden_dim=64, edge_embedding_dim=96, conv_layer=3)
+    sd96 = make_state_dict(c96, 21, 3.1, 1.2)
+    eng = _engine(sd96, n, box, rc, nbr_flavour="torch")
+    out = eng.forward(torch.from_numpy(g["pos"]), box=box, species=species).cpu().numpy()
+    ref = orc.forward_dynamic_box(sd96, torch.from_numpy(g["pos"]), torch.from_numpy(g["node_feat"]), box, rc).numpy()
+    assert rel_err(out, ref) < TOL
+    eng.close()
+    bad = make_state_dict(ModelConfig(kind="dynbox", update_edge=True, encoding_size=128, edge_embedding_dim=256, conv_layer=2), 1)
+    from gamd_amd._lib import GamdError
+    with pytest.raises((GamdError, ValueError)):
+        _engine(bad, n, box, rc, nbr_flavour="torch")

@@ -170,6 +170,19 @@ def test_batchnorm_checkpoints_spec_oracle_and_loader(tmp_path):
     assert torch.equal(got["graph_conv.norm_layers.1.running_var"], sd["graph_conv.norm_layers.1.running_var"])
 
 
+def test_update_edge_spec_roundtrip():
+    """update_edge=True: every conv layer registers its edge_layer_norm FIRST (nn_module.py:91-92); infer_config sees it."""
+    cfg = ModelConfig(kind="dynbox", update_edge=True, encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=2)
+    sd = make_state_dict(cfg, 2)
+    layer0 = [k for k in sd if k.startswith("graph_conv.conv.0.")]
+    assert layer0[:3] == ["graph_conv.conv.0.edge_layer_norm.weight", "graph_conv.conv.0.edge_layer_norm.bias",
+                          "graph_conv.conv.0.edge_affine.mlp_layer.0.weight"]
+    assert sd["graph_conv.conv.1.edge_layer_norm.weight"].shape == (256,)
+    got = infer_config(sd)
+    assert got.update_edge and not infer_config(make_state_dict(ModelConfig(kind="dynbox"), 2)).update_edge
+    validate_state_dict(sd, cfg)
+
+
 def test_compat_wrappers_are_lazy_and_mirror_the_reference_signatures():
     """Constructing the Lightning-shaped wrappers needs no GPU; the engine is created on first use."""
     import inspect

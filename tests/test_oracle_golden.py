@@ -61,7 +61,8 @@ def test_neighbor_semantics_jaxmd():
 
 
 @pytest.mark.parametrize("name", ["dynbox384_seed4", "dynbox384_dftcfg_seed5", "dynbox384_noexpand_seed6",
-                                  "dynbox384_h256_e128_seed7", "dynbox384_h128_e256_noexpand_seed8"])
+                                  "dynbox384_h256_e128_seed7", "dynbox384_h128_e256_noexpand_seed8",
+                                  "dynbox384_update_dftcfg_seed13", "dynbox384_update_seed14"])      # update_edge=True
 def test_dynamic_box_matches_reference(name):
     """md_module.get_neighbor executed as-is (<=, no self, per-axis box) and
     WaterMDDynamicBoxNet.forward."""
