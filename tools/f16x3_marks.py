@@ -12,7 +12,7 @@ from gamd_amd.engine import GamdForce                                   # noqa: 
 from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS  # noqa: E402
 from gamd_amd import workloads as wk                                      # noqa: E402
 
-SEG = ["phase 1 (GEMM, SiLU/split, DMA + S/D gather issue)", "barrier 1", "phase 2 (+ hn gather issue)", "barrier 2", "idx loads + phase 3",
+SEG = ["phase 1 (GEMM, SiLU/split, DMA issue)", "barrier 1", "phase 2 (+ S/D quads)", "barrier 2", "idx loads + phase 3 (+ hn rows 0-7)",
        "barrier 3", "phase 4 (GEMM, message, segment sum, next e)", "barrier 4", "piece stores"]
 pos, box = wk.lj_box(10000)
 sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
@@ -20,7 +20,7 @@ eng = GamdForce(sd, 10000, box, 10.2, scaler=SHIPPED_SCALERS["lj"], edge_dtype="
 x = torch.from_numpy(pos).float().cuda()
 for _ in range(3):
     eng.forward(x, inplace=True)
-t = eng._dbg(5, (256, 8, 16), np.int64).astype(np.float64)[:, :4]
+t = eng._dbg(5, (256, 8, 16), np.int64).astype(np.float64)            # 8 waves per workgroup
 tiles = t[:, :, 15]
 tot = t[:, :, :9].sum(-1)
 print(f"E = {eng.counts()[0]}, tiles per wave {tiles.mean():.2f}; ticks per tile {tot.sum() / tiles.sum():.0f}")
