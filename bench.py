@@ -159,17 +159,21 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         cfg = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
         w.sd = make_state_dict(cfg, 5, 3.1 * bohr, 1.2 * bohr)
         mean, var = SHIPPED_SCALERS["dft"]
+        if edge_dtype == "bf16":
+            raise SystemExit("--workload dft: the bf16 edge MLP is built for the 128-wide configuration (use f32 or f16x3)")
         w.eng = GamdForce(w.sd, pos.shape[0], box, 9.5, nbr_flavour="torch", cfg=cfg, device=dev, neighbor_skin=skin * 9.5,
-                          scaler=(mean * CONV, var * CONV ** 2))        # hartree/bohr -> kJ/mol/nm folded into the scaler
+                          scaler=(mean * CONV, var * CONV ** 2), edge_dtype=edge_dtype)   # hartree/bohr -> kJ/mol/nm folded into the scaler
         w.cutoff = 9.5
         w.uses_skin = skin > 0
         w.mass = wk.MASS_O
         w.md_extra = dict(mass_h_amu=wk.MASS_H, length_per_nm=wk.BOHR_PER_NM, rigid_water=True,
                           r_oh=wk.TIP3P_R_OH * bohr, r_hh=wk.TIP3P_R_HH * bohr)
         w.flop_per_edge, w.kernel_name = 2 * 128 * 128 * (2 + 2 + 2), "k_conv_edge_wide<2,2>"
+        if edge_dtype == "f16x3":
+            w.dtype_name, w.kernel_name = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)", "k_conv_edge_f16x3_wide<2,2>"
         w.label = ("DFT-water configuration: 258 rigid molecules = 774 atoms, positions/box in bohr (L = 37.8), cutoff 9.5, "
-                   "WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, fp32, random-init weights (seed 5), SETTLE on "
-                   "device, 1 box per GPU")
+                   f"WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, {'split-fp16 edge MLP' if edge_dtype == 'f16x3' else 'fp32'}, "
+                   "random-init weights (seed 5), SETTLE on device, 1 box per GPU")
     elif name in ("c2", "c1", "c1_batch"):
         n = N_ATOMS if name == "c2" else 258
         w.cutoff = 3.0 * wk.LJ_SIGMA if name == "c2" else 7.5       # C1: CUTOFF_RADIUS of LJ/train_network_lj.py:26-29
@@ -498,7 +502,8 @@ def main():
         # runs of C2 (c2_bf16: the north star's neighbour-gather figure on the 10k-atom LJ box itself, tolerance restated as
         # for config 5) and the DFT-water configuration, 20 timed steps each
         for name, wname, dt_name in (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c3", "c3", "f32"), ("c5", "c5", "f32"),
-                                     ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("c2_bf16", "c2", "bf16"), ("dft", "dft", "f32")):
+                                     ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("c2_bf16", "c2", "bf16"), ("dft", "dft", "f32"),
+                                     ("dft_f16x3", "dft", "f16x3")):
             s = build_workload(wname, ctx, dev, args.skin, dt_name)
             sdt, _, sconv_ms, sconv_n = timed_run(s, 20, 5, ctx, dev, ddev)
             se = s.eng.counts()[0]

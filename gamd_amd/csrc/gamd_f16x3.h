@@ -74,3 +74,139 @@ __device__ __forceinline__ void gemm128_f16x3(const f16x8* W, int lane, const f3
             gamd_f16x3_step<F2>(W, lane, t, u, xh, xl, acc);
         }
 }
+
+// ---- pieces shared by the conv-layer edge kernels on this pipe (conv_edge_f16x3.hip, wide_f16x3.hip) ----------------------
+// An operand set: the (hi, lo) fp16 images of a 32 x 128 activation block in MFMA operand order, 64 registers
+// (the size of the fp32 block it replaces): w[t][u][part] = 4 dwords = 8 halves of K step (t, u).
+struct OpSet { gamd_u32x4_t w[4][2][2]; };
+
+// one 1 KiB piece (k = 0 .. 64/NW - 1 for this wave) of the same copy, to be issued between MFMAs: with one wave per
+// SIMD the ~100 cycles each LDS-DMA instruction takes to issue are otherwise dead time of the matrix pipe
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // "m0" on the clobber lists: see gamd_common.h
+template <int NW>
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16, int k) {
+    // (inline assembly: a compiler-tracked global_load_lds turns the next wait of any kind into vmcnt(0) lgkmcnt(0), see
+    // gamd_stage_weight_raw in gamd_common.h; the landing is guaranteed by the counted vmcnt of phase_barrier.)  A wave's
+    // 64 / NW KiB are contiguous and addressed by the instruction's immediate offset (which advances the global and the LDS
+    // side alike): base pair + M0 are rebuilt per call from one opaque scalar instead of living in 16 x 3 loop-invariant,
+    // spilled SGPRs per matrix.
+    int woff = wave * (64 / NW) * 1024 + (k >> 2) * 4096;
+    asm volatile("" : "+s"(woff));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf + (unsigned)woff;
+    const char* g0 = reinterpret_cast<const char*>(gw) + woff;
+    switch (k & 3) {
+        case 0: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
+        case 1: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
+        case 2: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
+        default: asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072" ::"v"(lane16), "s"(g0), "s"(lds0) : "memory", "m0"); break;
+    }
+}
+
+#pragma clang diagnostic pop
+
+// End of a phase: every wave has its own weight DMA (issued at the phase start, before the N most
+// recent VMEM loads) landed, then the workgroup meets.  The N prefetch loads stay in flight.
+// vmcnt retires in order, so "at most N outstanding" proves the older DMA is done only if at least
+// N loads really were issued after it: callers pass 0 on paths that skip the prefetch.
+template <int N>
+__device__ __forceinline__ void phase_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// pre-split e fragments written by edge_encode_f16x3.hip: [tile][t][u][hi|lo][lane][8 halves], 16 KiB per tile; scalar tile
+// base + 32-bit lane offset (the tile index is wave-uniform): no 64-bit per-lane pointer to keep
+__device__ __forceinline__ void load_e_tile_s(const float* __restrict__ e_frag, int tile, unsigned lane16, OpSet& P) {
+    const char* base = reinterpret_cast<const char*>(e_frag) + (size_t)__builtin_amdgcn_readfirstlane(tile) * 16384;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                P.w[t][u][p] = *reinterpret_cast<const gamd_u32x4_t*>(base + (lane16 + (unsigned)(((t * 2 + u) * 2 + p) * 1024)));
+}
+// the same for wide_f16x3.hip (which register-allocates differently around it)
+__device__ __forceinline__ void load_e_tile_g(const float* __restrict__ e_frag, int tile, unsigned lane16, OpSet& P) {
+    const char* base = reinterpret_cast<const char*>(e_frag) + (size_t)__builtin_amdgcn_readfirstlane(tile) * 16384;
+    // one scalar base per 4 KiB group (the immediate offset of a global load ends at 4 095) + the lane offset every wave holds
+    // anyway: left to itself hipcc keeps a 64-bit per-lane offset pair per group alive across the tile loop
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+        const char* bk = base + 4096 * grp;
+        asm volatile("" : "+s"(bk));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * grp + k;                         // i = (t * 2 + u) * 2 + part
+            P.w[i >> 2][(i >> 1) & 1][i & 1] = *reinterpret_cast<const gamd_u32x4_t*>(bk + (lane16 + (unsigned)(1024 * k)));
+        }
+    }
+}
+
+struct SiluK2 { gamd_f32x2_t nl2e, one; };
+
+__device__ __forceinline__ void silu_split_pair(OpSet& P, int t, int r0, float x0, float x1, const SiluK2& k) {
+    const gamd_f32x2_t x = {x0, x1};
+    const gamd_f32x2_t a = x * k.nl2e;
+    const gamd_f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const gamd_f32x2_t d = e + k.one;
+    const gamd_f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const gamd_f32x2_t y = x * r;
+    const gamd_f16x2 h = __builtin_convertvector(y, gamd_f16x2);
+    const gamd_f32x2_t rem = y - __builtin_convertvector(h, gamd_f32x2_t);
+    const gamd_f16x2 l = __builtin_convertvector(rem, gamd_f16x2);
+    const int u = r0 >> 3, dw = (r0 & 7) >> 1;
+    const unsigned hb = __builtin_bit_cast(unsigned, h), lb = __builtin_bit_cast(unsigned, l);
+    // the first pair of a K step starts a NEW register quad: inserting into the old one would keep the set's previous
+    // contents (the operand of two phases ago) alive next to the accumulators that are being turned into it
+    if (dw == 0) { P.w[t][u][0] = gamd_u32x4_t{hb, 0u, 0u, 0u}; P.w[t][u][1] = gamd_u32x4_t{lb, 0u, 0u, 0u}; }
+    else { P.w[t][u][0][dw] = hb; P.w[t][u][1][dw] = lb; }
+}
+
+// 128x128 split-fp16 GEMM, output block by output block; acc[tp] = init(tp) right in front of its K loop; the post-op of
+// block tp - 1 rides between the K steps of block tp; step(i) in front of K step i = 0..31.
+template <bool F2, typename Init, typename Post, typename Step>
+__device__ __forceinline__ void gemm128_f16x3_lazy(const f16x8* W, int lane, const OpSet& P, f32x16 (&acc)[4], Init init, Post post,
+                                                   Step step) {
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+        __builtin_amdgcn_sched_barrier(0);       // output blocks stay in program order: interleaving them keeps all four alive
+        init(tp);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                step((tp * 4 + t) * 2 + u);
+                const f16x8 wh = W[((tp * 4 + t) * 2 + u) * 64 + lane];
+                const f16x8 wl = W[2048 + ((tp * 4 + t) * 2 + u) * 64 + lane];
+                const f16x8 xh = __builtin_bit_cast(f16x8, P.w[t][u][0]), xl = __builtin_bit_cast(f16x8, P.w[t][u][1]);
+                if (F2) {
+                    acc[tp] = mfma_f16(xl, wh, acc[tp]);
+                    acc[tp] = mfma_f16(xh, wl, acc[tp]);
+                    acc[tp] = mfma_f16(xh, wh, acc[tp]);
+                } else {
+                    acc[tp] = mfma_f16(wh, xl, acc[tp]);
+                    acc[tp] = mfma_f16(wl, xh, acc[tp]);
+                    acc[tp] = mfma_f16(wh, xh, acc[tp]);
+                }
+                if (tp > 0) post(tp - 1, 2 * (t * 2 + u));
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) post(3, 2 * k);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ f32x16 bias_block(const float* vb, int t, int half) {
+    f32x16 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&vb[32 * t + 8 * q + 4 * half]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[q * 4 + j] = v[j];
+    }
+    return o;
+}
+

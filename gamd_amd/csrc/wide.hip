@@ -14,6 +14,7 @@
 // simplicity over the last 20 % (plain workgroup barriers, no cross-barrier prefetch): the shipped wide
 // configuration is a 774-atom box where every launch is latency-bound anyway.
 #include "gamd_common.h"
+#include "gamd_f16x3.h"
 #include "gamd_internal.h"
 
 namespace {
@@ -180,7 +181,8 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
 #pragma unroll
             for (int ob = 0; ob < EHT; ++ob)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    f32x16 nv;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int f0 = 128 * ob + 32 * t + 8 * q + 4 * half;
@@ -188,9 +190,25 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
                         const f32x4 b = *reinterpret_cast<const f32x4*>(&vbeta[f0]);
                         f32x4 v;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = zero_row ? 0.f : (Y[ob][t][q * 4 + j] - mean) * rstd * g[j] + b[j];
-                        out[((ob * 4 + t) * 4 + q) * 64 + lane] = v;
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = zero_row ? 0.f : (Y[ob][t][q * 4 + j] - mean) * rstd * g[j] + b[j];
+                            nv[q * 4 + j] = v[j];
+                        }
+                        if (a.e_format == 0) out[((ob * 4 + t) * 4 + q) * 64 + lane] = v;
                     }
+                    if (a.e_format == 2) {
+                        // split-fp16 edge MLP (wide_f16x3.hip / conv_edge_f16x3.hip): e already split into (hi, lo) fp16 operand
+                        // images, [tile][block][t][u][hi | lo][lane][8 halves] -- the layout edge_encode_f16x3.hip writes
+                        f16x8* efrag = reinterpret_cast<f16x8*>(a.e_frag);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            f16x8 eh, el;
+                            gamd_split8(nv, u, eh, el);
+                            efrag[((((size_t)tile * EHT + ob) * 8 + t * 2 + u) * 2 + 0) * 64 + lane] = eh;
+                            efrag[((((size_t)tile * EHT + ob) * 8 + t * 2 + u) * 2 + 1) * 64 + lane] = el;
+                        }
+                    }
+                }
         }
     }
 }

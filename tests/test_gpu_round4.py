@@ -135,8 +135,8 @@ def test_wide_fixed_box_goldens_stage_by_stage(name):
 @pytest.mark.parametrize("name,widths", [("lj258_bn_seed11", (128, 128, 128)), ("tip3p774_bn_w256_seed12", (256, 128, 256))])
 @pytest.mark.parametrize("edge_dtype", ["f32", "bf16", "f16x3"])
 def test_batchnorm_checkpoints_stage_by_stage(name, widths, edge_dtype):
-    if edge_dtype != "f32" and widths != (128, 128, 128):
-        pytest.skip("reduced-precision edge operands are built for the 128-wide kernels")
+    if edge_dtype == "bf16" and widths != (128, 128, 128):
+        pytest.skip("bf16 edge operands are built for the 128-wide kernels")
     case = _wide_case(name, widths=widths, keep_stages=True, edge_dtype=edge_dtype)
     assert not case[1].use_layer_norm and "graph_conv.norm_layers.0.running_var" in case[2]
     _check_stages(*case, tol={"f32": TOL, "bf16": 1e-2, "f16x3": 1e-5}[edge_dtype], stages=edge_dtype == "f32")
@@ -408,3 +408,71 @@ def test_update_edge_emb_with_skin_reuse_batches_and_odd_widths():
     from gamd_amd._lib import GamdError
     with pytest.raises((GamdError, ValueError)):
         _engine(bad, n, box, rc, nbr_flavour="torch")
+
+
+# ---- split-fp16 edge MLP for every width (wide_f16x3.hip + the generic-width encoder writing split operands) -----------------
+@pytest.mark.parametrize("name", ["lj258_w256_seed9", "tip3p774_w256_seed10", "tip3p774_bn_w256_seed12", "dynbox384_dftcfg_seed5",
+                                  "dynbox384_h256_e128_seed7", "dynbox384_h128_e256_noexpand_seed8", "dynbox384_noexpand_seed6",
+                                  "lj64_h32"])
+def test_split_fp16_edge_mlp_on_the_generic_width_goldens(name):
+    """edge_dtype="f16x3" outside 128 / 128 / 128: trainers' default widths on the fixed-box models, the DFT-water configuration,
+    mixed widths, expand_edge=False, a zero-padded narrow model -- outputs of the reference modules at the fp32 bar (1e-5),
+    per-atom p99 included; fp32 engine alongside (the two differ by rounding only)."""
+    g, cfg, sd = load_golden(name)
+    n = g["pos"].shape[0]
+    dyn = cfg.kind == "dynbox"
+    box = g["box"] if dyn else float(g["box"])
+    kw = dict(nbr_flavour="torch") if dyn else dict(bond=g["bond"] if "bond" in g else None)
+    if "scaler_mean" in g:
+        kw["scaler"] = (g["scaler_mean"], g["scaler_var"])
+    species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
+    pos = torch.from_numpy(g["pos"] if dyn else np.mod(g["pos"], box)).float()
+    outs = {}
+    for dt in ("f16x3", "f32"):
+        eng = _engine(sd, n, box, float(g["cutoff"]), edge_dtype=dt, **kw)
+        outs[dt] = (eng.forward(pos, box=box, species=species) if dyn else eng.forward(pos, species=species)).cpu().numpy()
+        if dt == "f16x3":
+            assert np.array_equal(edge_set(eng.debug_edges()), edge_set(g["edge_idx"]))
+        eng.close()
+    assert rel_err(outs["f16x3"], g["out_norm"]) < TOL
+    med, p99, worst, cnt = per_atom_err(outs["f16x3"], g["out_norm"])
+    assert p99 < P99_TOL, (med, p99, worst)
+    assert rel_err(outs["f16x3"], outs["f32"]) < TOL
+
+
+def test_split_fp16_generic_width_with_skin_batches_and_large_boxes():
+    """The generic-width split-fp16 kernels under skin reuse, in a batch (bit-identical to the boxes one by one) and on a box
+    large enough for several tiles per wave (trainers' default widths on the C2 workload's box at 4 000 atoms, against the fp32
+    engine: the reference modules cannot run that size here in reasonable time, the fp32 kernels are pinned at it)."""
+    g, cfg, sd = load_golden("tip3p774_w256_seed10")
+    box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+    species = g["node_feat"].reshape(-1) != 0
+    scal = (g["scaler_mean"], g["scaler_var"])
+    one = _engine(sd, n, box, rc, bond=g["bond"], scaler=scal, edge_dtype="f16x3")
+    skin = _engine(sd, n, box, rc, bond=g["bond"], scaler=scal, edge_dtype="f16x3", neighbor_skin=rc / 6)
+    rng = np.random.default_rng(8)
+    x = np.mod(g["pos"], box)
+    frames = []
+    for step in range(5):
+        x = x + rng.normal(0, 0.04, x.shape)
+        a = one.forward(torch.from_numpy(x).float(), species=species).cpu().numpy()
+        b = skin.forward(torch.from_numpy(x).float(), species=species).cpu().numpy()
+        assert rel_err(b, a) < TOL
+        frames.append((x.copy(), a))
+    batch = _engine(sd, n, box, rc, bond=g["bond"], scaler=scal, edge_dtype="f16x3", n_boxes=3)
+    xb = np.concatenate([f[0] for f in frames[:3]])
+    ob = batch.forward(torch.from_numpy(xb).float(), species=np.tile(species, 3)).cpu().numpy()
+    assert np.array_equal(ob, np.concatenate([f[1] for f in frames[:3]]))
+    for e in (one, skin, batch):
+        e.close()
+    pos, lbox = workloads.lj_box(4000)
+    wide = make_state_dict(ModelConfig(kind="lj", encoding_size=256, hidden_dim=128, edge_embedding_dim=256), 3, 7.0, 2.2)
+    f32 = _engine(wide, 4000, lbox, 3.0 * workloads.LJ_SIGMA)
+    f16 = _engine(wide, 4000, lbox, 3.0 * workloads.LJ_SIGMA, edge_dtype="f16x3")
+    xa = torch.from_numpy(pos).float()
+    ref, got = f32.forward(xa).cpu().numpy(), f16.forward(xa).cpu().numpy()
+    assert rel_err(got, ref) < TOL
+    med, p99, worst, cnt = per_atom_err(got, ref)
+    assert p99 < P99_TOL, (med, p99, worst)
+    assert np.array_equal(got, f16.forward(xa).cpu().numpy())          # run-to-run bit identity
+    f32.close(); f16.close()
