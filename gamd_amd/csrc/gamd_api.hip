@@ -105,6 +105,7 @@ struct gamd_handle {
     int H_true = 128, Eh_true = 128, D_true = 128;   // encoding_size, edge_embedding_dim, hidden_dim as given (<= the padded ones)
     int norm_bn = 0;                             // graph_conv.norm_layers are BatchNorm1d (running statistics in the state_dict)
     bool update_edge = false;                    // update_edge_emb=True: conv.<l>.edge_layer_norm keys in the state_dict
+    bool node_f16 = false;                       // node.hip's GEMMs in split-fp16 (reduced-precision edge modes, 128-wide kernels)
     bool wide_enc = false, wide_conv = false;    // generic-width kernels of wide.hip
     long long small_tile_limit = 512;            // fp32 path: at most this many 32-edge tiles -> conv_edge_small.hip
     std::map<std::string, HostTensor> host_w;
@@ -343,6 +344,19 @@ void pack16(const float* W, float* out, int ld = 128) {
                 for (int r = 0; r < 4; ++r)
                     out[(((ob * 8 + blk) * 64 + lane) * 4) + r] = W[(size_t)(16 * ob + (lane & 15)) * ld + 16 * blk + 4 * (lane >> 4) + r];
 }
+// the same matrix as (hi | lo) fp16 fragments for node.hip's split-fp16 GEMMs on 16x16x32: fragment ((ob * 4 + m) * 2 + part),
+// lane (o = lane & 15, g = lane >> 4), value j = W[16 ob + o][32 m + 16 (j >> 2) + 4 g + (j & 3)]  -- 64 KiB like the fp32 image
+void split_f16(float w, uint16_t* hi, uint16_t* lo);
+void pack16_f16x3(const float* W, uint16_t* out) {
+    for (int ob = 0; ob < 8; ++ob)
+        for (int m = 0; m < 4; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * m + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+                    const size_t hi = ((((size_t)(ob * 4 + m) * 2 + 0) * 64 + lane) * 8) + j, lo = ((((size_t)(ob * 4 + m) * 2 + 1) * 64 + lane) * 8) + j;
+                    split_f16(W[(size_t)(16 * ob + (lane & 15)) * 128 + k], out + hi, out + lo);
+                }
+}
 // encoder first layer W [128][n_feat]: MFMA step s covers features (2s, 2s+1); K padded to 48
 void pack_enc1(const float* W, int n_feat, float* out) {
     for (int tp = 0; tp < 4; ++tp)
@@ -576,6 +590,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     no.ln_inv_width = 1.0f / (float)h->H_true;
     no.ln_n_pad = (float)(h->H - h->H_true);
     no.norm_bn = h->norm_bn;
+    no.f16x3 = h->node_f16 ? 1 : 0;
     no.scale = (float)std::sqrt(h->scaler_var);
     no.shift = (float)h->scaler_mean;
     no.perm = h->perm.as<int>();
@@ -953,10 +968,14 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     };
     // node-side matrices: the 128-wide node kernel (node.hip) runs on 16x16x4 MFMAs with its own operand order; the
     // generic-width node kernel of wide.hip keeps the 32x32x2 fragment blocks
+    // Reduced-precision edge modes (bf16, split-fp16) on the 128-wide kernels: the node kernel's five GEMMs run in split-fp16 too
+    // (fp32-grade results at 3/16 of the fp32 matrix time, node.hip); GAMD_NODE_F32=1 keeps them on the fp32 pipe (A/B timing)
+    h->node_f16 = !h->wide_conv && h->cfg.edge_dtype != GAMD_EDGE_F32 && !getenv("GAMD_NODE_F32");
     auto put_node = [&](const HostTensor* t, int OB, int KB) {
         if (h->wide_conv) return put_blocks(t, OB, KB);
         size_t o = bb.add(GAMD_WFRAG_FLOATS);
-        pack16(t->data.data(), bb.host.data() + o);
+        if (h->node_f16) pack16_f16x3(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));
+        else pack16(t->data.data(), bb.host.data() + o);
         return o;
     };
     const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16;       // 128-wide only (gamd_create)

@@ -246,6 +246,7 @@ struct NodeArgs {
     float scale, shift;        // sqrt(var), mean of the force scaler (fp32 copy for the device path)
     float ln_inv_width, ln_n_pad;   // graph_conv.norm_layers over the TRUE node width (zero-padded to the 128-blocks): 1 / width, #pad
     int norm_bn;                    // 1: norm_layers are eval-mode BatchNorm1d (use_layer_norm=False), folded into ln_g / ln_b
+    int f16x3;                      // 1 (node.hip, reduced-precision edge modes): node-side matrices are (hi | lo) fp16 images, GEMMs in split-fp16
     const int* perm;
     // outputs
     float* h_out;              // [n][128]

@@ -32,6 +32,10 @@
 
 namespace {
 
+typedef _Float16 nf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 nf16x2 __attribute__((ext_vector_type(2)));
+typedef float nf32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int NT = 16;                         // atoms per tile
 constexpr int XLD = GAMD_XLD;                  // padded row stride of the exchange buffer (floats)
 
@@ -66,16 +70,53 @@ __device__ __forceinline__ void gemm16_half(const WHalf& h, int half, const f32x
         }
 }
 
+// ---- split-fp16 form of the same GEMM (reduced-precision edge modes: the node side keeps fp32-grade arithmetic at 3/16 of
+// the fp32 matrix time; gamd_f16x3.h has the error analysis) on v_mfma_f32_16x16x32_f16.  K step m covers features
+// 32 m .. 32 m + 31; a lane's 8 operand values of it are its chain16 quads XB[2m], XB[2m + 1] (K position 8 g + j <-> feature
+// 32 m + 16 (j >> 2) + 4 g + (j & 3)): the C/D layout of one GEMM is still the B operand of the next without a shuffle, and the
+// weights are packed to match (pack16_f16x3 in gamd_api.hip): WHalf h.w[o * 4 + mm * 2 + part] = (hi | lo) fragment of row
+// block 2 w + o, K step 2 half + mm.  24 MFMAs of 16 cycles per GEMM and wave instead of 64 of 32.
+struct XSplit { nf16x8 h[4], l[4]; };
+__device__ __forceinline__ void split16(const f32x4 (&XB)[8], XSplit& s) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x4& q = XB[2 * m + (j >> 2)];
+            const nf32x2 x = {q[j & 3], q[(j & 3) + 1]};
+            const nf16x2 hi = __builtin_convertvector(x, nf16x2);
+            const nf32x2 rem = x - __builtin_convertvector(hi, nf32x2);
+            const nf16x2 lo = __builtin_convertvector(rem, nf16x2);
+            s.h[m][j] = hi[0]; s.h[m][j + 1] = hi[1];
+            s.l[m][j] = lo[0]; s.l[m][j + 1] = lo[1];
+        }
+}
+__device__ __forceinline__ void gemm16_half_f16(const WHalf& h, int half, const XSplit& X, f32x4 (&acc)[2], bool skip = false) {
+    if (skip) { asm volatile("" ::"v"(h.w[0]), "v"(h.w[7]), "v"(X.h[0])); return; }
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm) {
+        const int m = 2 * half + mm;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const nf16x8 wh = __builtin_bit_cast(nf16x8, h.w[o * 4 + mm * 2]), wl = __builtin_bit_cast(nf16x8, h.w[o * 4 + mm * 2 + 1]);
+            acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, X.l[m], acc[o], 0, 0, 0);
+            acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, X.h[m], acc[o], 0, 0, 0);
+            acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, X.h[m], acc[o], 0, 0, 0);
+        }
+    }
+}
+
 // One 128x128 GEMM.  On entry `wn` holds (or has in flight) the FIRST K half of this GEMM's weights W; on exit it holds the
 // first half of `next` (the matrix of the GEMM that follows; NEXT = false: none).  The compiler barriers pin the fetches
 // where they are written: hipcc otherwise hoists every load to the top of the kernel and pays with 50 more registers.
-template <bool NEXT, bool SKIP = false>
-__device__ __forceinline__ void gemm16(const float* W, const float* next, WHalf& wn, const f32x4 (&XB)[8], f32x4 (&acc)[2], int w, int lane) {
+// (The (hi | lo) fp16 image of a matrix has the size and the quarter / half structure of the fp32 one: same fetches.)
+template <bool NEXT, bool SKIP, bool F16, typename XT>
+__device__ __forceinline__ void gemm16(const float* W, const float* next, WHalf& wn, const XT& XB, f32x4 (&acc)[2], int w, int lane) {
     WHalf cur = wn;
     asm volatile("" ::: "memory");
     load_whalf(W, w, lane, 1, wn);                          // second half: lands during the first half's 32 MFMAs
     asm volatile("" ::: "memory");
-    gemm16_half(cur, 0, XB, acc, SKIP);
+    if constexpr (F16) gemm16_half_f16(cur, 0, XB, acc, SKIP); else gemm16_half(cur, 0, XB, acc, SKIP);
     __builtin_amdgcn_sched_barrier(0);
     cur = wn;
     if (NEXT) {
@@ -83,7 +124,7 @@ __device__ __forceinline__ void gemm16(const float* W, const float* next, WHalf&
         load_whalf(next, w, lane, 0, wn);                   // next GEMM's first half: lands during the second half + exchange
         asm volatile("" ::: "memory");
     }
-    gemm16_half(cur, 1, XB, acc, SKIP);
+    if constexpr (F16) gemm16_half_f16(cur, 1, XB, acc, SKIP); else gemm16_half(cur, 1, XB, acc, SKIP);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -114,7 +155,8 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // NABL (profiling build only, GAMD_NODE_VARIANT; wrong results): 1 = no piece loads (agg = 0: the bound of letting the conv kernels
 // write agg), 2 = every weight fragment from one cache-hot kilobyte (the bound of any better weight prefetch), 4 = no GEMMs
-template <int NABL>
+// F16: the five GEMMs in split-fp16 (the reduced-precision edge modes; weights packed by pack16_f16x3)
+template <int NABL, bool F16 = false>
 __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) float xbuf[NT * XLD];
     __shared__ float obuf[4][NT][3];
@@ -142,6 +184,10 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         a.post.wpep = a.post.wphip = a.pre.wsp = a.pre.wdp = a.pre.wpdp = a.dec_w1p = hot;
     }
     f32x4 XB[8];          // full activation rows (chain16 layout)
+    XSplit XS;            // F16: their (hi, lo) fp16 operand images
+#define GEMM16(NEXT, W, NXT) do { if constexpr (F16) gemm16<NEXT, (NABL & 4) != 0, true>(W, NXT, wn, XS, mine, w, lane); \
+                                  else gemm16<NEXT, (NABL & 4) != 0, false>(W, NXT, wn, XB, mine, w, lane); } while (0)
+#define SPLIT16() do { if constexpr (F16) split16(XB, XS); } while (0)
     f32x4 mine[2];        // this wave's 32 output features
     WHalf wn;             // the weight half that the next 32 MFMAs need (fetched one half ahead)
 
@@ -186,19 +232,21 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         asm volatile("" ::: "memory");                            // the weight fetch stays behind the piece loads (registers)
         load_whalf(a.post.wpep, w, lane, 0, wn);                  // in flight during the exchange
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = agg
+        SPLIT16();
         NMARK(2);                                                  // 2: exchange 1
         mine[0] = p_in[0]; mine[1] = p_in[1];
-        gemm16<true, (NABL & 4) != 0>(a.post.wpep, a.post.wphip, wn, XB, mine, w, lane);
+        GEMM16(true, a.post.wpep, a.post.wphip);
         NMARK(3);                                                  // 3: GEMM phi_edge
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[o][r] = gamd_silu_hw(mine[o][r]);
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = SiLU(P + phi_edge(agg))
+        SPLIT16();
         NMARK(4);                                                  // 4: SiLU + exchange 2
         load16(a.post.bphi, w, g, mine);
         load16(a.h_in + row, w, g, h_res);                        // residual: lands during the GEMM
-        gemm16<true, (NABL & 4) != 0>(a.post.wphip, a.mode != 2 ? a.pre.wsp : a.dec_w1p, wn, XB, mine, w, lane);
+        GEMM16(true, a.post.wphip, a.mode != 2 ? a.pre.wsp : a.dec_w1p);
         mine[0] += h_res[0]; mine[1] += h_res[1];                 // residual
         if (valid) store16(a.h_out + row, w, g, mine);
         NMARK(5);                                                  // 5: GEMM phi + residual
@@ -242,6 +290,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         }
         if (valid && !a.hn_perm) store16(a.hn_out + row, w, g, mine);
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = hn
+        SPLIT16();
         NMARK(6);                                                  // 6: LayerNorm + exchange 3
         if (a.hn_perm) {
             // feature-permuted copy for the row-layout gather of conv_edge_f16x3.hip, written from the assembled rows
@@ -256,16 +305,16 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
             }
         }
         load16(a.pre.bS, w, g, mine);
-        gemm16<true, (NABL & 4) != 0>(a.pre.wsp, a.pre.wdp, wn, XB, mine, w, lane);
+        GEMM16(true, a.pre.wsp, a.pre.wdp);
         if (valid) store16(a.S_out + row, w, g, mine);
         NMARK(7);                                                  // 7: GEMM S
         mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         mine[1] = mine[0];
-        gemm16<true, (NABL & 4) != 0>(a.pre.wdp, a.pre.wpdp, wn, XB, mine, w, lane);
+        GEMM16(true, a.pre.wdp, a.pre.wpdp);
         if (valid) store16(a.D_out + row, w, g, mine);
         NMARK(8);                                                  // 8: GEMM D
         load16(a.pre.bP, w, g, mine);
-        gemm16<false, (NABL & 4) != 0>(a.pre.wpdp, nullptr, wn, XB, mine, w, lane);
+        GEMM16(false, a.pre.wpdp, nullptr);
         if (valid) store16(a.P_out + row, w, g, mine);
         NMARK(9);                                                  // 9: GEMM P
 #ifdef GAMD_PROFILING
@@ -277,8 +326,9 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
     } else {
         // ---- decoder: Lin(128,128) GELU Lin(128,3); denormalise -------------------------------
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = h'
+        SPLIT16();
         load16(a.dec_b1, w, g, mine);
-        gemm16<false, (NABL & 4) != 0>(a.dec_w1p, nullptr, wn, XB, mine, w, lane);
+        GEMM16(false, a.dec_w1p, nullptr);
         float o3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
@@ -314,6 +364,8 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
 }
 
 #undef NMARK
+#undef GEMM16
+#undef SPLIT16
 
 }  // namespace
 
@@ -323,15 +375,16 @@ int launch_node(const NodeArgs& a, hipStream_t st) {
     static int v = -1;
     if (v < 0) { const char* e = getenv("GAMD_NODE_VARIANT"); v = e ? atoi(e) : 0; }
     switch (v) {
-        case 1: hipLaunchKernelGGL(k_node<1>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
-        case 2: hipLaunchKernelGGL(k_node<2>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
-        case 3: hipLaunchKernelGGL(k_node<3>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
-        case 4: hipLaunchKernelGGL(k_node<4>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
-        case 7: hipLaunchKernelGGL(k_node<7>, dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 1: hipLaunchKernelGGL((k_node<1>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 2: hipLaunchKernelGGL((k_node<2>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 3: hipLaunchKernelGGL((k_node<3>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 4: hipLaunchKernelGGL((k_node<4>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        case 7: hipLaunchKernelGGL((k_node<7>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
         default: break;
     }
 #endif
-    hipLaunchKernelGGL(k_node<0>, dim3(nb), dim3(256), 0, st, a);
+    if (a.f16x3) hipLaunchKernelGGL((k_node<0, true>), dim3(nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_node<0, false>), dim3(nb), dim3(256), 0, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
 }

@@ -61,7 +61,8 @@ typedef struct gamd_config {
     int64_t edge_capacity;   /* 0 = estimate from density */
     int32_t keep_stages;     /* 1 = keep per-stage tensors for the debug getters */
     int32_t edge_dtype;      /* GAMD_EDGE_F32 (bit-exact fp32 MFMA, default) | GAMD_EDGE_BF16 (BASELINE config 5: edge-MLP
-                                operands rounded to bf16, fp32 accumulate; node side, S/D adds, SiLU, sums stay fp32)
+                                operands rounded to bf16, fp32 accumulate; S/D adds, SiLU, sums in fp32; the node side's GEMMs fp32-grade: split-fp16
+                                as in F16X3)
                                 | GAMD_EDGE_F16X3 (fp32-grade edge-MLP on the fp16 matrix pipe: every operand split into
                                 hi + lo fp16, W x = Wh xh + (Wh xl + Wl xh), fp32 accumulate; same parity bar as F32).
                                 BF16: 128 / 128 / 128 RBF-expanded configuration only; F16X3: every width and feature set
