@@ -13,6 +13,16 @@ for w in c2 c3 c5 c5b c1 c1_batch dft; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -- $B --steps 50 --warmup 5 --workload $w > $out/trace_$w.log 2>&1
   python3 tools/profile_summary.py stats $out/trace_$w > $out/trace_$w.md
 done
+# the opt-in split-fp16 edge MLP: C2 and the DFT-water configuration
+for w in c2 dft; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_${w}_f16x3 -- $B --steps 50 --warmup 5 --workload $w --edge-dtype f16x3 > $out/trace_${w}_f16x3.log 2>&1
+  python3 tools/profile_summary.py stats $out/trace_${w}_f16x3 > $out/trace_${w}_f16x3.md
+done
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq_c2_f16x3 -- $B --steps 5 --warmup 2 --workload c2 --edge-dtype f16x3 > $out/pmc_sq_c2_f16x3.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch_c2_f16x3 -- $B --steps 5 --warmup 2 --workload c2 --edge-dtype f16x3 > $out/pmc_fetch_c2_f16x3.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write_c2_f16x3 -- $B --steps 5 --warmup 2 --workload c2 --edge-dtype f16x3 > $out/pmc_write_c2_f16x3.log 2>&1
+python3 tools/profile_summary.py pmc $out/pmc_sq_c2_f16x3 $out/pmc_fetch_c2_f16x3 $out/pmc_write_c2_f16x3 > $out/pmc_c2_f16x3.md
+GAMD_LIB=gamd_amd/libgamd_hip_prof.so GAMD_F16X3_TIME=1 python3 tools/f16x3_marks.py > $out/f16x3_marks.log 2>&1
 for w in c2 c5; do
   rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq_$w -- $B --steps 5 --warmup 2 --workload $w > $out/pmc_sq_$w.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch_$w -- $B --steps 5 --warmup 2 --workload $w > $out/pmc_fetch_$w.log 2>&1
