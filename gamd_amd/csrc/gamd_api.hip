@@ -966,13 +966,22 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
                         bb.host.data() + o + (size_t)(ob * KB + kb) * GAMD_WFRAG_FLOATS, 128 * KB);
         return o;
     };
+    // [128 OB][128 KB] matrix -> OB*KB [hi | lo] fp16 images, block (ob, kb) at index ob*KB + kb (the order put_blocks uses)
+    auto put_blocks_f16x3_fn = [&](const HostTensor* t, int OB, int KB) {
+        size_t o = bb.add((size_t)OB * KB * GAMD_WFRAG_FLOATS);
+        for (int ob = 0; ob < OB; ++ob)
+            for (int kb = 0; kb < KB; ++kb)
+                pack128_f16x3(t->data.data() + (size_t)128 * ob * 128 * KB + 128 * kb,
+                              reinterpret_cast<uint16_t*>(bb.host.data() + o + (size_t)(ob * KB + kb) * GAMD_WFRAG_FLOATS), 128 * KB);
+        return o;
+    };
     // node-side matrices: the 128-wide node kernel (node.hip) runs on 16x16x4 MFMAs with its own operand order; the
     // generic-width node kernel of wide.hip keeps the 32x32x2 fragment blocks
     // Reduced-precision edge modes (bf16, split-fp16) on the 128-wide kernels: the node kernel's five GEMMs run in split-fp16 too
-    // (fp32-grade results at 3/16 of the fp32 matrix time, node.hip); GAMD_NODE_F32=1 keeps them on the fp32 pipe (A/B timing)
-    h->node_f16 = !h->wide_conv && h->cfg.edge_dtype != GAMD_EDGE_F32 && !getenv("GAMD_NODE_F32");
+    // (fp32-grade results at 3/16 of the fp32 matrix time, node.hip and wide.hip's k_node_wide); GAMD_NODE_F32=1 keeps them on the fp32 pipe (A/B timing)
+    h->node_f16 = h->cfg.edge_dtype != GAMD_EDGE_F32 && !getenv("GAMD_NODE_F32");
     auto put_node = [&](const HostTensor* t, int OB, int KB) {
-        if (h->wide_conv) return put_blocks(t, OB, KB);
+        if (h->wide_conv) return h->node_f16 ? put_blocks_f16x3_fn(t, OB, KB) : put_blocks(t, OB, KB);
         size_t o = bb.add(GAMD_WFRAG_FLOATS);
         if (h->node_f16) pack16_f16x3(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));
         else pack16(t->data.data(), bb.host.data() + o);
@@ -986,15 +995,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         pack128_f16x3(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));
         return o;
     };
-    // [128 OB][128 KB] matrix -> OB*KB [hi | lo] fp16 images, block (ob, kb) at index ob*KB + kb (the order put_blocks uses)
-    auto put_blocks_f16x3 = [&](const HostTensor* t, int OB, int KB) {
-        size_t o = bb.add((size_t)OB * KB * GAMD_WFRAG_FLOATS);
-        for (int ob = 0; ob < OB; ++ob)
-            for (int kb = 0; kb < KB; ++kb)
-                pack128_f16x3(t->data.data() + (size_t)128 * ob * 128 * KB + 128 * kb,
-                              reinterpret_cast<uint16_t*>(bb.host.data() + o + (size_t)(ob * KB + kb) * GAMD_WFRAG_FLOATS), 128 * KB);
-        return o;
-    };
+    auto put_blocks_f16x3 = put_blocks_f16x3_fn;
     auto put_edge_bf16 = [&](const HostTensor* t) {
         size_t o = bb.add(GAMD_WFRAG_FLOATS / 2);
         pack128_bf16(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));

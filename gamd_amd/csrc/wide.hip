@@ -449,7 +449,28 @@ __device__ __forceinline__ void wq_gemm(const WQ& wq, const f32x16 (&X)[4], f32x
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
 }
-template <int HT>
+// split-fp16 form (the reduced-precision edge mode of the generic widths, wide_f16x3.hip): the block is a (hi | lo) fp16 image
+// (pack128_f16x3), a quarter = 8 + 8 fragments of 16 bytes per lane; 24 MFMAs of 32 cycles per block GEMM instead of 64 of 64.
+// The activations are split per K step on the fly (gamd_split8): 160 VALU per block GEMM, nothing next to the MFMAs saved.
+__device__ __forceinline__ void wq_load_f16(const float* __restrict__ Wp, int quarter, int lane, WQ& o) {
+    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 8 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { o.w[i] = W[i * 64]; o.w[8 + i] = W[2048 + i * 64]; }
+}
+__device__ __forceinline__ void wq_gemm_f16(const WQ& wq, const f32x16 (&X)[4], f32x16& acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f16x8 xh, xl;
+            gamd_split8(X[t], u, xh, xl);
+            const f16x8 wh = __builtin_bit_cast(f16x8, wq.w[t * 2 + u]), wl = __builtin_bit_cast(f16x8, wq.w[8 + t * 2 + u]);
+            acc = mfma_f16(wh, xl, acc);
+            acc = mfma_f16(wl, xh, acc);
+            acc = mfma_f16(wh, xh, acc);
+        }
+}
+template <int HT, bool F16 = false>
 __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
     constexpr int H = 128 * HT;
     constexpr int XLDW = H + 4;
@@ -489,13 +510,15 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         WQ& nxt = (st & 1) ? wqa : wqb;
         const float* np_ = wptr(st + 1);
         asm volatile("" ::: "memory");
-        if (np_) wq_load(np_, quarter, lane, nxt);
+        if (np_) { if (F16) wq_load_f16(np_, quarter, lane, nxt); else wq_load(np_, quarter, lane, nxt); }
         asm volatile("" ::: "memory");
-        wq_gemm(cur, Xb, acc);
+        if (F16) wq_gemm_f16(cur, Xb, acc); else wq_gemm(cur, Xb, acc);
         __builtin_amdgcn_sched_barrier(0);
     };
-    if (a.mode == 0) wq_load(wptr(2 * HT), quarter, lane, wqa);      // (2 HT is even: buffer a)
-    else wq_load(wptr(0), quarter, lane, wqa);
+    {
+        const float* w0 = a.mode == 0 ? wptr(2 * HT) : wptr(0);          // (2 HT is even: buffer a)
+        if (F16) wq_load_f16(w0, quarter, lane, wqa); else wq_load(w0, quarter, lane, wqa);
+    }
 
     if (a.mode == 0) {
 #pragma unroll
@@ -713,8 +736,10 @@ int launch_edge_update(const EdgeUpdateArgs& a, int ht, int n_blocks, hipStream_
 
 int launch_node_wide(const NodeArgs& a, int ht, hipStream_t st) {
     const int nb = (a.n + GAMD_TILE - 1) / GAMD_TILE;
-    if (ht == 1) hipLaunchKernelGGL(k_node_wide<1>, dim3(nb), dim3(256), 0, st, a);
-    else if (ht == 2) hipLaunchKernelGGL(k_node_wide<2>, dim3(nb), dim3(256), 0, st, a);
+    if (ht == 1 && !a.f16x3) hipLaunchKernelGGL((k_node_wide<1, false>), dim3(nb), dim3(256), 0, st, a);
+    else if (ht == 2 && !a.f16x3) hipLaunchKernelGGL((k_node_wide<2, false>), dim3(nb), dim3(256), 0, st, a);
+    else if (ht == 1) hipLaunchKernelGGL((k_node_wide<1, true>), dim3(nb), dim3(256), 0, st, a);
+    else if (ht == 2) hipLaunchKernelGGL((k_node_wide<2, true>), dim3(nb), dim3(256), 0, st, a);
     else return -22;
     GAMD_CHECK_LAUNCH();
     return 0;
