@@ -476,3 +476,59 @@ def test_split_fp16_generic_width_with_skin_batches_and_large_boxes():
     assert p99 < P99_TOL, (med, p99, worst)
     assert np.array_equal(got, f16.forward(xa).cpu().numpy())          # run-to-run bit identity
     f32.close(); f16.close()
+
+
+# ---- the feature matrix, sampled: widths x model flavour x normalisation x update_edge x expand_edge x edge dtype ------------------
+def _matrix_cases():
+    rng = np.random.default_rng(2026)
+    cases = []
+    for i in range(14):
+        kind = ["lj", "water", "dynbox"][i % 3]
+        upd = kind == "dynbox" and i % 2 == 0
+        enc = int(rng.choice([24, 64, 100, 128, 160, 256]))
+        emb = enc if upd else int(rng.choice([32, 72, 128, 200, 256]))
+        cases.append(dict(kind=kind, encoding_size=enc, edge_embedding_dim=emb, hidden_dim=int(rng.choice([16, 64, 96, 128])),
+                          conv_layer=int(rng.integers(1, 6)), use_bond=kind == "water" and i % 4 != 1,
+                          n_rbf=0 if (kind == "dynbox" and i % 3 == 0) else 40, use_layer_norm=bool(i % 5 != 2), update_edge=upd,
+                          edge_dtype="f16x3" if i % 2 else "f32", skin=bool(i % 3 == 1), seed=100 + i))
+    return cases
+
+
+@pytest.mark.parametrize("case", _matrix_cases(), ids=lambda c: "{kind}-{encoding_size}-{hidden_dim}-{edge_embedding_dim}-L{conv_layer}-{edge_dtype}".format(**c))
+def test_sampled_feature_matrix_against_the_oracle(case):
+    """Fourteen seeded combinations of everything a state_dict / constructor can select (any width up to 256 / 128 / 256, 1-5
+    layers, LayerNorm or BatchNorm, update_edge, expand_edge on / off, bond feature, the three model flavours, fp32 or
+    split-fp16 edge MLP, exact or skin neighbour mode) against the oracle, whose branches are each pinned by a
+    reference-generated golden (tests/test_oracle_golden.py): forces at the fp32 bar, per-atom p99 included."""
+    c = dict(case)
+    edge_dtype, skin, seed = c.pop("edge_dtype"), c.pop("skin"), c.pop("seed")
+    cfg = ModelConfig(**c)
+    sd = make_state_dict(cfg, seed, 2.9, 1.1)
+    if cfg.kind == "lj":
+        pos, box = workloads.lj_box(260, seed=seed)
+        species = bonds = feat = None
+        rc, flavour = 7.5, "jaxmd"
+    else:
+        pos, box, species, bonds = workloads.water_box(90, seed=seed)
+        feat, rc = torch.from_numpy(species.astype(np.float32)).view(-1, 1), 4.2
+        flavour = "torch" if cfg.kind == "dynbox" else "jaxmd"
+        if not cfg.use_bond:
+            bonds = None
+    n = pos.shape[0]
+    eng = _engine(sd, n, box, rc, bond=bonds, nbr_flavour=flavour, edge_dtype=edge_dtype, neighbor_skin=rc / 6 if skin else 0.0)
+    p = torch.remainder(torch.from_numpy(pos).float(), float(box))
+    out = eng.forward(p, species=species).cpu().numpy()
+    if skin:                                   # a second call on moved positions reuses the candidate list
+        p = torch.remainder(p + 0.03 * torch.from_numpy(np.random.default_rng(seed).normal(size=pos.shape)).float(), float(box))
+        out = eng.forward(p, species=species).cpu().numpy()
+        assert eng.skin_stats()[0] == 1
+    edges = orc.neighbor_edges(p, box, rc, flavour)
+    assert np.array_equal(edge_set(eng.debug_edges()), edge_set(edges.numpy()))
+    if cfg.kind == "dynbox":
+        ref = orc.forward_dynamic_box(sd, p, feat, np.full(3, box, dtype=np.float32), rc).numpy()
+    else:
+        ref = orc.forward(sd, p, edges, box, feat=feat, bond=bonds).numpy()
+    assert rel_err(out, ref) < TOL, case
+    med, p99, worst, cnt = per_atom_err(out, ref)
+    assert p99 < P99_TOL, (case, med, p99, worst)
+    eng.close()
