@@ -10,7 +10,7 @@
 #include <cstdio>
 #include <vector>
 
-struct OpSet { gamd_u32x4_t w[4][2][2]; };
+// (OpSet: gamd_f16x3.h)
 
 __device__ __forceinline__ void put_pair(OpSet& P, int t, int r0, float x0, float x1) {
     const gamd_f32x2_t x = {x0, x1};
