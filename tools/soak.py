@@ -8,7 +8,9 @@
   3. C5 bf16, 3 000 steps: finite, forces within the restated tolerance of the fp32 path on the final positions;
   4. C2 split-fp16 (f16x3), 2 000 steps run TWICE: bit-identical (its weight copies are issued from inline assembly and
      waited for by hand: a missing wait shows as a run-to-run difference), forces within 1e-5 of the fp32 path at the end;
-  5. a batch of 38 x 258-atom boxes, 2 000 steps run TWICE: bit-identical, every box finite, COM drift removed when asked."""
+  5. a batch of 38 x 258-atom boxes, 2 000 steps run TWICE: bit-identical, every box finite, COM drift removed when asked;
+  6. the DFT-water widths (256 / 128 / 256 x 5) in split-fp16 on rigid water, 1 000 steps run TWICE: bit-identical, forces within
+     1e-5 of the fp32 path at the end."""
 import hashlib
 import os
 import sys
@@ -122,3 +124,27 @@ for rep in range(2):
 print(f"LJ batch {nb} x 258: two 2000-step runs bit-identical: {runs[0] == runs[1]}; finite={bool(torch.isfinite(x).all())}; "
       f"largest per-box COM speed {vcom:.3e} A/ps")
 assert runs[0] == runs[1] and torch.isfinite(x).all() and vcom < 0.5      # what the last two half-kicks add; the drift itself is removed every step
+
+# ---- 6. generic-width split-fp16 (wide_f16x3.hip): the DFT-water widths on rigid water, run TWICE ---------------------------
+cfgw = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
+sdd = make_state_dict(cfgw, 5, 3.1, 1.2)
+posd, boxd, speciesd, _ = wk.water_box(258, seed=11, jitter=0.0, wrap=False)
+runs = []
+for rep in range(2):
+    eng = GamdForce(sdd, posd.shape[0], boxd, 5.0, nbr_flavour="torch", cfg=cfgw, neighbor_skin=5.0 / 6, edge_dtype="f16x3", scaler=(0.0, 25.0))
+    x = torch.from_numpy(posd).float().cuda()
+    v = torch.zeros_like(x)
+    f = eng.forward(x, species=speciesd, denormalize=True).clone()
+    for chunk in range(4):
+        eng.md_run(x, v, f, 250, dt_ps=0.0005, mass_amu=wk.MASS_O, mass_h_amu=wk.MASS_H, temperature_k=300.0, species=speciesd,
+                   rigid_water=True, r_oh=wk.TIP3P_R_OH, r_hh=wk.TIP3P_R_HH, first_step=chunk * 250, seed=4)
+    runs.append((sha(x), sha(v), sha(f)))
+    if rep == 0:
+        ref = GamdForce(sdd, posd.shape[0], boxd, 5.0, nbr_flavour="torch", cfg=cfgw, scaler=(0.0, 25.0))
+        f32 = ref.forward(x, species=speciesd, denormalize=True)
+        errw = float((f32 - eng.forward(x, species=speciesd, denormalize=True)).abs().max() / f32.abs().max())
+        ref.close()
+    eng.close()
+print(f"DFT widths f16x3: two 1000-step rigid-water runs bit-identical: {runs[0] == runs[1]}; finite={bool(torch.isfinite(x).all())}; "
+      f"f16x3-vs-f32 force err on the final positions={errw:.2e}")
+assert runs[0] == runs[1] and torch.isfinite(x).all() and errw < 1e-5
