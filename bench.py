@@ -159,8 +159,6 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         cfg = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
         w.sd = make_state_dict(cfg, 5, 3.1 * bohr, 1.2 * bohr)
         mean, var = SHIPPED_SCALERS["dft"]
-        if edge_dtype == "bf16":
-            raise SystemExit("--workload dft: the bf16 edge MLP is built for the 128-wide configuration (use f32 or f16x3)")
         w.eng = GamdForce(w.sd, pos.shape[0], box, 9.5, nbr_flavour="torch", cfg=cfg, device=dev, neighbor_skin=skin * 9.5,
                           scaler=(mean * CONV, var * CONV ** 2), edge_dtype=edge_dtype)   # hartree/bohr -> kJ/mol/nm folded into the scaler
         w.cutoff = 9.5
@@ -171,8 +169,10 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         w.flop_per_edge, w.kernel_name = 2 * 128 * 128 * (2 + 2 + 2), "k_conv_edge_wide<2,2>"
         if edge_dtype == "f16x3":
             w.dtype_name, w.kernel_name = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)", "k_conv_edge_f16x3_wide<2,2>"
+        elif edge_dtype == "bf16":
+            w.dtype_name, w.kernel_name = "bf16", "k_conv_edge_bf16_wide<2,2>"
         w.label = ("DFT-water configuration: 258 rigid molecules = 774 atoms, positions/box in bohr (L = 37.8), cutoff 9.5, "
-                   f"WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, {'split-fp16 edge MLP' if edge_dtype == 'f16x3' else 'fp32'}, "
+                   f"WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, {dict(f16x3='split-fp16 edge MLP', bf16='bf16 edge-MLP operands / fp32 accumulate').get(edge_dtype, 'fp32')}, "
                    "random-init weights (seed 5), SETTLE on device, 1 box per GPU")
     elif name in ("c2", "c1", "c1_batch"):
         n = N_ATOMS if name == "c2" else 258
@@ -349,8 +349,9 @@ def roofline_block(w, n_edges, conv_ms, conv_n):
         # SURVEY.md §8d "neighbour gather" figure (per edge: 4 B index + 512 B h[src] row + 512 B S[src] row) against HBM
         # peak.  These are ALGORITHMIC gather bytes: the rows are served from L2 (node tables are 3 MB), the HBM traffic
         # of the kernel is far lower; the kernel itself is VALU/MFMA-issue bound
-        gbytes = n_edges * 1028.0
-        r = {"kernel": "k_conv_edge_bf16", "bound": "hbm", "achieved": gbytes / (avg_ms * 1e-3) / 1e9,
+        hn_row = 512.0 * (w.flop_per_edge // (2 * 128 * 128) - 2) / 2 if w.name == "dft" else 512.0     # 256-wide models: 1 KiB hn rows
+        gbytes = n_edges * (4.0 + hn_row + 512.0)
+        r = {"kernel": w.kernel_name if w.kernel_name.startswith("k_conv_edge_bf16") else "k_conv_edge_bf16", "bound": "hbm", "achieved": gbytes / (avg_ms * 1e-3) / 1e9,
              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbytes / (avg_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), "traffic": None,
              "avg_launch_ms": avg_ms, "launches": conv_n, "bytes_per_launch": gbytes,
              "note": "algorithmic neighbour-gather bytes (L2-served), not HBM traffic"}

@@ -375,7 +375,7 @@ uint16_t f2bf(float x) {                       // round to nearest even
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-void pack128_bf16(const float* W, uint16_t* out) {
+void pack128_bf16(const float* W, uint16_t* out, int ld = 128) {
     for (int tp = 0; tp < 4; ++tp)
         for (int t = 0; t < 4; ++t)
             for (int u = 0; u < 2; ++u)
@@ -383,7 +383,7 @@ void pack128_bf16(const float* W, uint16_t* out) {
                     for (int j = 0; j < 8; ++j) {
                         const int r = 8 * u + j, half = lane >> 5;
                         const int n = 32 * tp + (lane & 31), k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        out[((((tp * 4 + t) * 2 + u) * 64 + lane) * 8) + j] = f2bf(W[n * 128 + k]);
+                        out[((((tp * 4 + t) * 2 + u) * 64 + lane) * 8) + j] = f2bf(W[(size_t)n * ld + k]);
                     }
 }
 void pack_enc1_bf16(const float* W, int n_feat, uint16_t* out) {     // [tp][s][lane][8], K padded to 48
@@ -530,7 +530,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.w1p = h->enc_w1p; ea.w2p = h->enc_w2p; ea.w3p = h->enc_w3p;
     ea.b1 = h->enc_b1; ea.b2 = h->enc_b2; ea.b3 = h->enc_b3;
     ea.ln_g = h->enc_lng; ea.ln_b = h->enc_lnb;
-    ea.e_format = (h->wide_enc && h->cfg.edge_dtype == GAMD_EDGE_F16X3) ? 2 : 0;
+    ea.e_format = !h->wide_enc ? 0 : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? 2 : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? 1 : 0;
     ea.e_frag = h->e_frag.as<float>();
     ea.e_cap = h->e_cap;
     ea.feat_dbg = h->cfg.keep_stages ? h->feat_dbg.as<float>() : nullptr;
@@ -623,6 +623,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.tdbg = h->tdbg.as<long long>();
         if ((r = tev_begin(l))) return r;                        // kind l: conv-layer edge kernel of layer l
         r = h->wide_conv ? (h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3_wide(ca, h->EHT, h->HT, h->n_cu, st)
+                            : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16_wide(ca, h->EHT, h->HT, h->n_cu, st)
                             : small_tiles > 0 ? launch_conv_edge_small_wide(ca, h->EHT, h->HT, small_tiles, st)
                                               : launch_conv_edge_wide(ca, h->EHT, h->HT, h->n_cu, st))
             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st)
@@ -792,13 +793,10 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     const int H = H_true <= 128 ? 128 : 256, Eh = Eh_true <= 128 ? 128 : 256;
     const bool exact128 = H_true == 128 && Eh_true == 128 && D_true == 128;
     const bool generic = H != 128 || Eh != 128 || cfg->no_expand_edge;
-    // reduced-precision edge MLPs: bf16 for the 128-wide RBF-expanded configuration; split-fp16 (fp32-grade) for every width
-    // and both feature sets (128 / 128 / 128 expanded: the specialised kernels; anything else: wide.hip's encoder writing the
-    // split operands + wide_f16x3.hip)
-    if ((generic || !exact128) && cfg->edge_dtype == GAMD_EDGE_BF16)
-        return fail(-22, "the bf16 edge-MLP is built for the 128-wide RBF-expanded configuration only");
-    if (cfg->edge_dtype == GAMD_EDGE_F16X3 && H == 256 && (long long)cfg->n_atoms * n_boxes > (1ll << 22) - 2)
-        return fail(-22, "split-fp16 with encoding_size > 128: at most 2^22 - 2 atoms per handle (32-bit byte offsets into hn)");
+    // reduced-precision edge MLPs (bf16, fp32-grade split-fp16) exist for every width and both feature sets: 128 / 128 / 128
+    // expanded runs the specialised kernels, anything else wide.hip's encoder writing the operands + wide_bf16.hip / wide_f16x3.hip
+    if (cfg->edge_dtype != GAMD_EDGE_F32 && H == 256 && (long long)cfg->n_atoms * n_boxes > (1ll << 22) - 2)
+        return fail(-22, "bf16 / split-fp16 with encoding_size > 128: at most 2^22 - 2 atoms per handle (32-bit byte offsets into hn)");
     gamd_handle* h = new gamd_handle();
     h->cfg = *cfg;
     h->dev = cfg->device;
@@ -811,10 +809,10 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     h->skin = cfg->neighbor_skin;
     if (cfg->small_tile_limit != 0) h->small_tile_limit = cfg->small_tile_limit < 0 ? -1 : cfg->small_tile_limit;
     const bool forced = (cfg->kernel_select & GAMD_KSEL_FORCE_GENERIC_WIDTH) && cfg->edge_dtype == GAMD_EDGE_F32;
-    // split-fp16 outside 128 / 128 / 128 expanded: encoder, conv and node kernels all take the generic-width route
-    const bool f16x3_generic = cfg->edge_dtype == GAMD_EDGE_F16X3 && (generic || !exact128);
-    h->wide_enc = generic || forced || f16x3_generic;
-    h->wide_conv = H != 128 || Eh != 128 || forced || f16x3_generic;
+    // bf16 / split-fp16 outside 128 / 128 / 128 expanded: encoder, conv and node kernels all take the generic-width route
+    const bool lp_generic = cfg->edge_dtype != GAMD_EDGE_F32 && (generic || !exact128);
+    h->wide_enc = generic || forced || lp_generic;
+    h->wide_conv = H != 128 || Eh != 128 || forced || lp_generic;
     h->n_feat = (cfg->no_expand_edge ? 4 : 44) + (cfg->use_bond ? 1 : 0);
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t n = (size_t)h->n;
@@ -987,7 +985,8 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         else pack16(t->data.data(), bb.host.data() + o);
         return o;
     };
-    const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16;       // 128-wide only (gamd_create)
+    const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16 && !h->wide_conv;     // 128 / 128 / 128 expanded: the specialised kernels
+    const bool bf16_wide = h->cfg.edge_dtype == GAMD_EDGE_BF16 && h->wide_conv;       // any other width / feature set: wide_bf16.hip
     const bool f16x3_edges = h->cfg.edge_dtype == GAMD_EDGE_F16X3 && !h->wide_conv;   // 128 / 128 / 128 expanded: the specialised kernels
     const bool f16x3_wide = h->cfg.edge_dtype == GAMD_EDGE_F16X3 && h->wide_conv;     // any other width / feature set: wide_f16x3.hip
     auto put_edge_f16x3 = [&](const HostTensor* t) {
@@ -1079,6 +1078,20 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             o.w1p = put_edge_bf16(ea0w); o.w2p = put_edge_bf16(ea2w); o.w3p = put_edge_bf16(t1w); o.w4p = put_edge_bf16(&w4_perm);
         } else if (f16x3_edges) {
             o.w1p = put_edge_f16x3(ea0w); o.w2p = put_edge_f16x3(ea2w); o.w3p = put_edge_f16x3(t1w); o.w4p = put_edge_f16x3(t3w);
+        } else if (bf16_wide) {
+            // one contiguous run of 32 KiB bf16 images: W1[:, kb] (EHT) | W2 | W3 | W4[ob, :] (HT)
+            auto put_blocks_bf16 = [&](const HostTensor* t, int OB, int KB) {
+                size_t o = bb.add((size_t)OB * KB * (GAMD_WFRAG_FLOATS / 2));
+                for (int ob = 0; ob < OB; ++ob)
+                    for (int kb = 0; kb < KB; ++kb)
+                        pack128_bf16(t->data.data() + (size_t)128 * ob * 128 * KB + 128 * kb,
+                                     reinterpret_cast<uint16_t*>(bb.host.data() + o + (size_t)(ob * KB + kb) * (GAMD_WFRAG_FLOATS / 2)), 128 * KB);
+                return o;
+            };
+            o.w1p = put_blocks_bf16(ea0w, 1, (int)EHT);
+            o.w2p = put_blocks_bf16(ea2w, 1, 1);
+            o.w3p = put_blocks_bf16(t1w, 1, 1);
+            o.w4p = put_blocks_bf16(t3w, (int)HT, 1);
         } else if (f16x3_wide) {
             // one contiguous run of [hi | lo] images: W1[:, kb] (EHT) | W2 | W3 | W4[ob, :] (HT)
             o.w1p = put_blocks_f16x3(ea0w, 1, (int)EHT);

@@ -89,3 +89,47 @@ __device__ __forceinline__ void gemm128_bf16_pf(const bf16x8* W, int lane, const
     __builtin_amdgcn_sched_group_barrier(0x008, D, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
+
+// ---- operand-set form (wide_bf16.hip; the structure of conv_edge_f16x3.hip on bf16 operands) -----------------------------------
+struct OpSetB { gamd_u32x4 w[4][2]; };           // bf16 operand set of a 32 x 128 block: w[t][u] = the 8 values of K step (t, u)
+struct SiluKB { gamd_f32x2 nl2e, one; };
+
+// SiLU of two accumulator elements + rounding to bf16, written as dword (r0 & 7) / 2 of K step (t, r0 >> 3)
+__device__ __forceinline__ void silu_pack_pair(OpSetB& P, int t, int r0, float x0, float x1, const SiluKB& k) {
+    const gamd_f32x2 x = {x0, x1};
+    const gamd_f32x2 a = x * k.nl2e;
+    const gamd_f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const gamd_f32x2 d = e + k.one;
+    const gamd_f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const gamd_f32x2 y = x * r;
+    const unsigned b = __builtin_bit_cast(unsigned, __builtin_convertvector(y, gamd_bf16x2));
+    const int u = r0 >> 3, dw = (r0 & 7) >> 1;
+    if (dw == 0) P.w[t][u] = gamd_u32x4{b, 0u, 0u, 0u};          // a NEW register quad (see silu_split_pair, gamd_f16x3.h)
+    else P.w[t][u][dw] = b;
+}
+
+// 128x128 bf16 GEMM, output block by output block: acc[tp] initialised by init(tp) right in front of its 8 MFMAs, the post-op of
+// block tp - 1 between the MFMAs of block tp, step(i) in front of K step i = 0..31 (gemm128_f16x3_lazy, gamd_f16x3.h)
+template <bool F2, typename Init, typename Post, typename Step>
+__device__ __forceinline__ void gemm128_bf16_lazy(const bf16x8* W, int lane, const OpSetB& P, f32x16 (&acc)[4], Init init, Post post, Step step) {
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+        __builtin_amdgcn_sched_barrier(0);
+        init(tp);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                step((tp * 4 + t) * 2 + u);
+                const bf16x8 w = W[((tp * 4 + t) * 2 + u) * 64 + lane];
+                const bf16x8 x = __builtin_bit_cast(bf16x8, P.w[t][u]);
+                acc[tp] = F2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, w, acc[tp], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, x, acc[tp], 0, 0, 0);
+                if (tp > 0) post(tp - 1, 2 * (t * 2 + u));
+            }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) post(3, 2 * k);
+    __builtin_amdgcn_sched_barrier(0);
+}

@@ -84,14 +84,14 @@ struct OpSet { gamd_u32x4_t w[4][2][2]; };
 // SIMD the ~100 cycles each LDS-DMA instruction takes to issue are otherwise dead time of the matrix pipe
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"      // "m0" on the clobber lists: see gamd_common.h
-template <int NW>
+template <int NW, int KB = 64>                         // KB: size of the image in KiB (64: [hi | lo] fp16 or fp32; 32: bf16)
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ gw, float* ldsbuf, int wave, unsigned lane16, int k) {
     // (inline assembly: a compiler-tracked global_load_lds turns the next wait of any kind into vmcnt(0) lgkmcnt(0), see
     // gamd_stage_weight_raw in gamd_common.h; the landing is guaranteed by the counted vmcnt of phase_barrier.)  A wave's
     // 64 / NW KiB are contiguous and addressed by the instruction's immediate offset (which advances the global and the LDS
     // side alike): base pair + M0 are rebuilt per call from one opaque scalar instead of living in 16 x 3 loop-invariant,
     // spilled SGPRs per matrix.
-    int woff = wave * (64 / NW) * 1024 + (k >> 2) * 4096;
+    int woff = wave * (KB / NW) * 1024 + (k >> 2) * 4096;
     asm volatile("" : "+s"(woff));
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ldsbuf + (unsigned)woff;
     const char* g0 = reinterpret_cast<const char*>(gw) + woff;

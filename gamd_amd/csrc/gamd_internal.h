@@ -141,8 +141,8 @@ struct EncArgs {
     float* e_frag;             // [tiles][4][4][64][4]
     long long e_cap;
     float* feat_dbg;           // optional [e_cap][48] raw features (debug/parity), or null
-    int e_format;              // generic-width encoder (wide.hip): 0 = fp32 fragments, 2 = (hi, lo) fp16 operand images for the
-                               // split-fp16 conv kernels (the layout edge_encode_f16x3.hip writes)
+    int e_format;              // generic-width encoder (wide.hip): 0 = fp32 fragments, 1 = bf16 fragments (wide_bf16.hip), 2 = (hi, lo)
+                               // fp16 operand images for the split-fp16 conv kernels (the layout edge_encode_f16x3.hip writes)
 };
 // self_loop_mode 1: is CSR slot x (source src, destination dst) the loop that was appended behind the row's real edges?  It is the
 // last slot of its row that is not a padding slot (padding follows only in the row of a box's last atom, n_boxes > 1).
@@ -199,6 +199,8 @@ int launch_conv_edge_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, 
 // the same on the fp16 matrix pipe by operand splitting (wide_f16x3.hip): w1p = eht + 2 + ht contiguous [hi | lo] fp16 images,
 // e_frag in the encoder's e_format 2, hn rows in their natural [n][H] layout
 int launch_conv_edge_f16x3_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
+// bf16 operands (wide_bf16.hip): w1p = eht + 2 + ht contiguous 32 KiB bf16 images, e_frag in the encoder's e_format 1
+int launch_conv_edge_bf16_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
 
 // update_edge_emb=True (SmoothConvLayerNew, nn_module.py:91-92, :140-146): the edge embedding the NEXT layers read is
 // edge_layer_norm(e_emb) of this layer.  emb: [E][128 ht] rows written by the conv kernel (emb_out); e_frag_out: the same

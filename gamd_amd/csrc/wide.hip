@@ -14,6 +14,7 @@
 // simplicity over the last 20 % (plain workgroup barriers, no cross-barrier prefetch): the shipped wide
 // configuration is a 774-atom box where every launch is latency-bound anyway.
 #include "gamd_common.h"
+#include "gamd_bf16.h"
 #include "gamd_f16x3.h"
 #include "gamd_internal.h"
 
@@ -195,6 +196,17 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
                             nv[q * 4 + j] = v[j];
                         }
                         if (a.e_format == 0) out[((ob * 4 + t) * 4 + q) * 64 + lane] = v;
+                    }
+                    if (a.e_format == 1) {
+                        // bf16 edge MLP (wide_bf16.hip): e as bf16 fragments, [tile][block][t][u][lane][8 values]
+                        bf16x8* efrag = reinterpret_cast<bf16x8*>(a.e_frag);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            gamd_u32x4 w;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) w[k] = gamd_pk_bf16(nv[8 * u + 2 * k], nv[8 * u + 2 * k + 1]);
+                            efrag[(((size_t)tile * EHT + ob) * 8 + t * 2 + u) * 64 + lane] = __builtin_bit_cast(bf16x8, w);
+                        }
                     }
                     if (a.e_format == 2) {
                         // split-fp16 edge MLP (wide_f16x3.hip / conv_edge_f16x3.hip): e already split into (hi, lo) fp16 operand

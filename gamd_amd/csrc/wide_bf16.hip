@@ -1,0 +1,304 @@
+// wide_bf16.hip — the bf16 conv-layer edge kernel (BASELINE config 5's arithmetic: operands rounded to bf16, fp32 accumulate)
+// for the generic widths of wide.hip: Eh = 128 EHT, H = 128 HT (EHT, HT in {1, 2}), hidden_dim = 128.  The structure of
+// wide_f16x3.hip (512-thread persistent workgroups, one 32-edge tile per wave, lazily initialised accumulators that become the
+// next GEMM's operands, gathers as quads, NP = EHT + 2 + HT GEMM phases per tile over the weight blocks W1[:, kb] | W2 | W3 |
+// W4[ob, :] streamed through a 2-slot ring one phase ahead) on bf16 operand sets (32 registers) and 32 KiB bf16 images; e arrives
+// as bf16 fragments from k_edge_encode_wide (e_format 1).  Tolerance restated as for config 5 (1e-2).
+#include "gamd_bf16.h"
+#include "gamd_f16x3.h"
+#include "gamd_internal.h"
+
+namespace {
+
+constexpr int WCONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 2 * 128 + 256;   // slots keep the 64 KiB stride (a bf16 image fills half of one)
+
+// bf16 e fragments written by k_edge_encode_wide (e_format 1): [tile][block][t][u][lane][8 values], 8 KiB per (tile, block);
+// scalar base per 4 KiB group + the lane offset
+__device__ __forceinline__ void load_e_tile_b(const float* __restrict__ e_frag, int idx, unsigned lane16, OpSetB& P) {
+    const char* base = reinterpret_cast<const char*>(e_frag) + (size_t)__builtin_amdgcn_readfirstlane(idx) * 8192;
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+        const char* bk = base + 4096 * grp;
+        asm volatile("" : "+s"(bk));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * grp + k;                         // i = t * 2 + u
+            P.w[i >> 1][i & 1] = *reinterpret_cast<const gamd_u32x4*>(bk + (lane16 + (unsigned)(1024 * k)));
+        }
+    }
+}
+// this wave's share (4 KiB) of a 32 KiB image, all at once (prologue / waves without a tile)
+template <int NW>
+__device__ __forceinline__ void stage_block_b(const float* gw, float* ldsbuf, int wave, unsigned lane16) {
+#pragma unroll
+    for (int k = 0; k < 32 / NW; ++k) stage_chunk<NW, 32>(gw, ldsbuf, wave, lane16, k);
+}
+
+template <int EHT, int HT>
+__global__ void __launch_bounds__(512, 2) k_conv_edge_bf16_wide(ConvEdgeArgs a) {
+    if (a.devflags[DEVFLAG_FROZEN]) return;
+    constexpr int NW = 8, NP = EHT + 2 + HT, H = 128 * HT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // bias vectors behind the two 64 KiB slots, addressed from one opaque base (see conv_edge_f16x3.hip)
+    unsigned boff = (unsigned)(2 * GAMD_WFRAG_FLOATS * sizeof(float));
+    asm volatile("" : "+s"(boff));
+    float* vb1 = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + boff);
+    float* vb3 = vb1 + 128;
+    float* vb4 = vb3 + 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, slot = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    int E = a.counters[CNT_E];
+    if ((long long)E > a.e_cap) E = (int)a.e_cap;
+    const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
+    const int n_units = (n_tiles + NW - 1) / NW;
+    int first, end, step;
+    gamd_xcd_range(n_units, blockIdx.x, gridDim.x, first, end, step);
+    if (first >= end) return;
+    const int n_iter = (end - first + step - 1) / step;
+    auto tile_of = [&](int it) {
+        const int u = first + it * step;
+        return (it < n_iter && u * NW + wave < n_tiles) ? u * NW + wave : n_tiles;
+    };
+
+    if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; }
+    if (tid < H) vb4[tid] = a.b4[tid];
+    stage_block_b<NW>(a.w1p, lds, wave, lane16);
+
+    // running phase counter: block blk = g % NP sits in slot g & 1; the slot offset stays a run-time scalar (one base register +
+    // immediate offsets for all 64 fragment reads of a phase, wide.hip)
+    unsigned g = 0;
+    int blk = 0;
+    auto cur_w = [&]() -> const bf16x8* {
+        unsigned off = (g & 1u) * (unsigned)(GAMD_WFRAG_FLOATS * sizeof(float));
+        asm volatile("" : "+s"(off));
+        return (const bf16x8*)((const char*)lds + off);
+    };
+    auto next_block = [&]() { return a.w1p + (size_t)((blk + 1 == NP) ? 0 : blk + 1) * (GAMD_WFRAG_FLOATS / 2); };
+    auto next_slot = [&]() { return lds + ((g + 1) & 1u) * GAMD_WFRAG_FLOATS; };
+    auto advance = [&]() { ++g; blk = (blk + 1 == NP) ? 0 : blk + 1; };
+
+    OpSetB PA;                        // e block 0 of the current tile (the only register set that crosses the tile loop)
+    SiluKB sk;
+    sk.nl2e = gamd_f32x2{-1.4426950408889634f, -1.4426950408889634f};
+    sk.one = gamd_f32x2{1.0f, 1.0f};
+    asm volatile("" : "+v"(sk.nl2e), "+v"(sk.one));
+
+    int tile = tile_of(0);
+    bool active = tile < n_tiles;
+    int src = a.zero_row, dst = a.zero_row;       // padding slots gather the all-zero row n of hn / S / D
+    {
+        const int x = tile * GAMD_TILE + gamd_pi(slot);
+        if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
+        if (active) load_e_tile_b(a.e_frag, tile * EHT, lane16, PA);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first block's copy is not tracked by hipcc
+    __syncthreads();
+
+    for (int it = 0; it < n_iter; ++it) {
+        const int tile_n = tile_of(it + 1);
+        const bool active_n = tile_n < n_tiles;
+        int src_n = a.zero_row, dst_n = a.zero_row;
+        if (!active) {
+            // no tile in this unit: copy this wave's share of every block and meet the barriers (register sets untouched)
+#pragma unroll
+            for (int ph = 0; ph < NP; ++ph) {
+                stage_block_b<NW>(next_block(), next_slot(), wave, lane16);
+                phase_barrier<0>();
+                advance();
+            }
+        } else {
+            const int x0 = tile * GAMD_TILE + 16 * half;
+            int nvalid = E - x0;
+            nvalid = nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid);
+            OpSetB PB, PC;                     // T1 / T4; e block 1 / T3
+            f32x16 ACC[4], RC[4];
+            const unsigned soff = ((unsigned)src << 9) + 16u * (unsigned)half, doff = ((unsigned)dst << 9) + 16u * (unsigned)half;
+            const unsigned mask = a.chunk_mask[tile * 2 + half];
+            const int p0 = a.chunk_piece[tile * 2 + half];
+            // ===== phase 1: T1 = SiLU(W1 e + b1), K = Eh: one GEMM per 128-wide block of e =====
+            {
+                const bf16x8* W = cur_w();
+                const float* nb = next_block();
+                float* ns = next_slot();
+                if (EHT == 1) {
+                    gemm128_bf16_lazy<false>(W, lane, PA, ACC, [&](int tp) { ACC[tp] = bias_block(vb1, tp, half); },
+                        [&](int tp, int r0) { silu_pack_pair(PB, tp, r0, ACC[tp][r0], ACC[tp][r0 + 1], sk); },
+                        [&](int i) { if (i < 4) stage_chunk<NW, 32>(nb, ns, wave, lane16, i); });
+                } else {
+                    // the second block of e is fetched during the second half of this GEMM (one 16-byte load per K step) and
+                    // stays in flight across the barrier
+                    const char* eb = reinterpret_cast<const char*>(a.e_frag) + (size_t)__builtin_amdgcn_readfirstlane(tile * EHT + 1) * 8192;
+                    gemm128_bf16_lazy<false>(W, lane, PA, ACC, [&](int tp) { ACC[tp] = bias_block(vb1, tp, half); },
+                        [&](int, int) {},
+                        [&](int i) {
+                            if (i < 4) stage_chunk<NW, 32>(nb, ns, wave, lane16, i);
+                            if (i >= 16 && i < 24) {
+                                const int k = i - 16;                  // k = t * 2 + u
+                                const char* bk = eb + 4096 * (k >> 2);
+                                asm volatile("" : "+s"(bk));
+                                PC.w[k >> 1][k & 1] = *reinterpret_cast<const gamd_u32x4*>(bk + (lane16 + (unsigned)(1024 * (k & 3))));
+                            }
+                        });
+                }
+                if (EHT == 2) phase_barrier<8>(); else phase_barrier<0>();
+                advance();
+            }
+            if (EHT == 2) {
+                const bf16x8* W = cur_w();
+                const float* nb = next_block();
+                float* ns = next_slot();
+                gemm128_bf16_lazy<false>(W, lane, PC, ACC, [&](int) {},
+                    [&](int tp, int r0) { silu_pack_pair(PB, tp, r0, ACC[tp][r0], ACC[tp][r0 + 1], sk); },
+                    [&](int i) { if (i < 4) stage_chunk<NW, 32>(nb, ns, wave, lane16, i); });
+                phase_barrier<0>();
+                advance();
+            }
+            // ===== phase 2: T3 = SiLU((W2 T1 + D[dst]) + S[src]) =====
+            {
+                const bf16x8* W = cur_w();
+                const float* nb = next_block();
+                float* ns = next_slot();
+                f32x4 SQ[4][4], DQ[4][4];
+                gemm128_bf16_lazy<false>(W, lane, PB, RC,
+                    [&](int tp) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) RC[tp][r] = 0.f;
+                    },
+                    [&](int tp, int r0) {
+                        const int q = r0 >> 2, j = r0 & 3;
+                        silu_pack_pair(PC, tp, r0, (RC[tp][r0] + DQ[tp][q][j]) + SQ[tp][q][j],
+                                        (RC[tp][r0 + 1] + DQ[tp][q][j + 1]) + SQ[tp][q][j + 1], sk);
+                    },
+                    [&](int i) {
+                        const int tp = i >> 3, k = i & 7;
+                        if (i < 4) stage_chunk<NW, 32>(nb, ns, wave, lane16, i);
+                        const int q = tp == 3 ? k : k - 4;
+                        if (q >= 0 && q < 4) {
+                            SQ[tp][q] = *(const f32x4*)((const char*)a.S + (soff + (unsigned)(128 * tp + 32 * q)));
+                            DQ[tp][q] = *(const f32x4*)((const char*)a.D + (doff + (unsigned)(128 * tp + 32 * q)));
+                        }
+                    });
+                phase_barrier<0>();
+                advance();
+            }
+            // ===== phase 3: T4 = SiLU(W3 T3 + b3) =====
+            if (active_n) {
+                const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
+                if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
+            }
+            {
+                const bf16x8* W = cur_w();
+                const float* nb = next_block();
+                float* ns = next_slot();
+                gemm128_bf16_lazy<false>(W, lane, PC, ACC, [&](int tp) { ACC[tp] = bias_block(vb3, tp, half); },
+                    [&](int tp, int r0) { silu_pack_pair(PB, tp, r0, ACC[tp][r0], ACC[tp][r0 + 1], sk); },
+                    [&](int i) { if (i < 4) stage_chunk<NW, 32>(nb, ns, wave, lane16, i); });
+                phase_barrier<0>();
+                advance();
+            }
+            // ===== phase 4, once per 128-wide output block: e_emb = T4 W4[ob]^T + b4 (F2), message with hn[src], segment sum =====
+            const unsigned keep_bits = ~(mask << 1);
+            unsigned ends = mask;
+            if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends |= 1u << (nvalid - 1);
+#pragma unroll
+            for (int ob = 0; ob < HT; ++ob) {
+                const bf16x8* W = cur_w();
+                const float* nb = next_block();
+                float* ns = next_slot();
+                // hn[src] block ob in the row layout (lane = feature 128 ob + 32 tp + slot, register = edge): natural [n][H] rows,
+                // 4 coalesced dword loads per edge; the row offset of edge r lives in lane rho(r, half) (one bpermute index
+                // register + immediate lane offsets); edges 4 r4 .. 4 r4 + 3 in front of K step r4 (first used 8 steps later)
+                f32x4 HN[16];
+                auto gather_hn = [&](int r4) {
+                    const unsigned rowoff = (unsigned)src * (unsigned)(H * 4), idx0 = 16u * (unsigned)half, slot4 = 4u * (unsigned)slot;
+                    unsigned o0, o1, o2, o3;
+                    switch (r4) {
+#define HN_BPERM(R4) asm volatile("ds_bpermute_b32 %0, %4, %5 offset:%6\n\tds_bpermute_b32 %1, %4, %5 offset:%7\n\t" \
+                                  "ds_bpermute_b32 %2, %4, %5 offset:%8\n\tds_bpermute_b32 %3, %4, %5 offset:%9\n\ts_waitcnt lgkmcnt(0)" \
+                                  : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) \
+                                  : "v"(idx0), "v"(rowoff), "n"(4 * (0 + 8 * R4)), "n"(4 * (1 + 8 * R4)), "n"(4 * (2 + 8 * R4)), "n"(4 * (3 + 8 * R4)))
+                        case 0: HN_BPERM(0); break;
+                        case 1: HN_BPERM(1); break;
+                        case 2: HN_BPERM(2); break;
+                        default: HN_BPERM(3); break;
+#undef HN_BPERM
+                    }
+                    const unsigned o[4] = {o0, o1, o2, o3};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp)
+                            HN[4 * r4 + k][tp] = *(const float*)((const char*)a.hn + (o[k] + slot4 + (unsigned)(512 * ob + 128 * tp)));
+                };
+                gemm128_bf16_lazy<true>(W, lane, PB, RC,
+                    [&](int tp) {
+                        const float b = vb4[128 * ob + 32 * tp + slot];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) RC[tp][r] = b;
+                    },
+                    [&](int tp, int r0) {
+#pragma unroll
+                        for (int r = r0; r < r0 + 2; ++r)
+                            RC[tp][r] = gamd_msg_acc(HN[r][tp], RC[tp][r], (r > 0 && ((keep_bits >> r) & 1u)) ? RC[tp][r - 1] : 0.f);
+                    },
+                    [&](int i) {
+                        if (i < 4) stage_chunk<NW, 32>(nb, ns, wave, lane16, i);
+                        if (i < 4) gather_hn(i);
+                    });
+                // the next tile's first e block behind the last GEMM (clamped index on the last iteration: see conv_edge_f16x3.hip)
+                if (ob == HT - 1) {
+                    load_e_tile_b(a.e_frag, (active_n ? tile_n : tile) * EHT, lane16, PA);
+                    phase_barrier<8>();
+                } else {
+                    phase_barrier<0>();
+                }
+                advance();
+                // one store per finished piece and output block
+                int p = p0;
+                unsigned pe = ends;
+                while (__any(pe != 0)) {
+                    if (pe != 0) {
+                        const int r = __builtin_ctz(pe);
+                        pe &= pe - 1;
+                        float* prow = a.partial + ((size_t)p * H + 128 * ob + slot);
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) {
+                            float v = RC[tp][0];
+#pragma unroll
+                            for (int k = 1; k < 16; ++k) v = (r == k) ? RC[tp][k] : v;
+                            prow[32 * tp] = v;
+                        }
+                        ++p;
+                    }
+                }
+            }
+        }
+        tile = tile_n; active = active_n; src = src_n; dst = dst_n;
+    }
+}
+
+template <int EHT, int HT>
+int conv_launch(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
+    const size_t lds = sizeof(float) * WCONV_LDS_FLOATS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_conv_edge_bf16_wide<EHT, HT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_conv_edge_bf16_wide<EHT, HT>), dim3(n_blocks), dim3(512), lds, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+int launch_conv_edge_bf16_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st) {
+    if (eht == 1 && ht == 1) return conv_launch<1, 1>(a, n_blocks, st);
+    if (eht == 1 && ht == 2) return conv_launch<1, 2>(a, n_blocks, st);
+    if (eht == 2 && ht == 1) return conv_launch<2, 1>(a, n_blocks, st);
+    if (eht == 2 && ht == 2) return conv_launch<2, 2>(a, n_blocks, st);
+    return -22;
+}

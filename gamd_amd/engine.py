@@ -83,9 +83,6 @@ class GamdForce:
                              "and the RBF expansion on (40 centres) or off "
                              f"(got enc={cfg.encoding_size} hidden={cfg.hidden_dim} edge={cfg.edge_embedding_dim} "
                              f"n_rbf={cfg.n_rbf})")
-        if edge_dtype == "bf16" and ((cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim) != (128, 128, 128) or cfg.n_rbf == 0):
-            raise ValueError("edge_dtype bf16 is built for the 128 / 128 / 128 RBF-expanded configuration only "
-                             "(f16x3, the fp32-grade split-fp16 edge MLP, covers every width)")
         validate_state_dict(state_dict, cfg)
         self.cfg = cfg
         self.n = int(n_atoms)                          # atoms per box

@@ -65,8 +65,8 @@ typedef struct gamd_config {
                                 as in F16X3)
                                 | GAMD_EDGE_F16X3 (fp32-grade edge-MLP on the fp16 matrix pipe: every operand split into
                                 hi + lo fp16, W x = Wh xh + (Wh xl + Wl xh), fp32 accumulate; same parity bar as F32).
-                                BF16: 128 / 128 / 128 RBF-expanded configuration only; F16X3: every width and feature set
-                                (at most 2^22 - 2 atoms per handle when encoding_size > 128) */
+                                Both exist for every width and feature set (at most 2^22 - 2 atoms per handle when
+                                encoding_size > 128); fp32 only: self_loop_mode 1 and update_edge models */
     int32_t encoding_size;   /* node width H: 0 (= 128) or 1 .. 256 (build_model 'encoding_size') */
     int32_t edge_embedding_dim; /* edge-embedding width Eh: 0 (= 128) or 1 .. 256 ('edge_embedding_dim') */
     int32_t hidden_dim;      /* 0 (= 128) or 1 .. 128 ('hidden_dim') */

@@ -420,8 +420,9 @@ def test_error_conventions_for_widths_and_constraints():
         cfg = ModelConfig(kind="water", hidden_dim=256, encoding_size=256, edge_embedding_dim=256)
         _engine(make_state_dict(cfg, 1), 30, 12.0, 3.0, cfg=cfg)
     wide = ModelConfig(kind="water", encoding_size=256, edge_embedding_dim=256, conv_layer=2)
-    with pytest.raises((GamdError, ValueError), match="bf16"):
-        _engine(make_state_dict(wide, 1), 30, 12.0, 3.0, cfg=wide, edge_dtype="bf16")
+    # (reduced-precision edge MLPs exist for every width since round 4; appended self loops are an fp32-only switch)
+    with pytest.raises((GamdError, ValueError)):
+        _engine(make_state_dict(ModelConfig(kind="lj"), 1), 30, 12.0, 3.0, edge_dtype="bf16", self_loop_mode="append_zero_feature_loops")
     # a 128-wide state_dict handed to a 256-wide configuration: strict shape check (load_state_dict semantics)
     with pytest.raises(KeyError, match="shape"):
         _engine(make_state_dict(ModelConfig(kind="water", conv_layer=2), 1), 30, 12.0, 3.0, cfg=wide)

@@ -417,7 +417,8 @@ def test_update_edge_emb_with_skin_reuse_batches_and_odd_widths():
 def test_split_fp16_edge_mlp_on_the_generic_width_goldens(name):
     """edge_dtype="f16x3" outside 128 / 128 / 128: trainers' default widths on the fixed-box models, the DFT-water configuration,
     mixed widths, expand_edge=False, a zero-padded narrow model -- outputs of the reference modules at the fp32 bar (1e-5),
-    per-atom p99 included; fp32 engine alongside (the two differ by rounding only)."""
+    per-atom p99 included; fp32 engine alongside (the two differ by rounding only).  edge_dtype="bf16" (wide_bf16.hip) on the
+    same cases at config 5's restated tolerance (1e-2)."""
     g, cfg, sd = load_golden(name)
     n = g["pos"].shape[0]
     dyn = cfg.kind == "dynbox"
@@ -428,12 +429,15 @@ def test_split_fp16_edge_mlp_on_the_generic_width_goldens(name):
     species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
     pos = torch.from_numpy(g["pos"] if dyn else np.mod(g["pos"], box)).float()
     outs = {}
-    for dt in ("f16x3", "f32"):
+    for dt in ("f16x3", "f32", "bf16"):
         eng = _engine(sd, n, box, float(g["cutoff"]), edge_dtype=dt, **kw)
         outs[dt] = (eng.forward(pos, box=box, species=species) if dyn else eng.forward(pos, species=species)).cpu().numpy()
-        if dt == "f16x3":
+        if dt != "f32":
             assert np.array_equal(edge_set(eng.debug_edges()), edge_set(g["edge_idx"]))
+            again = (eng.forward(pos, box=box, species=species) if dyn else eng.forward(pos, species=species)).cpu().numpy()
+            assert np.array_equal(again, outs[dt])                      # run-to-run bit identity
         eng.close()
+    assert rel_err(outs["bf16"], g["out_norm"]) < 1e-2 and rel_err(outs["bf16"], outs["f32"]) > 1e-6      # bf16 really ran
     assert rel_err(outs["f16x3"], g["out_norm"]) < TOL
     med, p99, worst, cnt = per_atom_err(outs["f16x3"], g["out_norm"])
     assert p99 < P99_TOL, (med, p99, worst)
@@ -465,6 +469,15 @@ def test_split_fp16_generic_width_with_skin_batches_and_large_boxes():
     assert np.array_equal(ob, np.concatenate([f[1] for f in frames[:3]]))
     for e in (one, skin, batch):
         e.close()
+    # the same in bf16 (wide_bf16.hip): skin == exact to the restated tolerance (identical edge sets; row order may differ after a
+    # rebuild), batch == boxes one by one bit for bit
+    oneb = _engine(sd, n, box, rc, bond=g["bond"], scaler=scal, edge_dtype="bf16")
+    batchb = _engine(sd, n, box, rc, bond=g["bond"], scaler=scal, edge_dtype="bf16", n_boxes=3)
+    singles = [oneb.forward(torch.from_numpy(f[0]).float(), species=species).cpu().numpy() for f in frames[:3]]
+    obb = batchb.forward(torch.from_numpy(xb).float(), species=np.tile(species, 3)).cpu().numpy()
+    assert np.array_equal(obb, np.concatenate(singles))
+    assert rel_err(singles[0], frames[0][1]) < 1e-2
+    oneb.close(); batchb.close()
     pos, lbox = workloads.lj_box(4000)
     wide = make_state_dict(ModelConfig(kind="lj", encoding_size=256, hidden_dim=128, edge_embedding_dim=256), 3, 7.0, 2.2)
     f32 = _engine(wide, 4000, lbox, 3.0 * workloads.LJ_SIGMA)
@@ -475,7 +488,9 @@ def test_split_fp16_generic_width_with_skin_batches_and_large_boxes():
     med, p99, worst, cnt = per_atom_err(got, ref)
     assert p99 < P99_TOL, (med, p99, worst)
     assert np.array_equal(got, f16.forward(xa).cpu().numpy())          # run-to-run bit identity
-    f32.close(); f16.close()
+    b16 = _engine(wide, 4000, lbox, 3.0 * workloads.LJ_SIGMA, edge_dtype="bf16")
+    assert rel_err(b16.forward(xa).cpu().numpy(), ref) < 1e-2
+    f32.close(); f16.close(); b16.close()
 
 
 # ---- the feature matrix, sampled: widths x model flavour x normalisation x update_edge x expand_edge x edge dtype ------------------
