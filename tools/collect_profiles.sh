@@ -7,6 +7,7 @@ hdr='`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py -
 for w in c1 c1_batch c2 c3 c5 c5b dft; do { echo "# $name — $hdr"; echo; cat $src/trace_$w.md; } > $dst/${name}_trace_$w.md; done
 hdr2='`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --steps 50 --warmup 5 --workload <w> --edge-dtype f16x3` (tools/gpu_profile_round.sh)'
 for w in c2 dft; do { echo "# $name — $hdr2"; echo; cat $src/trace_${w}_f16x3.md; } > $dst/${name}_trace_${w}_f16x3.md; done
+{ echo "# $name — ${hdr2/f16x3/bf16}"; echo; cat $src/trace_dft_bf16.md; } > $dst/${name}_trace_dft_bf16.md
 for w in c2 c5 c2_f16x3; do cp $src/pmc_$w.md $dst/${name}_pmc_$w.md; done
 tail -1 $src/bench_default.json > $dst/${name}_bench_default.json
 tail -1 $src/bench_f16x3.json > $dst/${name}_bench_f16x3.json

@@ -18,6 +18,8 @@ for w in c2 dft; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_${w}_f16x3 -- $B --steps 50 --warmup 5 --workload $w --edge-dtype f16x3 > $out/trace_${w}_f16x3.log 2>&1
   python3 tools/profile_summary.py stats $out/trace_${w}_f16x3 > $out/trace_${w}_f16x3.md
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_dft_bf16 -- $B --steps 50 --warmup 5 --workload dft --edge-dtype bf16 > $out/trace_dft_bf16.log 2>&1
+python3 tools/profile_summary.py stats $out/trace_dft_bf16 > $out/trace_dft_bf16.md
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $out/pmc_sq_c2_f16x3 -- $B --steps 5 --warmup 2 --workload c2 --edge-dtype f16x3 > $out/pmc_sq_c2_f16x3.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch_c2_f16x3 -- $B --steps 5 --warmup 2 --workload c2 --edge-dtype f16x3 > $out/pmc_fetch_c2_f16x3.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write_c2_f16x3 -- $B --steps 5 --warmup 2 --workload c2 --edge-dtype f16x3 > $out/pmc_write_c2_f16x3.log 2>&1
