@@ -794,7 +794,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     const bool exact128 = H_true == 128 && Eh_true == 128 && D_true == 128;
     const bool generic = H != 128 || Eh != 128 || cfg->no_expand_edge;
     // reduced-precision edge MLPs (bf16, fp32-grade split-fp16) exist for every width and both feature sets: 128 / 128 / 128
-    // expanded runs the specialised kernels, anything else wide.hip's encoder writing the operands + wide_bf16.hip / wide_f16x3.hip
+    // expanded runs the specialised kernels, anything else wide.hip's encoder writing the operands + wide_lp.hip
     if (cfg->edge_dtype != GAMD_EDGE_F32 && H == 256 && (long long)cfg->n_atoms * n_boxes > (1ll << 22) - 2)
         return fail(-22, "bf16 / split-fp16 with encoding_size > 128: at most 2^22 - 2 atoms per handle (32-bit byte offsets into hn)");
     gamd_handle* h = new gamd_handle();
@@ -986,9 +986,9 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         return o;
     };
     const bool bf16_edges = h->cfg.edge_dtype == GAMD_EDGE_BF16 && !h->wide_conv;     // 128 / 128 / 128 expanded: the specialised kernels
-    const bool bf16_wide = h->cfg.edge_dtype == GAMD_EDGE_BF16 && h->wide_conv;       // any other width / feature set: wide_bf16.hip
+    const bool bf16_wide = h->cfg.edge_dtype == GAMD_EDGE_BF16 && h->wide_conv;       // any other width / feature set: wide_lp.hip
     const bool f16x3_edges = h->cfg.edge_dtype == GAMD_EDGE_F16X3 && !h->wide_conv;   // 128 / 128 / 128 expanded: the specialised kernels
-    const bool f16x3_wide = h->cfg.edge_dtype == GAMD_EDGE_F16X3 && h->wide_conv;     // any other width / feature set: wide_f16x3.hip
+    const bool f16x3_wide = h->cfg.edge_dtype == GAMD_EDGE_F16X3 && h->wide_conv;     // any other width / feature set: wide_lp.hip
     auto put_edge_f16x3 = [&](const HostTensor* t) {
         size_t o = bb.add(GAMD_WFRAG_FLOATS);
         pack128_f16x3(t->data.data(), reinterpret_cast<uint16_t*>(bb.host.data() + o));

@@ -90,7 +90,7 @@ __device__ __forceinline__ void gemm128_bf16_pf(const bf16x8* W, int lane, const
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// ---- operand-set form (wide_bf16.hip; the structure of conv_edge_f16x3.hip on bf16 operands) -----------------------------------
+// ---- operand-set form (wide_lp.hip; the structure of conv_edge_f16x3.hip on bf16 operands) -----------------------------------
 struct OpSetB { gamd_u32x4 w[4][2]; };           // bf16 operand set of a 32 x 128 block: w[t][u] = the 8 values of K step (t, u)
 struct SiluKB { gamd_f32x2 nl2e, one; };
 

@@ -75,7 +75,7 @@ __device__ __forceinline__ void gemm128_f16x3(const f16x8* W, int lane, const f3
         }
 }
 
-// ---- pieces shared by the conv-layer edge kernels on this pipe (conv_edge_f16x3.hip, wide_f16x3.hip) ----------------------
+// ---- pieces shared by the conv-layer edge kernels on this pipe (conv_edge_f16x3.hip, wide_lp.hip) ----------------------
 // An operand set: the (hi, lo) fp16 images of a 32 x 128 activation block in MFMA operand order, 64 registers
 // (the size of the fp32 block it replaces): w[t][u][part] = 4 dwords = 8 halves of K step (t, u).
 struct OpSet { gamd_u32x4_t w[4][2][2]; };
@@ -127,23 +127,6 @@ __device__ __forceinline__ void load_e_tile_s(const float* __restrict__ e_frag, 
             for (int p = 0; p < 2; ++p)
                 P.w[t][u][p] = *reinterpret_cast<const gamd_u32x4_t*>(base + (lane16 + (unsigned)(((t * 2 + u) * 2 + p) * 1024)));
 }
-// the same for wide_f16x3.hip (which register-allocates differently around it)
-__device__ __forceinline__ void load_e_tile_g(const float* __restrict__ e_frag, int tile, unsigned lane16, OpSet& P) {
-    const char* base = reinterpret_cast<const char*>(e_frag) + (size_t)__builtin_amdgcn_readfirstlane(tile) * 16384;
-    // one scalar base per 4 KiB group (the immediate offset of a global load ends at 4 095) + the lane offset every wave holds
-    // anyway: left to itself hipcc keeps a 64-bit per-lane offset pair per group alive across the tile loop
-#pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {
-        const char* bk = base + 4096 * grp;
-        asm volatile("" : "+s"(bk));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = 4 * grp + k;                         // i = (t * 2 + u) * 2 + part
-            P.w[i >> 2][(i >> 1) & 1][i & 1] = *reinterpret_cast<const gamd_u32x4_t*>(bk + (lane16 + (unsigned)(1024 * k)));
-        }
-    }
-}
-
 struct SiluK2 { gamd_f32x2_t nl2e, one; };
 
 __device__ __forceinline__ void silu_split_pair(OpSet& P, int t, int r0, float x0, float x1, const SiluK2& k) {

@@ -141,7 +141,7 @@ struct EncArgs {
     float* e_frag;             // [tiles][4][4][64][4]
     long long e_cap;
     float* feat_dbg;           // optional [e_cap][48] raw features (debug/parity), or null
-    int e_format;              // generic-width encoder (wide.hip): 0 = fp32 fragments, 1 = bf16 fragments (wide_bf16.hip), 2 = (hi, lo)
+    int e_format;              // generic-width encoder (wide.hip): 0 = fp32 fragments, 1 = bf16 fragments (wide_lp.hip), 2 = (hi, lo)
                                // fp16 operand images for the split-fp16 conv kernels (the layout edge_encode_f16x3.hip writes)
 };
 // self_loop_mode 1: is CSR slot x (source src, destination dst) the loop that was appended behind the row's real edges?  It is the
@@ -196,10 +196,10 @@ int launch_conv_edge_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 // generic widths (wide.hip): Eh = 128 eht, H = 128 ht.  w1p points at eht + 2 + ht contiguous packed blocks
 // W1[:, kb] | W2 | W3 | W4[ob, :]; b4 is [H]; hn and partial rows are H wide, S and D stay 128 wide
 int launch_conv_edge_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
-// the same on the fp16 matrix pipe by operand splitting (wide_f16x3.hip): w1p = eht + 2 + ht contiguous [hi | lo] fp16 images,
+// the same on the fp16 matrix pipe by operand splitting (wide_lp.hip): w1p = eht + 2 + ht contiguous [hi | lo] fp16 images,
 // e_frag in the encoder's e_format 2, hn rows in their natural [n][H] layout
 int launch_conv_edge_f16x3_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
-// bf16 operands (wide_bf16.hip): w1p = eht + 2 + ht contiguous 32 KiB bf16 images, e_frag in the encoder's e_format 1
+// bf16 operands (wide_lp.hip): w1p = eht + 2 + ht contiguous 32 KiB bf16 images, e_frag in the encoder's e_format 1
 int launch_conv_edge_bf16_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
 
 // update_edge_emb=True (SmoothConvLayerNew, nn_module.py:91-92, :140-146): the edge embedding the NEXT layers read is

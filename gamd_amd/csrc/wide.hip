@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
                         if (a.e_format == 0) out[((ob * 4 + t) * 4 + q) * 64 + lane] = v;
                     }
                     if (a.e_format == 1) {
-                        // bf16 edge MLP (wide_bf16.hip): e as bf16 fragments, [tile][block][t][u][lane][8 values]
+                        // bf16 edge MLP (wide_lp.hip): e as bf16 fragments, [tile][block][t][u][lane][8 values]
                         bf16x8* efrag = reinterpret_cast<bf16x8*>(a.e_frag);
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
                         }
                     }
                     if (a.e_format == 2) {
-                        // split-fp16 edge MLP (wide_f16x3.hip / conv_edge_f16x3.hip): e already split into (hi, lo) fp16 operand
+                        // split-fp16 edge MLP (wide_lp.hip / conv_edge_f16x3.hip): e already split into (hi, lo) fp16 operand
                         // images, [tile][block][t][u][hi | lo][lane][8 halves] -- the layout edge_encode_f16x3.hip writes
                         f16x8* efrag = reinterpret_cast<f16x8*>(a.e_frag);
 #pragma unroll
@@ -461,7 +461,7 @@ __device__ __forceinline__ void wq_gemm(const WQ& wq, const f32x16 (&X)[4], f32x
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
 }
-// split-fp16 form (the reduced-precision edge mode of the generic widths, wide_f16x3.hip): the block is a (hi | lo) fp16 image
+// split-fp16 form (the reduced-precision edge mode of the generic widths, wide_lp.hip): the block is a (hi | lo) fp16 image
 // (pack128_f16x3), a quarter = 8 + 8 fragments of 16 bytes per lane; 24 MFMAs of 32 cycles per block GEMM instead of 64 of 64.
 // The activations are split per K step on the fly (gamd_split8): 160 VALU per block GEMM, nothing next to the MFMAs saved.
 __device__ __forceinline__ void wq_load_f16(const float* __restrict__ Wp, int quarter, int lane, WQ& o) {

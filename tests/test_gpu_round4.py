@@ -410,14 +410,14 @@ def test_update_edge_emb_with_skin_reuse_batches_and_odd_widths():
         _engine(bad, n, box, rc, nbr_flavour="torch")
 
 
-# ---- split-fp16 edge MLP for every width (wide_f16x3.hip + the generic-width encoder writing split operands) -----------------
+# ---- split-fp16 edge MLP for every width (wide_lp.hip + the generic-width encoder writing split operands) -----------------
 @pytest.mark.parametrize("name", ["lj258_w256_seed9", "tip3p774_w256_seed10", "tip3p774_bn_w256_seed12", "dynbox384_dftcfg_seed5",
                                   "dynbox384_h256_e128_seed7", "dynbox384_h128_e256_noexpand_seed8", "dynbox384_noexpand_seed6",
                                   "lj64_h32"])
 def test_split_fp16_edge_mlp_on_the_generic_width_goldens(name):
     """edge_dtype="f16x3" outside 128 / 128 / 128: trainers' default widths on the fixed-box models, the DFT-water configuration,
     mixed widths, expand_edge=False, a zero-padded narrow model -- outputs of the reference modules at the fp32 bar (1e-5),
-    per-atom p99 included; fp32 engine alongside (the two differ by rounding only).  edge_dtype="bf16" (wide_bf16.hip) on the
+    per-atom p99 included; fp32 engine alongside (the two differ by rounding only).  edge_dtype="bf16" (wide_lp.hip) on the
     same cases at config 5's restated tolerance (1e-2)."""
     g, cfg, sd = load_golden(name)
     n = g["pos"].shape[0]
@@ -469,7 +469,7 @@ def test_split_fp16_generic_width_with_skin_batches_and_large_boxes():
     assert np.array_equal(ob, np.concatenate([f[1] for f in frames[:3]]))
     for e in (one, skin, batch):
         e.close()
-    # the same in bf16 (wide_bf16.hip): skin == exact to the restated tolerance (identical edge sets; row order may differ after a
+    # the same in bf16 (wide_lp.hip): skin == exact to the restated tolerance (identical edge sets; row order may differ after a
     # rebuild), batch == boxes one by one bit for bit
     oneb = _engine(sd, n, box, rc, bond=g["bond"], scaler=scal, edge_dtype="bf16")
     batchb = _engine(sd, n, box, rc, bond=g["bond"], scaler=scal, edge_dtype="bf16", n_boxes=3)

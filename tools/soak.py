@@ -125,7 +125,7 @@ print(f"LJ batch {nb} x 258: two 2000-step runs bit-identical: {runs[0] == runs[
       f"largest per-box COM speed {vcom:.3e} A/ps")
 assert runs[0] == runs[1] and torch.isfinite(x).all() and vcom < 0.5      # what the last two half-kicks add; the drift itself is removed every step
 
-# ---- 6. generic-width split-fp16 (wide_f16x3.hip): the DFT-water widths on rigid water, run TWICE ---------------------------
+# ---- 6. generic-width split-fp16 (wide_lp.hip): the DFT-water widths on rigid water, run TWICE ---------------------------
 cfgw = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
 sdd = make_state_dict(cfgw, 5, 3.1, 1.2)
 posd, boxd, speciesd, _ = wk.water_box(258, seed=11, jitter=0.0, wrap=False)
