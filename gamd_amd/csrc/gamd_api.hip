@@ -1139,7 +1139,10 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     if (bf16_edges) pack_enc1_bf16(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
     else if (f16x3_edges) pack_enc1_f16x3(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
     else pack_enc1(e0w->data.data(), F, bb.host.data() + o_e1);
-    const size_t o_e2 = bf16_edges ? put_edge_bf16(e2w) : f16x3_edges ? put_edge_f16x3(e2w) : put_blocks(e2w, 1, 1);
+    // generic-width encoder in the reduced-precision modes: its two 128-wide GEMMs run in split-fp16 (wide.hip, e_format != 0)
+    const bool enc_wide_f16 = h->wide_enc && h->cfg.edge_dtype != GAMD_EDGE_F32;
+    const size_t o_e2 = bf16_edges ? put_edge_bf16(e2w) : f16x3_edges ? put_edge_f16x3(e2w) : enc_wide_f16 ? put_blocks_f16x3(e2w, 1, 1)
+                                                                                                              : put_blocks(e2w, 1, 1);
     // fp32 path: the last encoder Linear is stored with its OUTPUT rows centred, W' = W - mean over rows, b' = b - mean(b)
     // (in double): y' = W' x + b' = y - mean(y) exactly in real arithmetic, so edge_layer_norm's mean subtraction
     // (nn_module.py:646) is done here once instead of per edge; the kernels only normalise the variance
@@ -1158,7 +1161,8 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         mb /= (double)Et;
         for (int64_t o = 0; o < Et; ++o) e4b_c.data[(size_t)o] = (float)((double)e4b->data[(size_t)o] - mb);
     }
-    const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : f16x3_edges ? put_edge_f16x3(e4w) : put_blocks(&e4w_c, (int)EHT, 1);
+    const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : f16x3_edges ? put_edge_f16x3(e4w) : enc_wide_f16 ? put_blocks_f16x3(&e4w_c, (int)EHT, 1)
+                                                                                                              : put_blocks(&e4w_c, (int)EHT, 1);
     const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(&e4b_c), o_elg = put_vec(elg), o_elb = put_vec(elb);
     const size_t o_cen = expand ? put_vec(cen) : bb.add(64);
     const size_t o_d1 = put_node(d0w, 1, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);

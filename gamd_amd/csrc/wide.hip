@@ -38,7 +38,8 @@ __device__ __forceinline__ void wide_barrier() {
 // does not fit 256 registers (66 spilled registers in round 3): 4 waves, one per SIMD with the whole register file, no scratch.
 template <int EHT> struct EncWaves { static constexpr int value = EHT == 2 ? 4 : 8; };
 
-template <int NFEAT, int EHT>
+// LP: the reduced-precision edge modes (a.e_format 1 / 2): the two 128-wide GEMMs in split-fp16, e written in operand form
+template <int NFEAT, int EHT, bool LP = false>
 __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(EncArgs a) {
     if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
     static_assert(EHT == 1 || EHT == 2, "edge embedding width 128 or 256");
@@ -138,7 +139,10 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
 #pragma unroll
             for (int r = 0; r < 16; ++r) X[t][r] = gamd_gelu_hw(acc[t][r]);
         load_bias_chain(vb2, half, acc);
-        gemm128<false>((const f32x4*)w2, lane, X, acc);
+        // (reduced-precision edge modes, a.e_format != 0: the two 128-wide GEMMs of the encoder in split-fp16 -- fp32-grade at 3/16
+        //  of the fp32 matrix time; W2 / W3 blocks arrive as (hi | lo) fp16 images of the same size; the K = 48 first layer stays fp32)
+        if (LP) gemm128_f16x3<false>((const f16x8*)w2, lane, X, acc);
+        else gemm128<false>((const f32x4*)w2, lane, X, acc);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -155,7 +159,8 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
             load_bias_chain(vb3 + 128 * ob, half, Y[ob]);
             unsigned ws_off = (unsigned)((WIDE_ENC_W1_FLOATS + GAMD_WFRAG_FLOATS) * sizeof(float));
             asm volatile("" : "+s"(ws_off));                 // one base register + immediate offsets (see k_conv_edge_wide)
-            gemm128<false>((const f32x4*)((const char*)lds + ws_off), lane, X, Y[ob]);
+            if (LP) gemm128_f16x3<false>((const f16x8*)((const char*)lds + ws_off), lane, X, Y[ob]);
+            else gemm128<false>((const f32x4*)((const char*)lds + ws_off), lane, X, Y[ob]);
         }
         // LayerNorm over Eh features (torch: biased variance, eps inside the sqrt)
         float s1 = 0.f;
@@ -195,9 +200,9 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
                             v[j] = zero_row ? 0.f : (Y[ob][t][q * 4 + j] - mean) * rstd * g[j] + b[j];
                             nv[q * 4 + j] = v[j];
                         }
-                        if (a.e_format == 0) out[((ob * 4 + t) * 4 + q) * 64 + lane] = v;
+                        if (!LP) out[((ob * 4 + t) * 4 + q) * 64 + lane] = v;
                     }
-                    if (a.e_format == 1) {
+                    if (LP && a.e_format == 1) {
                         // bf16 edge MLP (wide_lp.hip): e as bf16 fragments, [tile][block][t][u][lane][8 values]
                         bf16x8* efrag = reinterpret_cast<bf16x8*>(a.e_frag);
 #pragma unroll
@@ -208,7 +213,7 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
                             efrag[(((size_t)tile * EHT + ob) * 8 + t * 2 + u) * 64 + lane] = __builtin_bit_cast(bf16x8, w);
                         }
                     }
-                    if (a.e_format == 2) {
+                    if (LP && a.e_format == 2) {
                         // split-fp16 edge MLP (wide_lp.hip / conv_edge_f16x3.hip): e already split into (hi, lo) fp16 operand
                         // images, [tile][block][t][u][hi | lo][lane][8 halves] -- the layout edge_encode_f16x3.hip writes
                         f16x8* efrag = reinterpret_cast<f16x8*>(a.e_frag);
@@ -679,19 +684,23 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
     }
 }
 
-template <int NFEAT, int EHT>
-int enc_launch(const EncArgs& a, int n_blocks, hipStream_t st) {
+template <int NFEAT, int EHT, bool LP>
+int enc_launch2(const EncArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * (WIDE_ENC_W1_FLOATS + 2 * GAMD_WFRAG_FLOATS + 256 + 3 * 128 * EHT + 64);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_edge_encode_wide<NFEAT, EHT>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_edge_encode_wide<NFEAT, EHT, LP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_edge_encode_wide<NFEAT, EHT>), dim3(n_blocks), dim3(64 * EncWaves<EHT>::value), lds, st, a);
+    hipLaunchKernelGGL((k_edge_encode_wide<NFEAT, EHT, LP>), dim3(n_blocks), dim3(64 * EncWaves<EHT>::value), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
+}
+template <int NFEAT, int EHT>
+int enc_launch(const EncArgs& a, int n_blocks, hipStream_t st) {
+    return a.e_format != 0 ? enc_launch2<NFEAT, EHT, true>(a, n_blocks, st) : enc_launch2<NFEAT, EHT, false>(a, n_blocks, st);
 }
 
 template <int EHT, int HT>
