@@ -502,7 +502,8 @@ def main():
         # (entry, workload, edge dtype): the other single-GPU BASELINE configs, the batched C1, the opt-in split-fp16 and bf16
         # runs of C2 (c2_bf16: the north star's neighbour-gather figure on the 10k-atom LJ box itself, tolerance restated as
         # for config 5) and the DFT-water configuration, 20 timed steps each
-        for name, wname, dt_name in (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c3", "c3", "f32"), ("c5", "c5", "f32"),
+        for name, wname, dt_name in (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c1_batch_f16x3", "c1_batch", "f16x3"),
+                                     ("c3", "c3", "f32"), ("c5", "c5", "f32"),
                                      ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("c2_bf16", "c2", "bf16"), ("dft", "dft", "f32"),
                                      ("dft_f16x3", "dft", "f16x3"), ("dft_bf16", "dft", "bf16")):
             s = build_workload(wname, ctx, dev, args.skin, dt_name)

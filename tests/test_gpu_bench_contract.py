@@ -175,7 +175,8 @@ def test_secondary_block_kernels_list_and_cpu_baseline_on_c2():
     enc = d["roofline"]["kernels"][0]
     assert enc["bound"] == "mfma" and 0.3 < enc["frac"] < 1.0 and abs(enc["frac"] - enc["achieved"] / 157.3) < 1e-9
     s = d["secondary"]
-    assert set(s) == {"c1", "c1_batch", "c3", "c5", "c5b", "c2_f16x3", "c2_bf16", "dft", "dft_f16x3", "dft_bf16"}
+    assert set(s) == {"c1", "c1_batch", "c1_batch_f16x3", "c3", "c5", "c5b", "c2_f16x3", "c2_bf16", "dft", "dft_f16x3", "dft_bf16"}
+    assert s["c1_batch_f16x3"]["n_boxes"] == 38 and s["c1_batch_f16x3"]["value"] > 1.5 * s["c1_batch"]["value"]
     assert s["dft_bf16"]["dtype"] == "bf16" and s["dft_bf16"]["conv_kernel"]["kernel"] == "k_conv_edge_bf16_wide<2,2>"
     assert s["dft_f16x3"]["dtype"].startswith("f16x3") and s["dft_f16x3"]["conv_kernel"]["kernel"] == "k_conv_edge_f16x3_wide<2,2>"
     assert s["dft_f16x3"]["value"] > 1.2 * s["dft"]["value"] and s["c2_f16x3"]["value"] > 1.5 * d["value"]
