@@ -547,3 +547,60 @@ def test_sampled_feature_matrix_against_the_oracle(case):
     med, p99, worst, cnt = per_atom_err(out, ref)
     assert p99 < P99_TOL, (case, med, p99, worst)
     eng.close()
+
+
+# ---- the reduced-precision kernels at the edges of their input space --------------------------------------------------------------
+@pytest.mark.parametrize("edge_dtype,widths", [("f16x3", (128, 128, 128)), ("bf16", (128, 128, 128)), ("f16x3", (256, 128, 256)),
+                                               ("bf16", (256, 128, 256)), ("f16x3", (96, 64, 160))])
+def test_reduced_precision_kernels_on_sparse_tiny_and_overflowing_inputs(edge_dtype, widths):
+    """What the frozen-flag / tail / padding paths of the two-wave kernels see: (a) a gas with isolated atoms and rows shorter than
+    a chunk, edge capacity far too small (detected on device, regrown, retried: status 1); (b) no edge at all (E = 0: every
+    wave idles through the barriers); (c) fewer atoms than one tile; (d) an overflow in the middle of an enqueued MD run
+    (freeze, regrow, resume).  Forces against the fp32 engine at the mode's tolerance, bit-reproducible run to run."""
+    tol = TOL if edge_dtype == "f16x3" else 1e-2
+    enc, hid, emb = widths
+    cfg = ModelConfig(kind="water", encoding_size=enc, hidden_dim=hid, edge_embedding_dim=emb, conv_layer=3)
+    sd = make_state_dict(cfg, 9, 2.0, 0.7)
+    rng = np.random.default_rng(5)
+    # (a) sparse gas + regrow
+    n, box, rc = 128, 16.0, 3.0
+    pos = torch.from_numpy(rng.uniform(0, box, (n, 3))).float()
+    species = np.arange(n) % 3 == 0
+    ref = _engine(sd, n, box, rc, nbr_flavour="torch")
+    want = ref.forward(pos, species=species).cpu().numpy()
+    eng = _engine(sd, n, box, rc, nbr_flavour="torch", edge_capacity=40, edge_dtype=edge_dtype)
+    out = eng.forward(pos, species=species).cpu().numpy()
+    assert eng.last_status == 1 and np.array_equal(edge_set(eng.debug_edges()), edge_set(ref.debug_edges()))
+    assert (np.bincount(eng.debug_edges()[0], minlength=n) == 0).any()
+    assert rel_err(out, want) < tol
+    assert np.array_equal(out, eng.forward(pos, species=species).cpu().numpy()) and eng.last_status == 0
+    # (b) no edges at all: a 3 x 3 x 3 lattice of spacing 4 in a box of 12, cutoff 3 (no self edges in this flavour)
+    lat = torch.tensor([[4.0 * i + 0.5, 4.0 * j + 0.5, 4.0 * k + 0.5] for i in range(3) for j in range(3) for k in range(3)])
+    e0, r0 = (_engine(sd, 27, 12.0, 3.0, nbr_flavour="torch", edge_dtype=dt) for dt in (edge_dtype, "f32"))
+    o0 = e0.forward(lat, species=species[:27]).cpu().numpy()
+    assert e0.counts()[0] == 0 and np.isfinite(o0).all() and rel_err(o0, r0.forward(lat, species=species[:27]).cpu().numpy()) < tol
+    # (c) fewer atoms than one 32-edge tile has slots
+    p7 = pos[:7] * 0.2
+    e7, r7 = (_engine(sd, 7, 16.0, rc, nbr_flavour="torch", edge_dtype=dt) for dt in (edge_dtype, "f32"))
+    o7 = e7.forward(p7, species=species[:7]).cpu().numpy()
+    assert 0 < e7.counts()[0] < 64 and rel_err(o7, r7.forward(p7, species=species[:7]).cpu().numpy()) < tol
+    for e in (ref, eng, e0, r0, e7, r7):
+        e.close()
+    # (d) overflow inside an enqueued run: equal to the ample-buffer run bit for bit (exact rebuild every step)
+    nl, steps = 1500, 8
+    sdl = make_state_dict(ModelConfig(kind="lj", encoding_size=enc, hidden_dim=hid, edge_embedding_dim=emb, conv_layer=2), 2, 5.0, 1.7)
+    posl, boxl = workloads.lj_box(nl, seed=4)
+    res = []
+    for cap in (0, 4000):
+        x = torch.from_numpy(posl).float().cuda()
+        v = torch.from_numpy(workloads.maxwell_boltzmann(nl, 300.0, seed=3)).float().cuda()
+        big = _engine(sdl, nl, boxl, 7.5, scaler=SHIPPED_SCALERS["lj"], edge_dtype=edge_dtype)
+        f = big.forward(x, denormalize=True).clone()
+        big.close()
+        eng = _engine(sdl, nl, boxl, 7.5, scaler=SHIPPED_SCALERS["lj"], edge_dtype=edge_dtype, edge_capacity=cap)
+        eng.md_run(x, v, f, steps, seed=11, sync=False)
+        assert eng.sync_status() == (1 if cap else 0)
+        res.append((x.cpu().numpy(), v.cpu().numpy(), f.cpu().numpy()))
+        eng.close()
+    for a, b in zip(*res):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
