@@ -81,6 +81,29 @@ def test_gpus_2_spawns_two_ranks_by_itself():
     assert "cpu_baseline" not in d and "secondary" not in d
 
 
+def test_the_drivers_own_launch_line_for_n_greater_1():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W`: ranks come up with RANK / LOCAL_RANK / WORLD_SIZE in the
+    environment and bench.py must NOT spawn again.  Same dry run as above (two ranks on this box's one GPU, gloo)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    e.update(GAMD_BENCH_SHARE_GPU="1", GAMD_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout                                   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["config"]["boxes"] == 2
+    assert d["config"]["launch"] != "self-spawned ranks"
+    assert [r["rank"] for r in d["ensemble"]["per_rank"]] == [0, 1] and all(r["group_world_size"] == 2 for r in d["ensemble"]["per_rank"])
+    assert abs(d["value"] - 2 * 10000 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+
+
 def test_gpus_2_line_names_each_ranks_device():
     """per_rank carries the device ordinal, the PCI bus id and the size of the process group each rank saw: on an 8-GPU node
     'N ranks on N distinct GPUs' is readable from the line (here both ranks share device 0 on purpose)."""
