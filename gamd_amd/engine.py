@@ -288,22 +288,31 @@ class GamdForce:
         """e [E, edge_embedding_dim] de-fragmented to CSR edge order."""
         e = self.counts()[0]
         nt = (e + 31) // 32
-        if self.edge_dtype == "f16x3":                   # pre-split fragments [tile][t][u][hi|lo][lane][8 halves]
-            raw = self._dbg(3, (nt, 4096), np.float32).view(np.float16).reshape(nt, 4, 2, 2, 64, 8).astype(np.float32)
-            val = raw[:, :, :, 0] + raw[:, :, :, 1]
+        nb = (self.cfg.edge_embedding_dim + 127) // 128               # widths below a 128-block are zero-padded on the device
+        if self.edge_dtype in ("f16x3", "bf16"):
+            # operand-form fragments: [tile][block][t][u][hi | lo][lane][8 halves] (split-fp16: the value is hi + lo) or
+            # [tile][block][t][u][lane][8 bf16]; K step (t, u) value j of lane (slot, half) is feature
+            # 128 block + 32 t + (r & 3) + 8 (r >> 2) + 4 half with r = 8 u + j
+            raw = self._dbg(3, (nt, nb, 4096), np.float32)
+            if self.edge_dtype == "f16x3":
+                v = raw.view(np.float16).reshape(nt, nb, 4, 2, 2, 64, 8).astype(np.float32)
+                val = v[:, :, :, :, 0] + v[:, :, :, :, 1]
+            else:
+                u16 = raw.reshape(-1).view(np.uint16)[:nt * nb * 4096].reshape(nt, nb, 4, 2, 64, 8)       # 8 KiB per (tile, block), dense
+                val = (u16.astype(np.uint32) << 16).view(np.float32)
             lane = np.arange(64)
             slot, half = lane & 31, lane >> 5
             pi = 16 * ((slot >> 2) & 1) + (slot & 3) + 4 * (slot >> 3)
             rows = (np.arange(nt)[:, None] * 32 + pi[None, :])
-            out = np.zeros((nt * 32, 128), dtype=np.float32)
-            for t in range(4):
-                for u in range(2):
-                    for j in range(8):
-                        r = 8 * u + j
-                        feat = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half
-                        out[rows, feat[None, :]] = val[:, t, u, :, j]
-            return out[:e]
-        nb = (self.cfg.edge_embedding_dim + 127) // 128               # widths below a 128-block are zero-padded on the device
+            out = np.zeros((nt * 32, 128 * nb), dtype=np.float32)
+            for blk in range(nb):
+                for t in range(4):
+                    for u in range(2):
+                        for j in range(8):
+                            r = 8 * u + j
+                            feat = 128 * blk + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half
+                            out[rows, feat[None, :]] = val[:, blk, t, u, :, j]
+            return out[:e, :self.cfg.edge_embedding_dim]
         frag = self._dbg(3, (nt, nb, 4, 4, 64, 4), np.float32)
         lane = np.arange(64)
         slot, half = lane & 31, lane >> 5

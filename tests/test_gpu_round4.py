@@ -604,3 +604,25 @@ def test_reduced_precision_kernels_on_sparse_tiny_and_overflowing_inputs(edge_dt
         eng.close()
     for a, b in zip(*res):
         assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["lj258_seed0", "tip3p774_w256_seed10", "dynbox384_h128_e256_noexpand_seed8"])
+def test_debug_getter_reads_the_operand_form_edge_embeddings(name):
+    """debug_e on the reduced-precision engines: the encoder's output in operand form (split-fp16 pairs / bf16 fragments, one or
+    two 128-blocks) de-fragmented by the host equals the fp32 engine's e to the format's precision."""
+    g, cfg, sd = load_golden(name)
+    n = g["pos"].shape[0]
+    dyn = cfg.kind == "dynbox"
+    box = g["box"] if dyn else float(g["box"])
+    kw = dict(nbr_flavour="torch") if dyn else dict(bond=g["bond"] if "bond" in g else None)
+    species = (g["node_feat"].reshape(-1) != 0) if "node_feat" in g else None
+    pos = torch.from_numpy(g["pos"] if dyn else np.mod(g["pos"], box)).float()
+    es = {}
+    for dt in ("f32", "f16x3", "bf16"):
+        eng = _engine(sd, n, box, float(g["cutoff"]), edge_dtype=dt, keep_stages=True, **kw)
+        eng.forward(pos, box=box, species=species) if dyn else eng.forward(pos, species=species)
+        es[dt] = eng.debug_e()
+        eng.close()
+    assert es["f32"].shape == (len(g["edge_idx"][0]), cfg.edge_embedding_dim)
+    assert rel_err(es["f16x3"], es["f32"]) < 5e-6
+    assert 1e-5 < rel_err(es["bf16"], es["f32"]) < 1e-2
