@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Random feature-matrix sweep on the GPU box (not part of pytest): 6 x 16 seeded combinations of widths (8..256 / 8..128 / 8..256),
+"""Random feature-matrix sweep on the GPU box (test infrastructure: it checks against the oracle, so it lives under tests/; not
+collected by pytest): 6 x 16 seeded combinations of widths (8..256 / 8..128 / 8..256),
 1-5 layers, the three model flavours, LayerNorm or BatchNorm, update_edge, expand_edge on / off, bond feature, skin or exact
 neighbour mode, 1-3 boxes per handle and the three edge dtypes -- forces against the oracle (1e-5; bf16: 1e-2).  The fixed
 sample in tests/test_gpu_round4.py::test_sampled_feature_matrix_against_the_oracle is the pytest-sized version of this."""
