@@ -99,18 +99,21 @@ def spawn_ranks(args) -> int:
     port = s.getsockname()[1]
     s.close()
     import signal
-    from gamd_amd.ensemble import supervise_ranks
-    # a SIGTERM to this launcher (a driver's timeout) must not orphan the ranks: turn it into an exception so that
-    # supervise_ranks' cleanup runs
+    from gamd_amd.ensemble import stop_ranks, supervise_ranks
+    # a SIGTERM to this launcher (a driver's timeout) must not orphan the ranks: turn it into an exception so that the
+    # cleanup below runs — also when it arrives while the ranks are still being started
     signal.signal(signal.SIGTERM, lambda *_: sys.exit(143))
     procs, out0 = [], tempfile.TemporaryFile(mode="w+")      # a file, not a pipe: rank 0 can never block on a full pipe
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
-    failed = supervise_ranks(procs, timeout_s=float(os.environ.get("GAMD_BENCH_TIMEOUT_S", "1800")))
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+        failed = supervise_ranks(procs, timeout_s=float(os.environ.get("GAMD_BENCH_TIMEOUT_S", "1800")))
+    finally:
+        stop_ranks(procs)                                    # no-op when supervise_ranks returned normally
     if failed is not None:
         r, c = failed
         print(f"bench.py: {'the run timed out' if r < 0 else f'rank {r} exited with status {c}'}; "

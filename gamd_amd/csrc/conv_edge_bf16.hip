@@ -300,13 +300,8 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
 
 template <int ABL>
 static int launch_bf16_abl(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge_bf16<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            CONVB_LDS_BYTES);
-        if (e1 != hipSuccess) return (int)e1;
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int e = gamd_allow_dynamic_lds(once, (int)CONVB_LDS_BYTES, k_conv_edge_bf16<ABL>)) return e;
     hipLaunchKernelGGL(k_conv_edge_bf16<ABL>, dim3(n_blocks), dim3(64 * BF16_NW), CONVB_LDS_BYTES, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;

@@ -247,12 +247,8 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_f16x3(ConvEdgeArgs a) {
 template <bool TIME>
 static int launch_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * CONV_LDS_FLOATS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_conv_edge_f16x3<TIME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e1 != hipSuccess) return (int)e1;
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int e = gamd_allow_dynamic_lds(once, (int)lds, k_conv_edge_f16x3<TIME>)) return e;
     hipLaunchKernelGGL(k_conv_edge_f16x3<TIME>, dim3(n_blocks), dim3(512), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;

@@ -338,14 +338,8 @@ int launch_edge_encode_small(const EncArgs& a, int n_blocks, hipStream_t st) {
 template <int ABL>
 static int launch_abl(const EncArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * ENC_LDS_FLOATS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_edge_encode<44, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute((const void*)k_edge_encode<45, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e1 != hipSuccess) return (int)e1;
-        if (e2 != hipSuccess) return (int)e2;
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int e = gamd_allow_dynamic_lds(once, (int)lds, k_edge_encode<44, ABL>, k_edge_encode<45, ABL>)) return e;
     if (a.n_feat == 44) hipLaunchKernelGGL((k_edge_encode<44, ABL>), dim3(n_blocks), dim3(512), lds, st, a);
     else if (a.n_feat == 45) hipLaunchKernelGGL((k_edge_encode<45, ABL>), dim3(n_blocks), dim3(512), lds, st, a);
     else return -22;

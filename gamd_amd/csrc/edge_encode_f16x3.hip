@@ -134,14 +134,8 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_f16x3(EncArgs a) {
 }  // namespace
 
 int launch_edge_encode_f16x3(const EncArgs& a, int n_blocks, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)k_edge_encode_f16x3<44>, hipFuncAttributeMaxDynamicSharedMemorySize, ENCH_LDS_BYTES);
-        hipError_t e2 = hipFuncSetAttribute((const void*)k_edge_encode_f16x3<45>, hipFuncAttributeMaxDynamicSharedMemorySize, ENCH_LDS_BYTES);
-        if (e1 != hipSuccess) return (int)e1;
-        if (e2 != hipSuccess) return (int)e2;
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int e = gamd_allow_dynamic_lds(once, (int)ENCH_LDS_BYTES, k_edge_encode_f16x3<44>, k_edge_encode_f16x3<45>)) return e;
     if (a.n_feat == 44) hipLaunchKernelGGL(k_edge_encode_f16x3<44>, dim3(n_blocks), dim3(512), ENCH_LDS_BYTES, st, a);
     else if (a.n_feat == 45) hipLaunchKernelGGL(k_edge_encode_f16x3<45>, dim3(n_blocks), dim3(512), ENCH_LDS_BYTES, st, a);
     else return -22;

@@ -188,6 +188,7 @@ int fill_com(gamd_handle* h, int enabled, MdCom* c) {
 }
 
 int alloc_candidates(gamd_handle* h, long long cap) {
+    if (!small_path(h)) cap = std::max<long long>(cap, h->n);     // fixed-width rows: at least one slot per atom
     if (h->cand_col.ensure(sizeof(int) * ((size_t)cap + 64), true)) return fail(-12, "candidate buffer allocation failed");
     h->cand_cap = cap;
     h->cand_valid = false;
@@ -318,7 +319,10 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
         a.cand_col = h->cand_col.as<int>();
         a.cand_cap = h->cand_cap;
         // fixed-width candidate rows above the single-workgroup size (neighbor.hip): the width follows the capacity
-        a.cand_stride = small_path(h) ? 0 : (int)std::min<long long>(h->cand_cap / h->n, 1 << 20);
+        // (alloc_candidates keeps cand_cap >= n on this path, so the width is at least 1: a buffer that is too small shows up
+        // as rows longer than the stride = the overflow -> regrow protocol, not as a zero stride)
+        a.use_small = small_path(h) ? 1 : 0;
+        a.cand_stride = small_path(h) ? 0 : (int)std::max<long long>(1, std::min<long long>(h->cand_cap / h->n, 1 << 20));
     }
     return a;
 }

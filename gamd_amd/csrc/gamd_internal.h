@@ -21,6 +21,27 @@ enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, 
 //                      half) of the first integrator kernel that found the flag set, -1 if none did: where to resume
 enum { DEVFLAG_FROZEN = 0, DEVFLAG_FROZEN_AT = 1, DEVFLAG_COUNT = 4 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel, DEVICE): a process that holds handles on several
+// devices (gamd_config.device; SURVEY.md 8e "one stream per device from one process") must raise the limit on each of them, or
+// the second device launches > 64 KiB of dynamic LDS without it.  One flag per device and kernel instantiation; launchers run
+// under the handle's DeviceGuard, so the current device is the one the launch goes to.
+constexpr int GAMD_MAX_DEVICES = 64;
+struct PerDeviceOnce { bool done[GAMD_MAX_DEVICES] = {}; };
+template <typename... Fn>
+inline int gamd_allow_dynamic_lds(PerDeviceOnce& once, int bytes, Fn... fns) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0 && dev < GAMD_MAX_DEVICES && once.done[dev]) return 0;
+    const void* list[] = {(const void*)fns...};
+    for (const void* fn : list) {
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (dev >= 0 && dev < GAMD_MAX_DEVICES) once.done[dev] = true;
+    return 0;
+}
+
 // ---- several independent boxes in one set of launches (gamd_config.n_boxes > 1) -----------------------------------------
 // Box b owns atoms [b * n_per_box, (b + 1) * n_per_box) in the caller's order AND in the sorted order (cells are numbered
 // box-major: cell = first cell of box b + local cell, and every box holds exactly n_per_box atoms).  boxes[3 b] = (Lx, Ly, Lz, 0),
@@ -95,6 +116,9 @@ struct NbrArgs {
     int cand_stride;       // > 0 (n > 1024): candidate row c is cand_col[c * cand_stride ..][cand_deg[c]] — fixed-width rows as in
                            // jax-md's idx[N, max_occupancy] (graph_utils.py:21-25): one kernel fills them, no count / scan / fill
                            // passes.  0 (n <= 1024, k_step_small): CSR rows cand_col[cand_ptr[c] ..][cand_deg[c]]
+    int use_small;         // the host's choice (gamd_api.hip: use_small, n <= 1024): k_step_small + k_filter_fill_small, CSR
+                           // candidate rows.  Explicit, not inferred from cand_stride == 0 (an undersized candidate buffer must
+                           // surface as an overflow on the grid-wide path, never send n > 1024 atoms into the one-workgroup kernel)
     int cells_one_wg;      // candidate rebuild: the four cell-list phases in one single-workgroup launch (rebuilds are rare: one
                            // gated launch per reuse step instead of four) or as four grid-wide kernels (rebuilds are frequent)
     float rc_build, rc2_build;   // rc + skin
@@ -320,7 +344,8 @@ struct NhcArgs {
     int n_blocks;              // blocks per box
     int* devflags;             // as in MdArgs
     int step_index;
-    MdCom com;                 // as in MdArgs: removed at the top of the first half, before the kinetic energy is taken
+    MdCom com;                 // as in MdArgs; in the first half the remover runs behind propagateNHC (hack_integrator.py:271-272):
+                               // KE2 and the chain see the velocities as they are, the scaled velocities lose their COM part
 };
 // per-block momentum sums of the current velocities (first kernel of a step whose integrator removes the COM motion)
 int launch_com_partial(const MdCom& com, const float* v, const uint8_t* species, float inv_mass, float inv_mass_h, int n,

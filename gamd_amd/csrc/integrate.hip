@@ -98,10 +98,8 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
     double s = 0.0;
     const double inv_len = 1.0 / (double)a.len;
     const int npb = nhc_npb(a), a0 = blockIdx.y * npb, a1 = a0 + npb;        // this box's atoms [a0, a1)
-    // first half: updateContextState (hack_integrator.py:272) = the CMMotionRemover, before the kinetic energy is taken
-    float com[3] = {0.f, 0.f, 0.f};
-    const bool decom = !KICK && a.com.enabled;
-    if (decom) md_com_velocity(a.com, blockIdx.y, com);
+    // (first half: propagateNHC takes KE2 from the velocities as they are, hack_integrator.py:271; the CMMotionRemover of
+    // addUpdateContextState() :272 acts AFTER the chain has scaled them -> k_nhc_apply_first)
     if (a.use_rigid) {
         for (int m = a0 / 3 + blockIdx.x * blockDim.x + threadIdx.x; 3 * m < a1; m += gridDim.x * blockDim.x) {
             Vec3 v[3];
@@ -115,11 +113,6 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
                 settle_velocities(x, v, a.rigid);
                 store_mol(a.v, m, v);
             }
-            if (decom) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) v[k] = v[k] - Vec3{com[0], com[1], com[2]};
-                store_mol(a.v, m, v);
-            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const double vx = inv_len * v[k].x, vy = inv_len * v[k].y, vz = inv_len * v[k].z;
@@ -131,7 +124,6 @@ __global__ void __launch_bounds__(256) k_nhc_ke2(NhcArgs a) {
             const float w = atom_inv_mass(a.species, 1.0f / a.mass, a.mass_h > 0.f ? 1.0f / a.mass_h : 0.f, i / 3);
             float v = a.v[i];
             if (KICK) { v += 0.5f * a.dt * a.len * w * a.f[i]; a.v[i] = v; }   // hack_integrator.py:427 v+0.5*dt*gnn_force/m
-            if (decom) { v -= com[i % 3]; a.v[i] = v; }
             const double vn = inv_len * (double)v;
             s += vn * vn / (double)w;
         }
@@ -181,7 +173,9 @@ __global__ void k_nhc_chain(NhcArgs a) {
     st[3 * M + 1] = KE2;
 }
 
-// first half tail: v = scale*v; v += dt/2 f_last/m; x += dt v   (hack_integrator.py:274-280)
+// first half tail: v = scale*v (end of propagateNHC, :316); updateContextState (:272) = the CMMotionRemover on the scaled
+// velocities, sum m (scale v) / sum m = scale * vcom with vcom from k_com_partial's sums over the unscaled ones;
+// v += dt/2 f_last/m; x += dt v   (hack_integrator.py:273-280)
 __global__ void k_nhc_apply_first(NhcArgs a) {
     GAMD_MD_GATE(0);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,9 +185,12 @@ __global__ void k_nhc_apply_first(NhcArgs a) {
     md_box(a.bx, a.box, ba.box, box);
     const float scale = (float)a.state[(size_t)ba.box * nhc_state_stride(a) + 3 * a.M];
     const float kick = 0.5f * a.dt * a.len * atom_inv_mass(a.species, 1.0f / a.mass, a.mass_h > 0.f ? 1.0f / a.mass_h : 0.f, i);
+    float com[3] = {0.f, 0.f, 0.f};
+    if (a.com.enabled) md_com_velocity(a.com, ba.box, com);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         float v = a.v[3 * i + d] * scale;
+        v -= scale * com[d];
         v += kick * a.f[3 * i + d];
         a.v[3 * i + d] = v;
         a.x[3 * i + d] = gamd_remainder(a.x[3 * i + d] + a.dt * v, box[d]);
@@ -212,9 +209,12 @@ __global__ void k_nhc_apply_first_rigid(NhcArgs a) {
     md_box(a.bx, a.box, ba.box, box);
     const float scale = (float)a.state[(size_t)ba.box * nhc_state_stride(a) + 3 * a.M];
     const float w[3] = {1.0f / a.rigid.m_o, 1.0f / a.rigid.m_h, 1.0f / a.rigid.m_h};
+    float com[3] = {0.f, 0.f, 0.f};
+    if (a.com.enabled) md_com_velocity(a.com, ba.box, com);
+    const Vec3 vcom{scale * com[0], scale * com[1], scale * com[2]};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        v[k] = (scale * v[k]) + ((0.5f * a.dt * a.len * w[k]) * f[k]);
+        v[k] = ((scale * v[k]) - vcom) + ((0.5f * a.dt * a.len * w[k]) * f[k]);
         x1[k] = x[k] + (a.dt * v[k]);
         xc[k] = x1[k];
     }

@@ -950,7 +950,8 @@ int launch_csr_from_edges(const NbrArgs& a, const int* centre, const int* neigh,
 int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     hipError_t e;
     const int tb = 256, gb = (a.n + tb - 1) / tb, ga = (a.n + 7) / 8;
-    if (a.counters_next && a.cand_stride == 0) {           // the host's choice (gamd_api.hip: small_path)
+    if (a.counters_next && a.use_small) {                  // the host's choice (gamd_api.hip: small_path)
+        if (a.n > 1024) return -22;                        // k_step_small keeps one atom per thread of ONE workgroup
         // small system (n <= 1024): 3 launches and no memset node instead of 13 + 1 (+ 2 integrator launches): counters
         // ping-pong, cell arrays cleared inside the rebuild, integrator halves folded in
         MdArgs md{};

@@ -687,13 +687,8 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
 template <int NFEAT, int EHT, bool LP>
 int enc_launch2(const EncArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * (WIDE_ENC_W1_FLOATS + 2 * GAMD_WFRAG_FLOATS + 256 + 3 * 128 * EHT + 64);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_edge_encode_wide<NFEAT, EHT, LP>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int e = gamd_allow_dynamic_lds(once, (int)lds, k_edge_encode_wide<NFEAT, EHT, LP>)) return e;
     hipLaunchKernelGGL((k_edge_encode_wide<NFEAT, EHT, LP>), dim3(n_blocks), dim3(64 * EncWaves<EHT>::value), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
@@ -706,13 +701,8 @@ int enc_launch(const EncArgs& a, int n_blocks, hipStream_t st) {
 template <int EHT, int HT>
 int conv_launch(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * (2 * GAMD_WFRAG_FLOATS + 256 + 128 * HT);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_conv_edge_wide<EHT, HT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static PerDeviceOnce once;
+    if (int e = gamd_allow_dynamic_lds(once, (int)lds, k_conv_edge_wide<EHT, HT>)) return e;
     hipLaunchKernelGGL((k_conv_edge_wide<EHT, HT>), dim3(n_blocks), dim3(512), lds, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;

@@ -330,13 +330,9 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_bf16_wide(ConvEdgeArgs a) 
 template <bool BF, int EHT, int HT>
 int conv_launch(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
     const size_t lds = sizeof(float) * WCONV_LDS_FLOATS;
-    static bool attr_set = false;
+    static PerDeviceOnce once;
     const void* fn = BF ? (const void*)k_conv_edge_bf16_wide<EHT, HT> : (const void*)k_conv_edge_f16x3_wide<EHT, HT>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int e = gamd_allow_dynamic_lds(once, (int)lds, fn)) return e;
     if (BF) hipLaunchKernelGGL((k_conv_edge_bf16_wide<EHT, HT>), dim3(n_blocks), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((k_conv_edge_f16x3_wide<EHT, HT>), dim3(n_blocks), dim3(512), lds, st, a);
     GAMD_CHECK_LAUNCH();

@@ -37,17 +37,17 @@ def _box3(box) -> np.ndarray:
 
 
 def _boxes(box, n_boxes: int) -> np.ndarray:
-    """scalar | [3] (every box the same) | [n_boxes] of scalars or [3]s -> float32 [n_boxes, 3]."""
+    """scalar | [3] (ONE orthorhombic box, the same for every box) | [n_boxes, 1] or [n_boxes] cubic edge per box |
+    [n_boxes, 3] -> float32 [n_boxes, 3].  A 1-D input of three numbers is always one box for all, also when n_boxes == 3:
+    per-box cubic edges of a 3-box batch are spelled [3, 1] (or [3, 3])."""
     b = np.asarray(box, dtype=np.float64)
-    if b.ndim == 0 or b.size == 1 or (b.ndim == 1 and b.size == 3 and n_boxes != 3):
+    if b.ndim == 0 or b.size == 1 or (b.ndim == 1 and b.size == 3):
         return np.tile(_box3(b), (n_boxes, 1))
-    if b.ndim == 1 and b.size == n_boxes:
-        return np.repeat(b.astype(np.float32)[:, None], 3, axis=1)
     if b.ndim == 2 and b.shape == (n_boxes, 3):
         return b.astype(np.float32)
-    if b.ndim == 1 and b.size == 3:              # n_boxes == 3 and three numbers: one box for all (use [n_boxes, 3] to differ)
-        return np.tile(_box3(b), (n_boxes, 1))
-    raise ValueError(f"box must be a scalar, 3 values, or one of those per box ({n_boxes} boxes)")
+    if (b.ndim == 1 and b.size == n_boxes) or (b.ndim == 2 and b.shape == (n_boxes, 1)):
+        return np.repeat(b.reshape(-1).astype(np.float32)[:, None], 3, axis=1)
+    raise ValueError(f"box must be a scalar, 3 values, [{n_boxes}, 1] or [{n_boxes}, 3] ({n_boxes} boxes)")
 
 
 class GamdForce:
@@ -378,7 +378,8 @@ class GamdForce:
         constraints (three per rigid molecule), minus 3 when the System holds a CMMotionRemover.
         ``remove_cm_motion`` says whether it does: default True with ``rigid_water`` (the water drivers build an
         openmmtools WaterBox, whose System carries one), False otherwise (the LJ drivers' ndf is 3N).  When it does, the
-        centre-of-mass velocity is also subtracted on the device at the top of every step (hack_integrator.py:272)."""
+        centre-of-mass velocity is also subtracted on the device where hack_integrator.py:271-272 does it: behind
+        propagateNHC() of the first half (the chain sees the velocities as they are), in front of the kick."""
         self._md_state(x, v, f)
         reset = chain_state is None
         if reset:

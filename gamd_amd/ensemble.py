@@ -66,8 +66,8 @@ def box_seed(base_seed: int, ctx: EnsembleContext) -> int:
 def barrier(ctx: EnsembleContext, device=None) -> None:
     if ctx.distributed:
         if ctx.backend == "nccl":
-            d = torch.cuda.current_device() if device is None else torch.device(device).index
-            dist.barrier(device_ids=[d])
+            d = None if device is None else torch.device(device).index      # "cuda" carries no index: the current device
+            dist.barrier(device_ids=[torch.cuda.current_device() if d is None else d])
         else:
             dist.barrier()
 
@@ -126,6 +126,20 @@ def shutdown(ctx: EnsembleContext) -> None:
         dist.destroy_process_group()
 
 
+def stop_ranks(procs: Sequence["subprocess.Popen"], grace_s: float = 5.0) -> None:
+    """SIGTERM, then SIGKILL after `grace_s`, to whichever of the given children (exact PIDs) are still running."""
+    alive = [p for p in procs if p.poll() is None]
+    for p in alive:
+        p.terminate()
+    t_end = time.monotonic() + grace_s
+    for p in alive:
+        try:
+            p.wait(timeout=max(0.0, t_end - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+
+
 def supervise_ranks(procs: Sequence["subprocess.Popen"], timeout_s: float = 1800.0, poll_s: float = 0.2,
                     grace_s: float = 5.0) -> Optional[Tuple[int, int]]:
     """Watch the rank processes a launcher started (bench.py --gpus N without torchrun).  Returns None when every rank
@@ -148,14 +162,5 @@ def supervise_ranks(procs: Sequence["subprocess.Popen"], timeout_s: float = 1800
                 break
             time.sleep(poll_s)
     finally:
-        alive = [p for p in procs if p.poll() is None]
-        for p in alive:
-            p.terminate()
-        t_end = time.monotonic() + grace_s
-        for p in alive:
-            try:
-                p.wait(timeout=max(0.0, t_end - time.monotonic()))
-            except subprocess.TimeoutExpired:
-                p.kill()
-                p.wait()
+        stop_ranks(procs, grace_s)
     return failed

@@ -64,7 +64,9 @@ typedef struct gamd_config {
                                 operands rounded to bf16, fp32 accumulate; S/D adds, SiLU, sums in fp32; the node side's GEMMs fp32-grade: split-fp16
                                 as in F16X3)
                                 | GAMD_EDGE_F16X3 (fp32-grade edge-MLP on the fp16 matrix pipe: every operand split into
-                                hi + lo fp16, W x = Wh xh + (Wh xl + Wl xh), fp32 accumulate; same parity bar as F32).
+                                hi + lo fp16, W x = Wh xh + (Wh xl + Wl xh), fp32 accumulate; meets F32's 1e-5 parity bar on every
+                                shipped architecture and golden; 3-4 x the fp32 kernels' rounding error, so a deep model with
+                                heavy cancellation can land just above it: opt-in, labelled with its own dtype).
                                 Both exist for every width and feature set (at most 2^22 - 2 atoms per handle when
                                 encoding_size > 128); fp32 only: self_loop_mode 1 and update_edge models */
     int32_t encoding_size;   /* node width H: 0 (= 128) or 1 .. 256 (build_model 'encoding_size') */
@@ -250,7 +252,9 @@ typedef struct gamd_nhc_params {
                                 of the water drivers at every addConstrainPositions / addConstrainVelocities of
                                 hack_integrator.py:145-164,178,277-280,427-428 (SETTLE + analytic velocity constraint) */
     float r_oh, r_hh;        /* constraint lengths in the length unit (TIP3P: 0.9572, 1.5139 A) */
-    int32_t remove_cm_motion;/* as in gamd_md_params (hack_integrator.py:272; ndf is then 3 smaller, :226-235) */
+    int32_t remove_cm_motion;/* as in gamd_md_params, at the place hack_integrator.py:271-272 has it: propagateNHC() takes KE2 from
+                                the velocities as they are and scales them, THEN addUpdateContextState() removes the centre-of-mass
+                                velocity, then the kick (ndf is 3 smaller with a remover, :226-235) */
 } gamd_nhc_params;
 int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, const uint8_t* species_dev,
                         const float* box, const gamd_nhc_params* p, double* chain_state_dev, int64_t n_steps, void* stream);

@@ -362,10 +362,14 @@ def nhc_propagate(st, ke2, dt, kT, freq, ndf, n_c=5, n_ys=5):
     return scale
 
 
-def nhc_first_half(st, x, v, f_last, mass, dt, kT, freq, ndf):
-    """HackNoseHooverIntegrator step, hack_integrator.py:274-280 (x A, v A/ps, f kJ/mol/nm, no constraints)."""
+def nhc_first_half(st, x, v, f_last, mass, dt, kT, freq, ndf, remove_com=False):
+    """HackNoseHooverIntegrator step, hack_integrator.py:271-280 (x A, v A/ps, f kJ/mol/nm, no constraints):
+    propagateNHC() :271 (KE2 from the velocities as they are, v *= scale), THEN addUpdateContextState() :272 — the
+    System's CMMotionRemover when it has one (``remove_com``) — then the kick."""
     ke2 = float(np.sum(mass * (0.1 * v) ** 2))
     v = v * nhc_propagate(st, ke2, dt, kT, freq, ndf)
+    if remove_com:
+        v = remove_cm_motion(v, mass)
     v = v + 0.5 * dt * f_last * 10.0 / mass
     return x + dt * v, v
 
@@ -462,11 +466,14 @@ def baoab_second_half_rigid(x, v, f, inv_m, dt, pairs, acc_unit=10.0):
     return rattle_velocities(x, v + (0.5 * dt) * acc_unit * f * inv_m, inv_m.reshape(-1), pairs)
 
 
-def nhc_first_half_rigid(st, x, v, f_last, mass, dt, kT, freq, ndf, pairs, lengths, acc_unit=10.0):
-    """HackNoseHooverIntegrator with constraints, hack_integrator.py:274-280: propagateNHC, v kick, x += dt v,
-    ConstrainPositions, v += (x - x1)/dt (no ConstrainVelocities in this half)."""
+def nhc_first_half_rigid(st, x, v, f_last, mass, dt, kT, freq, ndf, pairs, lengths, acc_unit=10.0, remove_com=False):
+    """HackNoseHooverIntegrator with constraints, hack_integrator.py:271-280: propagateNHC, updateContextState (the
+    CMMotionRemover, ``remove_com``), v kick, x += dt v, ConstrainPositions, v += (x - x1)/dt (no ConstrainVelocities in this
+    half)."""
     ke2 = float(np.sum(mass * (v / acc_unit) ** 2))
     v = v * nhc_propagate(st, ke2, dt, kT, freq, ndf)
+    if remove_com:
+        v = remove_cm_motion(v, mass)
     v = v + 0.5 * dt * f_last * acc_unit / mass
     x1 = x + dt * v
     xc = shake_positions(x, x1, (1.0 / mass).reshape(-1), pairs, lengths)

@@ -13,10 +13,21 @@ seed)` into the reference module with `load_state_dict(strict=True)` — which
 also proves our key names / shapes equal the reference's — so tests rebuild the
 identical weights from the seed.
 
-Usage:  python oracle/make_golden.py            (writes tests/golden/*.npz)
+Usage:  python oracle/make_golden.py                     writes tests/golden/*.npz
+        python oracle/make_golden.py --only-wide         (or --only-bn / --only-update / --only-batch / --only-selfloop)
+        python oracle/make_golden.py --out DIR           writes DIR/*.npz instead
+        python oracle/make_golden.py --check             regenerates every fixture into a temporary directory and compares it
+                                                         with tests/golden/ array by array, BIT FOR BIT (keys, dtypes, shapes,
+                                                         bytes); exit status 1 and a list of differences when anything drifted.
+        python oracle/make_golden.py --check --float-rtol 2e-6
+                                                         the same, but floating-point arrays may differ by that much relative to
+                                                         their largest element (torch's CPU GEMM blocking depends on the thread
+                                                         count of the host); keys, dtypes, shapes, integer arrays stay exact.
+                                                         tests/test_oracle_golden.py runs this wherever /root/reference exists.
 """
 import os
 import sys
+import tempfile
 
 import numpy as np
 import torch
@@ -190,7 +201,64 @@ def run_batched_lj(nn_module, name, cfg, seed, pos_list, box, cutoff, lmean, lst
     print(f"{name}: graphs={len(pos_list)} N={[p.shape[0] for p in pos_w]} E={[e.shape[1] for e in edges]} |out|max={np.abs(out).max():.4g}")
 
 
+def compare_dirs(new_dir, old_dir, float_rtol=0.0):
+    """Differences between the fixtures of two directories, as a list of strings (empty = identical bit for bit, or — with
+    float_rtol > 0 — floating-point arrays within that relative distance and everything else identical)."""
+    diffs = []
+    new, old = (sorted(f for f in os.listdir(d) if f.endswith(".npz")) for d in (new_dir, old_dir))
+    for f in sorted(set(new) ^ set(old)):
+        diffs.append(f"{f}: only in {'the regenerated set' if f in new else old_dir}")
+    for f in sorted(set(new) & set(old)):
+        a, b = np.load(os.path.join(new_dir, f), allow_pickle=False), np.load(os.path.join(old_dir, f), allow_pickle=False)
+        for k in sorted(set(a.files) ^ set(b.files)):
+            diffs.append(f"{f}[{k}]: only in {'the regenerated file' if k in a.files else 'the committed file'}")
+        for k in sorted(set(a.files) & set(b.files)):
+            x, y = a[k], b[k]
+            if x.dtype != y.dtype or x.shape != y.shape:
+                diffs.append(f"{f}[{k}]: {x.dtype}{x.shape} regenerated vs {y.dtype}{y.shape} committed")
+            elif x.tobytes() != y.tobytes():
+                worst = ""
+                if x.dtype.kind == "f":
+                    rel = float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max() / max(float(np.abs(y).max()), 1e-30))
+                    if rel <= float_rtol:
+                        continue
+                    worst = f", worst relative difference {rel:.3g}"
+                diffs.append(f"{f}[{k}]: contents differ{worst}")
+    return diffs
+
+
 def main():
+    global OUT
+    argv = list(sys.argv[1:])
+    check = "--check" in argv
+    if check:
+        argv.remove("--check")
+        rtol = float(argv[argv.index("--float-rtol") + 1]) if "--float-rtol" in argv else 0.0
+        committed, tmp = OUT, tempfile.TemporaryDirectory(prefix="gamd_golden_")
+        OUT = tmp.name
+        generate([])
+        diffs = compare_dirs(OUT, committed, rtol)
+        exact = rtol == 0.0 or not compare_dirs(OUT, committed)
+        tmp.cleanup()
+        if diffs:
+            print(f"make_golden --check: {len(diffs)} difference(s) between the reference's outputs here and tests/golden/:")
+            for d in diffs:
+                print("  " + d)
+            sys.exit(1)
+        print("make_golden --check: every fixture under tests/golden/ regenerates "
+              + ("bit for bit" if exact else f"within {rtol:g} (floats), exactly otherwise (not bit for bit on this host)")
+              + " from the reference")
+        return
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = os.path.abspath(argv[i + 1])
+        del argv[i:i + 2]
+    generate(argv)
+
+
+def generate(argv):
+    """argv: at most one --only-* selector."""
+    everything = len(argv) == 0
     os.makedirs(OUT, exist_ok=True)
     nn_module, md_module = ref_stubs.import_reference(REF)
     lj_pos = np.load(os.path.join(REF, "code/LJ/init_pos.npy"))          # [258,3] f32, in [0, 27.22]
@@ -202,7 +270,7 @@ def main():
     # 4 layers — the configuration the generic-width kernels (wide.hip) serve outside the dynamic-box flavour.
     # `--only-wide` writes just these two.
     wide = dict(encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=4)
-    if "--only-wide" in sys.argv or len(sys.argv) == 1:
+    if "--only-wide" in argv or everything:
         run_fixed_box(nn_module, "lj258_w256_seed9", ModelConfig(kind="lj", **wide), 9, lj_pos, 27.27, 7.5,
                       SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, edge_stride=61, h_stride=3)
         nw = w_pos.shape[0]
@@ -211,13 +279,13 @@ def main():
         run_fixed_box(nn_module, "tip3p774_w256_seed10", ModelConfig(kind="water", use_bond=True, **wide), 10,
                       w_pos, 20.0, 4.2, SHIPPED_SCALERS["tip3p"], feat=featw, bond=water_bond(nw),
                       lmean=2.9, lstd=1.1, edge_stride=211, h_stride=9)
-    if "--only-wide" in sys.argv:
+    if "--only-wide" in argv:
         return
 
     # use_layer_norm=False: the constructors' and the trainers' DEFAULT (--use_layer_norm is a store_true flag,
     # LJ/train_network_lj.py:398): nn.BatchNorm1d between the conv layers (nn_module.py:171-196, :579), in eval mode with
     # non-trivial running statistics.  `--only-bn` writes just these two.
-    if "--only-bn" in sys.argv or len(sys.argv) == 1:
+    if "--only-bn" in argv or everything:
         run_fixed_box(nn_module, "lj258_bn_seed11", ModelConfig(kind="lj", use_layer_norm=False, **full), 11, lj_pos, 27.27, 7.5,
                       SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, edge_stride=211, h_stride=3)
         nb_ = w_pos.shape[0]
@@ -228,13 +296,13 @@ def main():
                                   edge_embedding_dim=256, conv_layer=4), 12,
                       w_pos, 20.0, 4.2, SHIPPED_SCALERS["tip3p"], feat=featb, bond=water_bond(nb_),
                       lmean=2.9, lstd=1.1, edge_stride=211, h_stride=9)
-    if "--only-bn" in sys.argv:
+    if "--only-bn" in argv:
         return
 
     # update_edge=True (--update_edge, water/train_network_real_large.py:83,362 -> SmoothConvLayerNew.update_edge_emb,
     # nn_module.py:91-92, :140-146): every conv layer hands LayerNorm(e_emb) to the layers after it as their edge embedding.
     # The DFT-water widths and a 128-wide 3-layer model.  `--only-update` writes just these two.
-    if "--only-update" in sys.argv or len(sys.argv) == 1:
+    if "--only-update" in argv or everything:
         subu = np.mod(w_pos[:384], 20.0)
         run_dynbox(nn_module, md_module, "dynbox384_update_dftcfg_seed13",
                    ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5,
@@ -242,14 +310,14 @@ def main():
         run_dynbox(nn_module, md_module, "dynbox384_update_seed14",
                    ModelConfig(kind="dynbox", update_edge=True, encoding_size=128, hidden_dim=128, edge_embedding_dim=128,
                                conv_layer=3), 14, subu, [20.0, 21.0, 22.5], 4.6, 3.1, 1.2)
-    if "--only-update" in sys.argv:
+    if "--only-update" in argv:
         return
 
     # model-level call with two graphs (`--only-batch` writes just this one)
     rngb = np.random.default_rng(11)
     run_batched_lj(nn_module, "lj258_batch2_seed0", ModelConfig(kind="lj", **full), 0,
                    [lj_pos, lj_pos.astype(np.float64) + rngb.normal(0, 0.3, lj_pos.shape)], 27.27, 7.5, 5.3, 1.6)
-    if "--only-batch" in sys.argv:
+    if "--only-batch" in argv:
         return
 
     # The other reading of `fluid_graph.add_self_loop()` (result discarded, nn_module.py:650-652, :364): an IN-PLACE
@@ -259,7 +327,7 @@ def main():
                   SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, edge_stride=211, inplace_self_loop=True)
     run_dynbox(nn_module, md_module, "dynbox384_selfloop_inplace_seed4", ModelConfig(kind="dynbox", **full), 4,
                np.mod(w_pos[:384], 20.0), [20.0, 21.0, 22.5], 4.6, 3.1, 1.2, inplace_self_loop=True)
-    if "--only-selfloop" in sys.argv:
+    if "--only-selfloop" in argv:
         return
 
     # C1: the reference's own LJ snapshot, shipped LJ scaler, full-size model

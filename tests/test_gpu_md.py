@@ -252,9 +252,7 @@ def test_rigid_water_nose_hoover_matches_oracle(remove_com):
     st = orc.nhc_init(M, freq)
     kT, ndf = wl.KB * T, 2.0 * n - (3.0 if remove_com else 0.0)
     for _ in range(steps):
-        if remove_com:
-            vr = orc.remove_cm_motion(vr, mass)
-        xr, vr = orc.nhc_first_half_rigid(st, xr, vr, fr, mass, dt, kT, freq, ndf, pairs, lengths)
+        xr, vr = orc.nhc_first_half_rigid(st, xr, vr, fr, mass, dt, kT, freq, ndf, pairs, lengths, remove_com=remove_com)
         fr = _oracle_water_forces(sd, xr, box, species, bonds)
         vr = orc.nhc_second_half_rigid(st, xr, vr, fr, mass, dt, kT, freq, ndf, pairs)
     xd, vd = x.cpu().double().numpy(), v.cpu().double().numpy()
@@ -363,14 +361,15 @@ def test_com_motion_removal_is_mass_weighted_and_per_box():
     kw = dict(dt_ps=0.0005, mass_amu=wl.MASS_O, mass_h_amu=wl.MASS_H, species=sp)
     x = torch.from_numpy(pos).float().cuda(); v = torch.from_numpy(v0).float().cuda()
     f = eng.forward(x, species=sp, denormalize=True).clone()
-    # NHC, one step: the first thing it does is remove each box's COM velocity; compare with the oracle per box
+    # NHC, one step: propagateNHC on the velocities as they are (the drift counts as kinetic energy, hack_integrator.py:271),
+    # then each box's COM velocity is removed (:272); compare with the oracle per box
     xn, vn, fn = x.clone(), v.clone(), f.clone()
     chain = eng.md_run_nhc(xn, vn, fn, 1, temperature_k=300.0, remove_cm_motion=True, ndf=3.0 * n - 3.0, **kw)
     for b in range(nb):
         sl = slice(b * n, (b + 1) * n)
         st = orc.nhc_init(10, 25.0)
-        vr = orc.remove_cm_motion(v0[sl], mass)
-        xr, vr = orc.nhc_first_half(st, pos[sl], vr, f[sl].cpu().double().numpy(), mass, 0.0005, wl.KB * 300.0, 25.0, 3.0 * n - 3.0)
+        xr, vr = orc.nhc_first_half(st, pos[sl], v0[sl], f[sl].cpu().double().numpy(), mass, 0.0005, wl.KB * 300.0, 25.0,
+                                    3.0 * n - 3.0, remove_com=True)
         fr = fn[sl].cpu().double().numpy()
         vr = orc.nhc_second_half(st, vr, fr, mass, 0.0005, wl.KB * 300.0, 25.0, 3.0 * n - 3.0)
         assert rel_err(vn[sl].cpu().numpy(), vr) < 1e-4, b

@@ -135,8 +135,6 @@ def test_wide_fixed_box_goldens_stage_by_stage(name):
 @pytest.mark.parametrize("name,widths", [("lj258_bn_seed11", (128, 128, 128)), ("tip3p774_bn_w256_seed12", (256, 128, 256))])
 @pytest.mark.parametrize("edge_dtype", ["f32", "bf16", "f16x3"])
 def test_batchnorm_checkpoints_stage_by_stage(name, widths, edge_dtype):
-    if edge_dtype == "bf16" and widths != (128, 128, 128):
-        pytest.skip("bf16 edge operands are built for the 128-wide kernels")
     case = _wide_case(name, widths=widths, keep_stages=True, edge_dtype=edge_dtype)
     assert not case[1].use_layer_norm and "graph_conv.norm_layers.0.running_var" in case[2]
     _check_stages(*case, tol={"f32": TOL, "bf16": 1e-2, "f16x3": 1e-5}[edge_dtype], stages=edge_dtype == "f32")

@@ -268,3 +268,22 @@ def test_gelu_tail_polynomial_in_the_kernel_header_is_accurate():
     ulp = np.spacing(np.abs(exact).astype(f)).astype(np.float64)
     assert (err / (0.5 * ulp + 1.2e-7)).max() < 1.6 and err.max() < 7e-7
     assert err[np.abs(x) < 2.5].max() < 3.5e-7
+
+
+def test_box_argument_of_a_three_box_batch_is_not_ambiguous():
+    """A 1-D box of three numbers is ONE orthorhombic box for every box of the batch — also when the batch has exactly three
+    boxes (round-4 advisor: it used to be read as three cubic boxes, silently wrong min-image forces); per-box cubic edges
+    are spelled [n_boxes, 1], per-box orthorhombic boxes [n_boxes, 3]."""
+    from gamd_amd.engine import _boxes, _box3
+    one = np.array([20.0, 30.0, 40.0], dtype=np.float32)
+    for nb in (1, 2, 3, 5):
+        assert np.array_equal(_boxes(_box3(one), nb), np.tile(one, (nb, 1)))
+        assert np.array_equal(_boxes(27.27, nb), np.full((nb, 3), np.float32(27.27)))
+    assert np.array_equal(_boxes(np.array([[20.0], [30.0], [40.0]]), 3), np.repeat(one[:, None], 3, axis=1))
+    assert np.array_equal(_boxes([20.0, 30.0], 2), np.array([[20.0] * 3, [30.0] * 3], dtype=np.float32))
+    per_box = np.arange(9, dtype=np.float32).reshape(3, 3) + 10
+    assert np.array_equal(_boxes(per_box, 3), per_box)
+    with pytest.raises(ValueError, match="box must be"):
+        _boxes(np.ones((2, 3)), 3)
+    with pytest.raises(ValueError, match="box must be"):
+        _boxes([1.0, 2.0, 3.0, 4.0], 3)

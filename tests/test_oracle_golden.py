@@ -138,3 +138,21 @@ def test_batched_model_call_golden_is_the_graphs_one_by_one():
         outs.append(orc.forward(sd, torch.from_numpy(g[f"pos{i}"]), torch.from_numpy(g[f"edge_idx{i}"]).long(), float(g["box"])).numpy())
     assert np.concatenate(outs).shape == g["out_norm"].shape
     assert rel_err(np.concatenate(outs), g["out_norm"]) < 5e-6
+
+
+def test_committed_fixtures_are_what_the_generator_writes_today():
+    """Fixtures vs generator drift (round-4 review): wherever the reference is present, oracle/make_golden.py --check runs
+    the reference's own modules again into a temporary directory and compares every array of every fixture with the
+    committed one — same files, same keys, dtypes and shapes, integer arrays identical, floating-point arrays within 2e-6 of
+    their largest element (bit for bit on the build container; torch's CPU GEMM blocking may differ with the host's thread
+    count).  Skipped on the GPU box, where /root/reference does not exist."""
+    import os
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/code"):
+        pytest.skip("the reference is not present on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "make_golden.py"), "--check", "--float-rtol", "2e-6"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "regenerates" in r.stdout
