@@ -38,6 +38,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32
 PEAK_HBM_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E spec peak
 CPU_SAMPLE_ATOMS = 2000
 C1_BATCH_BOXES = 38                         # 38 x 258 = 9 804 atoms: a C2-sized set of launches
+C2_BATCH_BOXES = 8                          # config 4's eight rank boxes (seeds 1234 .. 1241) as ONE batch on one GPU
 # SURVEY.md 8d algorithmic FLOPs of one force evaluation (F = 44, L = 4, H = 128), src/dst Linears on node rows
 FLOP_PER_EDGE_STEP = 2 * (44 * 128 + 2 * 128 * 128) + 4 * (8 * 128 * 128 + 4 * 128)      # 603 136
 FLOP_PER_NODE_STEP = 4 * (10 * 128 * 128) + 2 * (128 * 128 + 3 * 128)                    # 688 896
@@ -61,9 +62,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short C1/C3/C5 runs and the per-kernel replays")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c1_batch", "c2", "c3", "c5", "c5b", "dft"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c1_batch", "c2", "c2_batch8", "c3", "c5", "c5b", "dft"],
                     help="c2 (default, the headline metric): 10k-atom LJ fp32; c1: the reference's own 258-atom LJ snapshot "
-                         "(code/LJ/init_pos.npy); c1_batch: 38 such boxes in one set of launches (gamd_config.n_boxes); c3: 4 170-atom TIP3P fp32; c5: TIP4P-Ew-sized box of 2 000 molecules = 6 000 network "
+                         "(code/LJ/init_pos.npy); c1_batch: 38 such boxes in one set of launches (gamd_config.n_boxes); c2_batch8: the eight 10k-atom boxes the ranks of "
+                         "BASELINE config 4 own (seeds 1234 .. 1241), as one n_boxes = 8 batch on ONE GPU; c3: 4 170-atom TIP3P fp32; c5: TIP4P-Ew-sized box of 2 000 molecules = 6 000 network "
                          "atoms, bf16 edge-MLP; c5b: the other reading of BASELINE config 5, 2 667 molecules = 8 001 network "
                          "atoms; dft: the 774-atom DFT-water configuration (256/256/128 x 5 layers, bohr, cutoff 9.5)")
     ap.add_argument("--skin", type=float, default=1.0 / 6.0,
@@ -177,12 +179,17 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         w.label = ("DFT-water configuration: 258 rigid molecules = 774 atoms, positions/box in bohr (L = 37.8), cutoff 9.5, "
                    f"WaterMDDynamicBoxNet widths 256/256/128, 5 conv layers, {dict(f16x3='split-fp16 edge MLP', bf16='bf16 edge-MLP operands / fp32 accumulate').get(edge_dtype, 'fp32')}, "
                    "random-init weights (seed 5), SETTLE on device, 1 box per GPU")
-    elif name in ("c2", "c1", "c1_batch"):
-        n = N_ATOMS if name == "c2" else 258
-        w.cutoff = 3.0 * wk.LJ_SIGMA if name == "c2" else 7.5       # C1: CUTOFF_RADIUS of LJ/train_network_lj.py:26-29
-        w.n_boxes = C1_BATCH_BOXES if name == "c1_batch" else 1
+    elif name in ("c2", "c2_batch8", "c1", "c1_batch"):
+        n = N_ATOMS if name in ("c2", "c2_batch8") else 258
+        w.cutoff = 3.0 * wk.LJ_SIGMA if n == N_ATOMS else 7.5       # C1: CUTOFF_RADIUS of LJ/train_network_lj.py:26-29
+        w.n_boxes = C1_BATCH_BOXES if name == "c1_batch" else C2_BATCH_BOXES if name == "c2_batch8" else 1
         if name == "c2":
             pos, box = wk.lj_box(n, seed=ens.box_seed(1234, ctx))
+        elif name == "c2_batch8":
+            # box b = the box rank b of `bench.py --gpus 8` owns: positions lj_box(seed 1234 + b), velocities seed 99 + b,
+            # Langevin noise seed 7 + b (gamd_md_run's seed means seed + b for box b)
+            boxes = [wk.lj_box(n, seed=1234 + b) for b in range(w.n_boxes)]
+            pos, box = np.concatenate([p for p, _ in boxes]), boxes[0][1]
         else:
             # C1 = the reference's code/LJ/init_pos.npy verbatim (committed as the `pos` array of the golden
             # fixture oracle/make_golden.py wrote from it), BOX_SIZE 27.27.  c1_batch: box 0 is the snapshot, the others are
@@ -203,6 +210,9 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
         w.dt_ps = 0.002
         w.label = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
                    "random-init weights (seed 0), 1 box per GPU") if name == "c2" else \
+                  (f"C2 x {w.n_boxes}: the {w.n_boxes} independent 10 000-atom LJ boxes of BASELINE config 4 (box seeds 1234 .. "
+                   f"{1233 + w.n_boxes}: what the ranks of --gpus {w.n_boxes} own) evaluated and integrated as ONE batch on one GPU "
+                   "(gamd_config.n_boxes), same model and cutoff as C2") if name == "c2_batch8" else \
                   ("C1: the reference's 258-atom LJ snapshot (code/LJ/init_pos.npy), L=27.27 A, cutoff 7.5 A, fp32, "
                    "random-init weights (seed 0)") if name == "c1" else \
                   (f"C1 x {w.n_boxes}: {w.n_boxes} independent 258-atom LJ boxes (the reference's snapshot + per-box jitter) "
@@ -229,7 +239,11 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
                    "random-init weights (seed 3), 1 box per GPU")
     w.n_atoms, w.box, w.pos = pos.shape[0], box, pos            # n_atoms: all boxes of this rank together
     w.x = torch.from_numpy(pos).float().cuda(dev)
-    w.v = torch.from_numpy(wk.maxwell_boltzmann(w.n_atoms, mass_amu=w.mass, seed=99 + ctx.rank)).float().cuda(dev)
+    if name == "c2_batch8":
+        vel = np.concatenate([wk.maxwell_boltzmann(N_ATOMS, mass_amu=w.mass, seed=99 + b) for b in range(w.n_boxes)])
+    else:
+        vel = wk.maxwell_boltzmann(w.n_atoms, mass_amu=w.mass, seed=99 + ctx.rank)
+    w.v = torch.from_numpy(vel).float().cuda(dev)
     if name == "dft":
         w.v *= float(wk.BOHR_PER_NM / 10.0)
     w.f = w.eng.forward(w.x, species=w.species, denormalize=True)
@@ -245,10 +259,12 @@ def timed_run(w, steps, warmup, ctx, dev, ddev):
     import torch
     from gamd_amd import ensemble as ens
     w.eng.md_run(w.x, w.v, w.f, warmup, first_step=0, **w.md)
+    w.warmup_status = int(w.eng.last_status)
+    w.eng.timing_enable(True)                      # creates its event pools here, outside the timed region
     torch.cuda.synchronize(dev)
     ens.barrier(ctx)
     torch.cuda.synchronize(dev)
-    w.eng.timing_enable(True)
+    rebuilds0 = w.eng.skin_stats()[0] if w.uses_skin else 0
     t0 = time.perf_counter()
     w.eng.md_run(w.x, w.v, w.f, steps, first_step=warmup, sync=True, **w.md)
     w.timed_status = int(w.eng.last_status)        # 1: a neighbour buffer overflowed inside the timed run (frozen, regrown, resumed)
@@ -257,9 +273,43 @@ def timed_run(w, steps, warmup, ctx, dev, ddev):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     w.stages = w.eng.timing_read_stages()          # live HIP events of the timed region, per stage
+    w.step_ms = w.eng.timing_read_steps()          # one HIP event per MD step of the timed region
+    w.rebuilds_in_timed = (w.eng.skin_stats()[0] - rebuilds0) if w.uses_skin else steps
     conv_ms, conv_n = w.stages["conv_edge"]
     w.eng.timing_enable(False)
     return dt, ens.max_over_ranks(dt, ctx, device=ddev), conv_ms, conv_n
+
+
+def step_report(w, steps):
+    """What the timed region was made of, so that the record can explain its own number: the per-step distribution (device
+    time between the HIP events in front of consecutive MD steps), how many candidate-list rebuilds and buffer regrows fell
+    inside it, and what one candidate rebuild costs (event-timed replays of the neighbour stage after the timed region,
+    with and without a forced rebuild)."""
+    import numpy as np
+    s = np.sort(np.asarray(w.step_ms, dtype=np.float64))
+    rep = {"step_ms": ({"min": float(s[0]), "p50": float(np.percentile(s, 50)), "p99": float(np.percentile(s, 99)),
+                        "max": float(s[-1]), "mean": float(s.mean()), "intervals": int(s.size),
+                        "definition": "device ms between HIP events recorded in front of the first kernel of consecutive MD steps"}
+                       if s.size else None),
+           "rebuilds_in_timed": int(w.rebuilds_in_timed),
+           "regrown_in_timed": bool(getattr(w, "timed_status", 0) == 1),
+           "regrown_in_warmup": bool(getattr(w, "warmup_status", 0) == 1)}
+    if s.size and s.size != steps:
+        rep["step_ms"]["note"] = (f"{s.size} intervals for {steps} steps: a run that froze on a buffer overflow contributes its "
+                                  "frozen steps and the resumed ones separately")
+    if w.uses_skin:
+        def nbr_ms(force):
+            acc = []
+            for _ in range(3):
+                if force:
+                    w.eng.build_neighbors(w.x, species=w.species)      # an exact build invalidates the candidate list ...
+                ms = dict(w.eng.profile(w.x, species=w.species))       # ... so this evaluation rebuilds it
+                acc.append(ms.get("neighbor_build", float("nan")))
+            return float(np.median(acc))
+        reuse, rebuild = nbr_ms(False), nbr_ms(True)
+        rep["neighbour_stage_ms"] = {"reuse_step": reuse, "rebuild_step": rebuild}
+        rep["rebuild_ms"] = rebuild - reuse
+    return rep
 
 
 def stage_replays(w, reps=8):
@@ -424,6 +474,7 @@ def main():
                                       if w.uses_skin else "exact cell-list rebuild every step"),
                    "step": "BAOAB half + neighbour build + GNN forces + BAOAB half, on device",
                    "buffers_regrown_in_timed_run": bool(getattr(w, "timed_status", 0) == 1),
+                   "timed_region": step_report(w, args.steps),
                    "launch": "torch.distributed.run" if os.environ.get("TORCHELASTIC_RUN_ID") else
                              ("self-spawned ranks" if ctx.world > 1 else "single process")},
         "ensemble": {"boxes": ctx.world, "collective_on_step_path": False,
@@ -506,7 +557,7 @@ def main():
         # runs of C2 (c2_bf16: the north star's neighbour-gather figure on the 10k-atom LJ box itself, tolerance restated as
         # for config 5) and the DFT-water configuration, 20 timed steps each
         for name, wname, dt_name in (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c1_batch_f16x3", "c1_batch", "f16x3"),
-                                     ("c3", "c3", "f32"), ("c5", "c5", "f32"),
+                                     ("c2_batch8", "c2_batch8", "f32"), ("c3", "c3", "f32"), ("c5", "c5", "f32"),
                                      ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("c2_bf16", "c2", "bf16"), ("dft", "dft", "f32"),
                                      ("dft_f16x3", "dft", "f16x3"), ("dft_bf16", "dft", "bf16")):
             s = build_workload(wname, ctx, dev, args.skin, dt_name)
@@ -516,7 +567,7 @@ def main():
             rb = roofline_block(s, se, sconv_ms, sconv_n)
             sec[name] = {"workload": s.label, "n_atoms": s.n_atoms, "n_boxes": s.n_boxes, "edges_per_step": se, "dtype": s.dtype_name,
                          "steps": 20, "warmup": 5, "ms_per_step": sdt / 20 * 1e3, "value": s.n_atoms * 20 / sdt,
-                         "unit": "atom-steps/s", "finite": ok,
+                         "unit": "atom-steps/s", "finite": ok, "timed_region": step_report(s, 20),
                          "conv_kernel": {k: rb[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}}
             s.eng.close()
         line["secondary"] = sec

@@ -68,6 +68,7 @@ SYMBOLS = {
     "gamd_timing_enable": (_i32, [_vp, _i32]),
     "gamd_timing_read": (_i32, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "gamd_timing_read_stages": (_i32, [_vp, _vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "gamd_timing_read_steps": (_i32, [_vp, _vp, C.POINTER(C.c_float), _i64, C.POINTER(_i64)]),
 }
 
 _lib = None

@@ -160,6 +160,10 @@ struct gamd_handle {
     std::vector<hipEvent_t> tev;     // pairs (start, stop)
     std::vector<int> tev_kind;       // per pair: 0 = conv-layer edge kernel(s) of layer l, 1 = edge encoder; -(l+1) coded below
     size_t tev_used = 0;
+    // one event at the top of every MD step of an enqueued run (and one behind the last): gamd_timing_read_steps
+    std::vector<hipEvent_t> sev;
+    size_t sev_used = 0;
+    size_t sev_run_begin = 0;        // first event of the gamd_md_run / gamd_md_run_nhc call being enqueued
 };
 
 namespace {
@@ -697,6 +701,16 @@ int clear_devflags(gamd_handle* h) {
     return 0;
 }
 
+// live timing: a HIP event on the launch stream in front of the first kernel of an MD step (and behind the last kernel of
+// the run); consecutive events bracket one step.  Events are created outside the timed region (gamd_timing_enable).
+int step_event(gamd_handle* h, hipStream_t st) {
+    if (!h->timing) return 0;
+    if (h->sev_used == h->sev.size())
+        for (int k = 0; k < 256; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->sev.push_back(e); }
+    HIP_TRY(hipEventRecord(h->sev[h->sev_used++], st));
+    return 0;
+}
+
 // steps [s_begin, n_steps) of the pending MD run; skip_first: the first half of step s_begin has already been done
 int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
     MdPending& p = h->pending;
@@ -705,6 +719,7 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
     // evaluation (k_step_small / k_skin_check): 2 launches less per step; the last B is launched on its own.
     if (p.kind == 0 && h->skin > 0.f) {
         for (long long s = s_begin; s < p.n_steps; ++s) {
+            if ((r = step_event(h, p.st))) return r;
             p.m.step = p.first_step + (unsigned long long)s;
             p.m.step_index = (int)s;
             int do_second = s > s_begin ? 1 : 0;
@@ -731,9 +746,10 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
             p.m.step_index = (int)(p.n_steps - 1);
             if ((r = launch_baoab_second(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
         }
-        return 0;
+        return step_event(h, p.st);
     }
     for (long long s = s_begin; s < p.n_steps; ++s) {
+        if ((r = step_event(h, p.st))) return r;
         const bool first = !(skip_first && s == s_begin);
         const bool last = s + 1 == p.n_steps;
         if (p.kind == 0) {
@@ -749,7 +765,7 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
             if ((r = launch_nhc_second(p.a, p.st))) return fail(-1, "integrator launch failed (%d)", r);
         }
     }
-    return 0;
+    return step_event(h, p.st);
 }
 
 }  // namespace
@@ -916,6 +932,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->sticky_host) (void)hipHostFree(h->sticky_host);
     for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->sev) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }
@@ -1573,8 +1590,36 @@ int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* specie
 
 int32_t gamd_timing_enable(gamd_handle* h, int32_t enable) {
     if (!h) return fail(-22, "null handle");
+    DeviceGuard guard(h->dev);
     h->timing = enable != 0;
     h->tev_used = 0;
+    h->sev_used = 0;
+    if (h->timing) {
+        // a first pool of events HERE, not inside the region that is about to be timed (round-4 review: nothing but the
+        // step's own launches belongs between the two synchronisation points); the pools still grow on demand
+        while (h->tev.size() < 4096) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->tev.push_back(e); h->tev_kind.push_back(0); }
+        while (h->sev.size() < 1024) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->sev.push_back(e); }
+    }
+    return 0;
+}
+
+int32_t gamd_timing_read_steps(gamd_handle* h, void* stream, float* step_ms, int64_t max_steps, int64_t* n_steps) {
+    if (!h || !n_steps || (max_steps > 0 && !step_ms)) return fail(-22, "null argument");
+    DeviceGuard guard(h->dev);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    // events: one in front of every step, one behind the last step of each enqueue_md_steps call.  A run that froze on a
+    // neighbour-buffer overflow and was resumed contributes the frozen steps (cheap: their kernels return at once) and the
+    // resumed ones as separate intervals; the interval that spans the host's regrow is reported like any other step.
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < h->sev_used; ++i) {
+        if (n < max_steps) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, h->sev[i], h->sev[i + 1]));
+            step_ms[n] = t;
+        }
+        ++n;
+    }
+    *n_steps = n;
     return 0;
 }
 

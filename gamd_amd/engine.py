@@ -430,6 +430,14 @@ class GamdForce:
         check(self._lib.gamd_timing_read_stages(self._h, self._stream(), ms, cnt), "gamd_timing_read_stages")
         return {k: (ms[i], cnt[i]) for i, k in enumerate(("conv_edge", "edge_encode", "node_mid"))}
 
+    def timing_read_steps(self, max_steps: int = 1 << 16) -> np.ndarray:
+        """Device milliseconds of every MD step enqueued by md_run / md_run_nhc since timing_enable(True) (one HIP event in
+        front of each step's first kernel, one behind the last); synchronises."""
+        buf = (C.c_float * max_steps)()
+        n = C.c_int64()
+        check(self._lib.gamd_timing_read_steps(self._h, self._stream(), buf, max_steps, C.byref(n)), "gamd_timing_read_steps")
+        return np.ctypeslib.as_array(buf)[:min(n.value, max_steps)].astype(np.float64)
+
     def profile(self, pos: ArrayLike, box=None, species=None):
         """Event-timed single forward: list of (kernel label, ms)."""
         p = self._dev_pos(pos)

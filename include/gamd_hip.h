@@ -275,6 +275,12 @@ int32_t gamd_timing_read(gamd_handle* h, void* stream, double* total_ms, int64_t
  * [2] the node kernel between two conv layers (from the stop event of layer l to the start event of layer l + 1, so it
  * includes the two kernel boundaries around it). */
 int32_t gamd_timing_read_stages(gamd_handle* h, void* stream, double total_ms[3], int64_t n_launches[3]);
+/* While timing is enabled, gamd_md_run / gamd_md_run_nhc also record one HIP event in front of the first kernel of every MD
+ * step (the iteration of the drivers' loop, LJ/test_script/test_langevin.py:95-113) and one behind the last: step_ms[i] =
+ * device time between consecutive events, in enqueue order, since the last gamd_timing_enable.  Writes at most max_steps
+ * values; *n_steps = intervals available.  A step that takes far longer than the median is a candidate rebuild, a regrow
+ * (the interval that spans the host's re-allocation) or a stall: bench.py reports min / p50 / p99 / max. */
+int32_t gamd_timing_read_steps(gamd_handle* h, void* stream, float* step_ms, int64_t max_steps, int64_t* n_steps);
 
 #ifdef __cplusplus
 }

@@ -353,3 +353,24 @@ def test_batch_with_isolated_atoms_at_box_boundaries():
         assert rel_err(one, ref) < TOL
     assert seen_isolated_last == nb
     batch.close(); single.close()
+
+
+def test_three_boxes_with_one_non_cubic_box_argument():
+    """n_boxes == 3 and a box of three numbers (round-4 advisor): [Lx, Ly, Lz] is ONE orthorhombic box for all three graphs —
+    as the constructor box, as forward's default (self.box, stored as [3]) and as an explicit 1-D argument — never three
+    cubic boxes.  The dynamic-box golden's box is [20, 21, 22.5]; every box of the batch reproduces the reference output."""
+    g, cfg, sd = load_golden("dynbox384_seed4")
+    n, rc, box = g["pos"].shape[0], float(g["cutoff"]), g["box"].astype(np.float32)
+    assert box.shape == (3,) and len(set(box.tolist())) == 3
+    pos3 = torch.from_numpy(np.concatenate([g["pos"]] * 3)).float()
+    species = np.tile(g["node_feat"].reshape(-1) != 0, 3)
+    eng = _engine(sd, n, box, rc, nbr_flavour="torch", cfg=cfg, n_boxes=3)
+    for arg in (None, box, np.tile(box, (3, 1))):
+        out = eng.forward(pos3, box=arg, species=species).cpu().numpy()
+        for b in range(3):
+            assert rel_err(out[b * n:(b + 1) * n], g["out_norm"]) < TOL, (b, arg)
+        assert eng.counts()[0] - sum(eng.debug_csr()[1] >= 3 * n) == 3 * g["edge_idx"].shape[1]
+    # per-box cubic edges of a 3-box batch are spelled [3, 1]; they are NOT what [Lx, Ly, Lz] means
+    cubic = eng.forward(pos3, box=box.reshape(3, 1), species=species).cpu().numpy()
+    assert rel_err(cubic[n:2 * n], g["out_norm"]) > 1e-3
+    eng.close()

@@ -45,6 +45,24 @@ def test_default_line_has_the_contract_keys():
     g = r["neighbour_gather"]
     assert g["bound"].startswith("mfma-bound") and 0.0 < g["frac_of_hbm_peak"] < 1.0
     assert d["ensemble"]["boxes"] == 1 and len(d["ensemble"]["per_rank"]) == 1
+    # the record explains its own number: per-step distribution, rebuilds / regrows inside the timed region, cost of a rebuild
+    tr = d["config"]["timed_region"]
+    assert tr["step_ms"]["intervals"] == 6 and tr["step_ms"]["min"] <= tr["step_ms"]["p50"] <= tr["step_ms"]["p99"] <= tr["step_ms"]["max"]
+    assert abs(tr["step_ms"]["mean"] - d["ms_per_step"]) / d["ms_per_step"] < 0.05      # device events vs the host clock
+    assert tr["regrown_in_timed"] is False and 0 <= tr["rebuilds_in_timed"] <= 6
+    assert 0.0 < tr["rebuild_ms"] < 1.0 and tr["neighbour_stage_ms"]["reuse_step"] < tr["neighbour_stage_ms"]["rebuild_step"]
+
+
+def test_headline_steps_are_evenly_paced():
+    """C2, 100 timed steps: no step of the timed region may stand out (p99 / p50 < 1.3; a candidate rebuild costs ~0.1 ms of a
+    3.2 ms step) and the device-event mean agrees with the host clock: a stall inside the region would show in `max`."""
+    d = _run("--no-cpu-baseline", "--no-secondary", steps=100, warmup=20)
+    tr = d["config"]["timed_region"]
+    s = tr["step_ms"]
+    assert s["intervals"] == 100 and s["p99"] / s["p50"] < 1.3, s
+    assert s["max"] / s["p50"] < 1.5, s
+    assert abs(s["mean"] - d["ms_per_step"]) / d["ms_per_step"] < 0.02
+    assert 1 <= tr["rebuilds_in_timed"] <= 10 and tr["regrown_in_timed"] is False and tr["regrown_in_warmup"] is False
 
 
 def test_long_water_run_does_not_outgrow_its_neighbour_buffers():
@@ -198,7 +216,14 @@ def test_secondary_block_kernels_list_and_cpu_baseline_on_c2():
     enc = d["roofline"]["kernels"][0]
     assert enc["bound"] == "mfma" and 0.3 < enc["frac"] < 1.0 and abs(enc["frac"] - enc["achieved"] / 157.3) < 1e-9
     s = d["secondary"]
-    assert set(s) == {"c1", "c1_batch", "c1_batch_f16x3", "c3", "c5", "c5b", "c2_f16x3", "c2_bf16", "dft", "dft_f16x3", "dft_bf16"}
+    assert set(s) == {"c1", "c1_batch", "c1_batch_f16x3", "c2_batch8", "c3", "c5", "c5b", "c2_f16x3", "c2_bf16", "dft", "dft_f16x3",
+                      "dft_bf16"}
+    # config 4's eight rank boxes as one batch on this GPU: per-atom-step cost no worse than the single box
+    assert s["c2_batch8"]["n_boxes"] == 8 and s["c2_batch8"]["n_atoms"] == 80000 and s["c2_batch8"]["value"] > 0.97 * d["value"]
+    for k, v in s.items():
+        tr = v["timed_region"]
+        assert tr["step_ms"]["intervals"] >= 20 and tr["regrown_in_timed"] is False, (k, tr)
+        assert tr["step_ms"]["max"] < 3.0 * tr["step_ms"]["p50"] + 0.3, (k, tr["step_ms"])       # no stall inside a timed region
     assert s["c1_batch_f16x3"]["n_boxes"] == 38 and s["c1_batch_f16x3"]["value"] > 1.5 * s["c1_batch"]["value"]
     assert s["dft_bf16"]["dtype"] == "bf16" and s["dft_bf16"]["conv_kernel"]["kernel"] == "k_conv_edge_bf16_wide<2,2>"
     assert s["dft_f16x3"]["dtype"].startswith("f16x3") and s["dft_f16x3"]["conv_kernel"]["kernel"] == "k_conv_edge_f16x3_wide<2,2>"
