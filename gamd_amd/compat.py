@@ -10,10 +10,13 @@
 
 Physics constants that are module-level in the reference (BOX_SIZE, CUTOFF_RADIUS,
 NUM_OF_ATOMS; LJ/train_network_lj.py:26-29, water/train_network_tip3p.py:24-29) are
-constructor arguments here.
+constructor arguments here; `gamd_amd/dropin/` holds modules NAMED like the reference's
+(`train_network_lj`, `train_network_tip3p`, `train_network_tip4p`, `train_network_real_large`) that carry
+those constants and the reference's constructor signature, so a driver runs with no edit at all.
 """
 from __future__ import annotations
 
+import functools
 from types import SimpleNamespace
 from typing import Optional
 
@@ -59,6 +62,7 @@ class _ModelLevel:
             feat, edge_lst = rest
         elif len(rest) == 3:
             feat, box_lst, cutoff = rest
+            self._owner._size_for(int(pos_lst[0].shape[0]))
             eng = self._owner._get_engine()
             if abs(float(cutoff) - eng.cutoff) > 1e-6 * eng.cutoff:
                 raise ValueError(f"cutoff {cutoff} differs from the one the engine was built with ({eng.cutoff})")
@@ -84,8 +88,10 @@ class _ModelLevel:
         name, lst = ("box_size_lst", rest[1]) if len(rest) == 3 else ("edge_lst", rest[-1])
         if len(lst) != len(pos_lst):
             raise ValueError(f"{name} has {len(lst)} entries for {len(pos_lst)} graphs in pos_lst")
-        n, nb = self._owner.num_atoms, len(pos_lst)
         sizes = [int(p.shape[0]) for p in pos_lst]
+        if len(rest) == 3 and len(set(sizes)) == 1:
+            self._owner._size_for(sizes[0])
+        n, nb = self._owner.num_atoms, len(pos_lst)
         if any(k != n for k in sizes):
             raise ValueError(f"every graph of a batch must have {n} atoms (the wrapper's size), got {sizes}")
         eng = self._owner._get_engine(n_boxes=nb)
@@ -111,12 +117,40 @@ class _ModelLevel:
     forward = __call__
 
 
+class _class_or_instance_method:
+    """Binds (cls, instance-or-None): Lightning's load_from_checkpoint is a classmethod that the drivers call on an
+    instance (`ParticleNetLightning(args).load_from_checkpoint(PATH, args=args)`, LJ/test_script/test_langevin.py:74)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        functools.update_wrapper(self, fn)
+
+    def __get__(self, obj, cls=None):
+        return functools.partial(self.fn, cls if cls is not None else type(obj), obj)
+
+
+# args fields that name a width / depth of the network: a checkpoint of another size is refused, as load_state_dict(strict)
+# refuses it in the reference (size mismatch)
+_ARG_WIDTHS = (("encoding_size", "encoding_size"), ("hidden_dim", "hidden_dim"), ("edge_embedding_dim", "edge_embedding_dim"))
+
+
 class _ForceFieldBase:
+    # build_model of the LJ / TIP wrappers hard-codes 'conv_layer': 4 (LJ/train_network_lj.py:75,
+    # water/train_network_tip3p.py:85; the drop-in modules set _FIXED_CONV_LAYER = 4); only
+    # train_network_real_large.py:80 reads args.conv_layer
+    _CONV_LAYER_FROM_ARGS = False
+    _FIXED_CONV_LAYER = None
+
     def __init__(self, args=None, state_dict=None, *, num_atoms: int, box_size, cutoff: float,
                  bond=None, scaler_ckpt: Optional[str] = None, device: int = 0, edge_dtype: str = "f32",
                  self_loop_mode: str = "dgl07_noop"):
+        # what a fresh instance of the same wrapper needs (load_from_checkpoint returns one)
+        self._ctor_kw = dict(num_atoms=num_atoms, box_size=box_size, cutoff=cutoff, bond=bond, device=device,
+                             edge_dtype=edge_dtype, self_loop_mode=self_loop_mode)
         self.args = args or SimpleNamespace()
-        self.num_atoms, self.box_size, self.cutoff = int(num_atoms), box_size, float(cutoff)
+        # num_atoms None (DFT flavour only): taken from the first call, and re-sized when a later call brings another count
+        self.num_atoms = None if num_atoms is None else int(num_atoms)
+        self.box_size, self.cutoff = box_size, float(cutoff)
         self.bond, self.device_index = bond, device
         self.edge_dtype = edge_dtype                 # "f32" (default) | "f16x3" (fp32-grade split-fp16 GEMMs) | "bf16"
         self.self_loop_mode = self_loop_mode         # what add_self_loop()'s discarded result means (SURVEY.md section 8c)
@@ -132,17 +166,51 @@ class _ForceFieldBase:
             self.load_training_stats(scaler_ckpt)
 
     # -- construction / loading (test_langevin.py:74-77) --------------------------------------
-    def load_from_checkpoint(self, path: str, args=None, allow_pickle: bool = False, **kw):
-        """Instance-style call used by the drivers: ParticleNetLightning(args).load_from_checkpoint(PATH, args=args).
+    @_class_or_instance_method
+    def load_from_checkpoint(cls, self, path: str, args=None, allow_pickle: bool = False, **kw):
+        """pl.LightningModule.load_from_checkpoint as the drivers use it,
+        ``ParticleNetLightning(args).load_from_checkpoint(PATH, args=args)`` (LJ/test_script/test_langevin.py:74): a
+        classmethod (callable on the class or on an instance) that builds a NEW wrapper from ``args`` (+ ``kw``), loads the
+        checkpoint's ``state_dict`` ('pnet_model.' prefix) into it and returns it; the instance it was called on is left
+        alone.  Called on an instance, the new wrapper inherits its system size / box / cutoff / bond / device.
         ``allow_pickle``: see weights.load_checkpoint (restricted unpickler unless opted out)."""
-        self._sd = load_checkpoint(path, allow_pickle=allow_pickle)
+        sd = load_checkpoint(path, allow_pickle=allow_pickle)
+        if self is not None:
+            new = self._respawn(args if args is not None else self.args, **kw)
+            new.training_mean, new.training_var = self.training_mean, self.training_var
+        else:
+            new = cls(args, **kw)
+        new.load_state_dict(sd)
+        return new
+
+    def _respawn(self, args, **kw):
+        return type(self)(args, None, **{**self._ctor_kw, **kw})
+
+    def load_state_dict(self, sd, strict: bool = True):
+        sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        self._check_against_args(sd)
+        self._sd = sd
         self._drop_engines()
         return self
 
-    def load_state_dict(self, sd):
-        self._sd = {k: v.detach().float().cpu() for k, v in sd.items()}
-        self._drop_engines()
-        return self
+    def state_dict(self):
+        return dict(self._sd) if self._sd is not None else {}
+
+    def _check_against_args(self, sd):
+        """The reference builds the network from ``args`` and then loads the checkpoint strictly: a checkpoint of other
+        widths / depth raises there (size mismatch / missing keys).  Same here, for the fields ``args`` carries."""
+        cfg = infer_config(sd)
+        want = {f: getattr(self.args, a) for a, f in _ARG_WIDTHS if hasattr(self.args, a)}
+        if self._CONV_LAYER_FROM_ARGS and hasattr(self.args, "conv_layer"):
+            want["conv_layer"] = int(self.args.conv_layer)
+        elif self._FIXED_CONV_LAYER is not None:
+            want["conv_layer"] = self._FIXED_CONV_LAYER
+        if hasattr(self.args, "use_layer_norm"):
+            want["use_layer_norm"] = bool(self.args.use_layer_norm)
+        bad = {f: (v, getattr(cfg, f)) for f, v in want.items() if getattr(cfg, f) != v}
+        if bad:
+            raise RuntimeError("Error(s) in loading state_dict: size mismatch between args and checkpoint: "
+                               + ", ".join(f"{f}: args {a} vs checkpoint {c}" for f, (a, c) in bad.items()))
 
     def _drop_engines(self):
         for e in self._engines.values():
@@ -164,6 +232,16 @@ class _ForceFieldBase:
 
     def eval(self):
         return self
+
+    def _size_for(self, n: int) -> None:
+        """The dynamic-box model has no fixed atom count in the reference (md_module.get_neighbor searches whatever it is
+        handed, water/train_network_real_large.py:148-162): the engines are (re)built for the count a call brings.  The
+        fixed-box wrappers keep the count they were constructed with (NUM_OF_ATOMS is baked into the reference's jitted
+        neighbour mask, LJ/train_network_lj.py:110-112)."""
+        if self._nbr_flavour != "torch" or n == self.num_atoms:
+            return
+        self._drop_engines()
+        self.num_atoms = int(n)
 
     def _get_engine(self, n_boxes: int = 1) -> GamdForce:
         """n_boxes = 1: the engine behind predict_forces / single-graph model calls; n_boxes = B: the batched engine a
@@ -233,16 +311,20 @@ class ParticleNetLightningDFT(_ForceFieldBase):
     hidden 128 / 5 layers, cutoff ``args.cutoff`` (9.5 bohr), positions and box in bohr, the box handed over per
     call; neighbour semantics of md_module.get_neighbor ('<=' on the norm, no self edges)."""
 
+    _CONV_LAYER_FROM_ARGS = True                     # water/train_network_real_large.py:80
+
     def __init__(self, args=None, state_dict=None, *, num_atoms=258 * 3, box_size=None, cutoff=None, **kw):
         if cutoff is None:
             cutoff = getattr(args, "cutoff", 9.5)
         if box_size is None:                         # only sizes the first neighbour buffers; the real box comes per call
             box_size = 20.0 / 0.529177
+        kw.pop("bond", None)                         # WaterMDDynamicBoxNet is built without a bond graph (:64)
         super().__init__(args, state_dict, num_atoms=num_atoms, box_size=box_size, cutoff=cutoff, **kw)
         self._nbr_flavour = "torch"
         self._skin = 0.0                             # md_module.get_neighbor searches from scratch every call
 
     def predict_forces(self, feat: torch.Tensor, pos: np.ndarray, box_size) -> np.ndarray:
+        self._size_for(int(np.asarray(pos).shape[0]))
         eng = self._get_engine()
         box = np.asarray(box_size, dtype=np.float64).reshape(-1)
         posw = np.mod(np.asarray(pos, dtype=np.float64), box)                 # train_network_real_large.py:150
