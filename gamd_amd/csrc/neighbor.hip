@@ -165,6 +165,23 @@ __global__ void __launch_bounds__(256) k_sort_gather(NbrArgs a) {
     if (c < a.ncell) d_sort_gather(a, c, threadIdx.x & 63);
 }
 
+// Squared minimum-image distance of the neighbour test, op for op what the reference's mask evaluates in fp32:
+//   jax-md flavour  dR = displacement(R_centre, R_neigh) = periodic(R_centre - R_neigh)  (graph_utils.py:53-56 map_neighbor
+//                   over space.periodic's displacement: mod(dR + side/2, side) - side/2), then sum(dR ** 2) (:59);
+//   torch flavour   dist_mat[a, b] = pos[b] - pos[a] with centre = b (md_module.py:65-66, :121), i.e. centre - neighbour too.
+// Centre MINUS neighbour (the rounding of mod(d + L/2, L) - L/2 is not symmetric in d), every product rounded before the
+// adds, (x^2 + y^2) + z^2 in that order (what torch's / XLA's reduction over the last axis of three gives): a pair that sits
+// on the cutoff to fp32 rounding falls on the same side here as in the oracle's restatement, so the edge SETS are equal,
+// not just equal up to near-cutoff pairs.
+__device__ __forceinline__ float gamd_mask_d2(const float4& pc, const float4& pb, const BoxDims& B) {
+#pragma clang fp contract(off)
+    const float rx = gamd_min_image_wrapped(pc.x - pb.x, B.bx, B.hx);
+    const float ry = gamd_min_image_wrapped(pc.y - pb.y, B.by, B.hy);
+    const float rz = gamd_min_image_wrapped(pc.z - pb.z, B.bz, B.hz);
+    const float xx = rx * rx, yy = ry * ry, zz = rz * rz;
+    return (xx + yy) + zz;
+}
+
 // 27-cell sweep shared by the count and the fill pass: one half-wave (32 lanes) per centre atom, lanes
 // test the atoms of a cell in parallel.  visit(ok, b) is called by every lane for every pass; the
 // accepted neighbours of a pass are compacted in lane order with a ballot, so the CSR order is fixed:
@@ -195,11 +212,7 @@ __device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit)
                     bool ok = false;
                     if (b < e) {
                         const float4 pb = a.pos_s[b];
-                        // rel = pos[neigh] - pos[centre], min image (nn_module.py:615-621)
-                        const float rx = gamd_min_image_wrapped(pb.x - pc.x, B.bx, B.hx);
-                        const float ry = gamd_min_image_wrapped(pb.y - pc.y, B.by, B.hy);
-                        const float rz = gamd_min_image_wrapped(pb.z - pc.z, B.bz, B.hz);
-                        const float d2 = (rx * rx + ry * ry) + rz * rz;
+                        const float d2 = gamd_mask_d2(pc, pb, B);
                         if (a.flavour == 0) ok = d2 < a.rc2;                      // graph_utils.py:59, self kept
                         else ok = (sqrtf(d2) <= a.rc) && (b != ctr);              // md_module.py:111
                     }
@@ -645,10 +658,7 @@ __device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPt
         if (b0 + l < e) {
             b = a.cand_col[b0 + l];
             const float4 pb = a.pos_s[b];
-            const float rx = gamd_min_image_wrapped(pb.x - pc.x, B.bx, B.hx);
-            const float ry = gamd_min_image_wrapped(pb.y - pc.y, B.by, B.hy);
-            const float rz = gamd_min_image_wrapped(pb.z - pc.z, B.bz, B.hz);
-            const float d2 = (rx * rx + ry * ry) + rz * rz;
+            const float d2 = gamd_mask_d2(pc, pb, B);
             if (a.flavour == 0) ok = d2 < a.rc2;
             else ok = (sqrtf(d2) <= a.rc) && (b != c);
         }

@@ -48,8 +48,11 @@ def rank_boxes():
 
 @pytest.mark.parametrize("rank", range(RANKS))
 def test_each_ranks_box_matches_the_oracle(rank, rank_boxes):
-    """Rank r's input of `bench.py --gpus 8`: edge set == the oracle's own search (pairs within 1e-4 of the cutoff may
-    flip between two fp32 searches, nothing else), forces == the oracle on its own edge list."""
+    """Rank r's input of `bench.py --gpus 8`: edge set == the oracle's own search, forces == the oracle on its own edge list.
+    The library evaluates the cutoff test op for op as the oracle's restatement does (neighbor.hip: gamd_mask_d2), so the
+    sets are expected to be EQUAL (seed 1237 has a pair 3e-5 from the cutoff that an earlier build put on the other side);
+    should a pair within 1e-4 of the cutoff ever flip again, the set check still bounds it and the forces are then compared
+    on the GPU's list (a network is not continuous in its edge set)."""
     pos, box = rank_boxes[0][rank], rank_boxes[1]
     sd = _sd()
     eng = _engine(sd, N, box, RC, scaler=SHIPPED_SCALERS["lj"])
@@ -61,6 +64,8 @@ def test_each_ranks_box_matches_the_oracle(rank, rank_boxes):
     pairs, dist = edge_set_diff_near_cutoff(got, ref_edges.numpy(), pw.numpy(), box, RC, N)
     assert len(pairs) <= 8 and (len(pairs) == 0 or dist.max() < NEAR_CUTOFF), (rank, len(pairs))
     assert len(np.unique(edge_set(got))) == got.shape[1] and int((got[0] == got[1]).sum()) == N
+    if len(pairs):
+        ref_edges = torch.from_numpy(got).long()
     ref = orc.forward(sd, pw, ref_edges, box).numpy()
     med, p99, worst, cnt = per_atom_err(out, ref)
     print(f"rank {rank} (seed {1234 + rank}): E={got.shape[1]} max-norm {rel_err(out, ref):.2e}; per atom median {med:.2e} "

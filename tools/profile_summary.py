@@ -3,6 +3,9 @@
 
     python tools/profile_summary.py stats <dir>            kernel-trace --stats run -> table of kernels
     python tools/profile_summary.py pmc <dir> [<dir> ...]   --pmc runs -> per-kernel average of every counter
+    python tools/profile_summary.py gather <dir> <n_atoms> <edge dtype>
+        tools/gpu_pmc_gather.sh's passes (<dir>/live.json, trace/, fetch/, write/, tcc/) -> the conv-layer edge kernel's HBM
+        traffic per launch, its L2 hit rate and the neighbour-gather figure in counter bytes (<dir>/gather.json + markdown)
     python tools/profile_summary.py pmcjson <fetch_dir> <write_dir> <kernel substring> <out.json>
         HBM bytes per launch of one kernel (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), stamped with
         the hash of the kernel sources (bench.kernel_source_hash) so that bench.py only reports it for the build it was taken on
@@ -90,11 +93,68 @@ def pmcjson(fetch_dir, write_dir, kernel, out):
     print(json.dumps(rec, indent=1))
 
 
+def gather(d, n_atoms, dtype):
+    n_atoms = int(n_atoms)
+    live = json.load(open(os.path.join(d, "live.json")))[0]
+    E = live["edges"]
+    kern = {"f32": "k_conv_edge<", "bf16": "k_conv_edge_bf16", "f16x3": "k_conv_edge_f16x3"}[dtype]
+    trace_us = None
+    for f in find(os.path.join(d, "trace"), "*kernel_stats.csv"):
+        for r in csv.DictReader(open(f)):
+            if kern in short(r["Name"]):
+                trace_us = float(r["AverageNs"]) / 1e3
+    def avg(sub, cname):
+        acc = counters([os.path.join(d, sub)])
+        for k in acc:
+            if kern in short(k) and cname in acc[k]:
+                v = acc[k][cname]
+                v = v[len(v) // 5:] if len(v) >= 5 else v
+                return sum(v) / len(v)
+        return None
+    fetch_kb, write_kb = avg("fetch", "FETCH_SIZE"), avg("write", "WRITE_SIZE")
+    hit, miss, req = avg("tcc", "TCC_HIT_sum"), avg("tcc", "TCC_MISS_sum"), avg("tcc", "TCC_REQ_sum")
+    e_bytes = {"f32": 512.0, "bf16": 256.0, "f16x3": 512.0}[dtype]
+    alg_gather = E * 1028.0 + n_atoms * 1024.0                     # SURVEY.md 8d, per layer: idx + hn[src] + S[src] rows, D rows, agg
+    mandatory = E * (e_bytes + 4.0 + 4.0 + 36.0) + n_atoms * 3 * 512.0   # e stream + col / erow + pieces; each node-table row ONCE
+    t_live = live["conv_ms_per_launch"] * 1e-3
+    hbm = (2.0 * fetch_kb + write_kb) * 1024.0 if fetch_kb is not None and write_kb is not None else None
+    rec = {"n_atoms": n_atoms, "edges": E, "edge_dtype": dtype, "kernel": kern.rstrip("<"),
+           "conv_ms_per_launch_live": live["conv_ms_per_launch"], "conv_us_per_launch_rocprofv3": trace_us,
+           "ms_per_step": live["ms_per_step"], "atom_steps_per_s": live["atom_steps_per_s"],
+           "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_HIT": hit, "TCC_MISS": miss, "TCC_REQ": req,
+           "l2_hit_rate": hit / (hit + miss) if hit is not None and miss else None,
+           "hbm_bytes_per_launch": hbm,
+           "hbm_GB_per_s": hbm / t_live / 1e9 if hbm else None,
+           "hbm_frac_of_8TBs": hbm / t_live / 8e12 if hbm else None,
+           "algorithmic_gather_bytes_per_launch": alg_gather,
+           "algorithmic_gather_frac_of_8TBs": alg_gather / t_live / 8e12,
+           "mandatory_bytes_per_launch": mandatory,
+           "hbm_over_mandatory": hbm / mandatory if hbm else None,
+           "correction": "FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md section HBM); WRITE_SIZE as "
+                         "reported; Infinity-Cache hits are counted by both (fabric-side request counters)",
+           "node_tables_MB": n_atoms * 3 * 512.0 / 1e6}
+    json.dump(rec, open(os.path.join(d, "gather.json"), "w"), indent=1)
+    g = lambda v, f="%.4g": "n/a" if v is None else f % v
+    print(f"### {n_atoms} atoms, {E} edges, edge dtype {dtype}: `{rec['kernel']}`\n")
+    print("| quantity | value |\n|---|---|")
+    print(f"| step | {live['ms_per_step']:.3f} ms, {live['atom_steps_per_s']:.3e} atom-steps/s |")
+    print(f"| conv-layer edge kernel | {live['conv_ms_per_launch'] * 1e3:.1f} us per launch (live HIP events), {g(trace_us, '%.1f')} us (rocprofv3 trace) |")
+    print(f"| node tables hn + S + D | {rec['node_tables_MB']:.0f} MB (L2 8 x 4 MiB, Infinity Cache 256 MiB) |")
+    print(f"| FETCH_SIZE x 2 | {g(None if fetch_kb is None else 2 * fetch_kb * 1024 / 1e6)} MB per launch |")
+    print(f"| WRITE_SIZE | {g(None if write_kb is None else write_kb * 1024 / 1e6)} MB per launch |")
+    print(f"| memory-side traffic | {g(None if hbm is None else hbm / 1e6)} MB per launch = {g(rec['hbm_GB_per_s'])} GB/s = **{g(rec['hbm_frac_of_8TBs'], '%.3f')}** of 8 TB/s |")
+    print(f"| mandatory bytes (e stream, indices, pieces, every node-table row once) | {mandatory / 1e6:.4g} MB per launch; traffic / mandatory = {g(rec['hbm_over_mandatory'], '%.2f')} |")
+    print(f"| L2 (TCC) | hit {g(hit)} miss {g(miss)} req {g(req)} per launch: hit rate {g(rec['l2_hit_rate'], '%.3f')} |")
+    print(f"| SURVEY 8d gather figure (algorithmic: E x 1 028 B + N x 1 024 B) | {alg_gather / 1e6:.4g} MB per launch = {alg_gather / t_live / 1e9:.4g} GB/s = {rec['algorithmic_gather_frac_of_8TBs']:.3f} of 8 TB/s |")
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
     if cmd == "stats":
         stats(sys.argv[2])
     elif cmd == "pmc":
         pmc(sys.argv[2:])
+    elif cmd == "gather":
+        gather(*sys.argv[2:5])
     elif cmd == "pmcjson":
         pmcjson(*sys.argv[2:6])

@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""Step time of the LJ workload (rho* = 0.5, cutoff 3 sigma, fp32, skin reuse, BAOAB on device) over the system size:
-python tools/size_scan.py [N ...].  GPU box only; the C2 line of bench.py is the N = 10 000 point."""
+"""Step time of the LJ workload (rho* = 0.5, cutoff 3 sigma, skin reuse, BAOAB on device) over the system size:
+
+    python tools/size_scan.py [N ...] [--edge-dtype f32|bf16|f16x3] [--steps K] [--json out.json]
+
+GPU box only; the C2 line of bench.py is the N = 10 000 point.  With --steps K it times exactly K steps after 2 warm-up
+steps (the form tools/gpu_pmc_gather.sh profiles under rocprofv3: at 10^5 - 10^6 atoms the node tables the conv-layer edge
+kernel gathers from — hn, S, D: 512 B per atom each — no longer fit the 8 x 4 MiB L2s / the 256 MiB Infinity Cache)."""
+import argparse
+import json
 import os
 import sys
 import time
@@ -14,27 +21,45 @@ from gamd_amd import workloads                                           # noqa:
 from gamd_amd.engine import GamdForce                                    # noqa: E402
 from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS   # noqa: E402
 
-sizes = [int(a) for a in sys.argv[1:]] or [1000, 2000, 5000, 10000, 20000, 50000, 100000, 200000]
+ap = argparse.ArgumentParser()
+ap.add_argument("sizes", nargs="*", type=int)
+ap.add_argument("--edge-dtype", default="f32", choices=["f32", "bf16", "f16x3"])
+ap.add_argument("--steps", type=int, default=0)
+ap.add_argument("--json", default="")
+args = ap.parse_args()
+sizes = args.sizes or [1000, 2000, 5000, 10000, 20000, 50000, 100000, 200000]
 sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
 rc = 3.0 * workloads.LJ_SIGMA
-print("| atoms | edges | ms / step | atom-steps/s | GB device memory |")
-print("|---|---|---|---|---|")
+rows = []
+print(f"edge dtype {args.edge_dtype}\n")
+print("| atoms | edges | ms / step | atom-steps/s | conv kernel ms / launch | GB device memory |")
+print("|---|---|---|---|---|---|")
 for n in sizes:
     pos, box = workloads.lj_box(n)
-    eng = GamdForce(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=rc / 6)
+    eng = GamdForce(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=rc / 6, edge_dtype=args.edge_dtype)
     x = torch.from_numpy(pos).float().cuda()
     v = torch.from_numpy(workloads.maxwell_boltzmann(n, temperature_k=100.0, seed=1)).float().cuda()
     f = eng.forward(x, denormalize=True).clone()
-    steps = 100 if n <= 20000 else 30
-    eng.md_run(x, v, f, 10, temperature_k=100.0)
+    steps = args.steps or (100 if n <= 20000 else 30)
+    warm = 2 if args.steps else 10
+    eng.md_run(x, v, f, warm, temperature_k=100.0)
     torch.cuda.synchronize()
+    eng.timing_enable(True)
     t0 = time.perf_counter()
-    eng.md_run(x, v, f, steps, temperature_k=100.0, first_step=10)
+    eng.md_run(x, v, f, steps, temperature_k=100.0, first_step=warm)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    conv_ms, conv_n = eng.timing_read()
+    eng.timing_enable(False)
     free, total = torch.cuda.mem_get_info()
-    print(f"| {n} | {eng.counts()[0]} | {dt * 1e3:.3f} | {n / dt:.3e} | {(total - free) / 2**30:.2f} |")
+    e = eng.counts()[0]
+    print(f"| {n} | {e} | {dt * 1e3:.3f} | {n / dt:.3e} | {conv_ms / max(conv_n, 1):.4f} | {(total - free) / 2**30:.2f} |")
+    rows.append({"atoms": n, "edges": e, "ms_per_step": dt * 1e3, "atom_steps_per_s": n / dt,
+                 "conv_ms_per_launch": conv_ms / max(conv_n, 1), "conv_launches": conv_n, "edge_dtype": args.edge_dtype,
+                 "device_GB": (total - free) / 2 ** 30})
     assert torch.isfinite(x).all() and eng.last_status in (0, 1)
     eng.close()
     del eng, x, v, f
     torch.cuda.empty_cache()
+if args.json:
+    json.dump(rows, open(args.json, "w"), indent=1)
