@@ -155,7 +155,7 @@ __device__ __forceinline__ void load_e_tile(const float* __restrict__ e_frag, in
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = ef[(t * 4 + q) * 64 + lane];
+            const f32x4 v = gamd_load_stream(&ef[(t * 4 + q) * 64 + lane]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = v[j];
         }

@@ -145,7 +145,8 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) P[t][u] = *reinterpret_cast<const bf16x8*>(tb + (size_t)lane16 + (t * 2 + u) * 1024);
+            for (int u = 0; u < 2; ++u)
+                P[t][u] = __builtin_bit_cast(bf16x8, gamd_load_stream(reinterpret_cast<const f32x4*>(tb + (size_t)lane16 + (t * 2 + u) * 1024)));
     };
 #if BF16_STAGGER > 0
     // de-phase the two waves of a SIMD (waves w and w + 4): their MFMA phases and their VALU phases then interleave instead

@@ -727,15 +727,22 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
             if (p.m.com.enabled) {
                 // COM motion removal sits between the B of step s-1 and the first half of step s and needs a sum over all
                 // atoms: the B is launched on its own, then the momentum sums; only the first half rides in the neighbour kernel
-                if (do_second) {
+                if (do_second && do_first) {                      // B of step s - 1 + the momentum sums of step s: one launch
                     MdArgs prev = p.m;
                     prev.step_index = (int)(s - 1);
-                    if ((r = launch_baoab_second(prev, p.st))) return fail(-1, "integrator launch failed (%d)", r);
+                    if ((r = launch_baoab_second_com(prev, p.st))) return fail(-1, "integrator launch failed (%d)", r);
                     do_second = 0;
+                } else {
+                    if (do_second) {
+                        MdArgs prev = p.m;
+                        prev.step_index = (int)(s - 1);
+                        if ((r = launch_baoab_second(prev, p.st))) return fail(-1, "integrator launch failed (%d)", r);
+                        do_second = 0;
+                    }
+                    if (do_first && (r = launch_com_partial(p.m.com, p.m.v, p.m.species, p.m.inv_mass, p.m.inv_mass_h, p.m.n, p.m.bx,
+                                                            p.m.devflags, p.st)))
+                        return fail(-1, "integrator launch failed (%d)", r);
                 }
-                if (do_first && (r = launch_com_partial(p.m.com, p.m.v, p.m.species, p.m.inv_mass, p.m.inv_mass_h, p.m.n, p.m.bx,
-                                                        p.m.devflags, p.st)))
-                    return fail(-1, "integrator launch failed (%d)", r);
             }
             const MdFuse fuse{&p.m, do_second, do_first};
             if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, &fuse,

@@ -152,6 +152,19 @@ __device__ __forceinline__ float gamd_min_image_wrapped(float d, float L, float 
     return t - halfL;
 }
 
+// The edge embeddings are a STREAM: every conv-layer launch reads each e tile exactly once (256 - 512 B per edge, 15 - 30 KB per
+// atom) next to gathers of node-table rows (hn, S: 1 KB per atom) that are re-used by the ~60 edges of each neighbour.  Loaded
+// with the non-temporal hint (global_load ... nt) the stream does not push the rows out of the XCD's 4 MiB L2: measured where
+// the tables no longer fit (10^5 - 10^6 atoms, profiles/r05_gather_hbm.md); at the BASELINE sizes everything is L2-resident
+// either way.  -DGAMD_E_TEMPORAL builds the plain loads for the A/B.
+__device__ __forceinline__ f32x4 gamd_load_stream(const f32x4* p) {
+#ifdef GAMD_E_TEMPORAL
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+
 // Message of one edge folded into the running sum of its partial-sum piece (nn_module.py:142, u_mul_e -> sum): a single fused
 // multiply-add, i.e. hn[src] * e_emb is not rounded before it is added (the reference multiplies and adds separately; the
 // two differ by at most half an ulp of the product).  Every fp32 conv-layer edge kernel uses this form, so they stay

@@ -7,7 +7,11 @@
 
 enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD = 4, CNT_NCAND = 5,
        CNT_CAND_MAX = 6,      // fixed-stride candidate rows: the longest row of the rebuild of this call
-       CNT_COUNT = 8 };
+       // "last workgroup done" tickets of the skin path's first two kernels (neighbor.hip: last_workgroup_done): the
+       // workgroup that arrives last continues with the single-workgroup phase that used to be a launch of its own
+       CNT_TICKET_CHECK = 8,  // k_skin_check  -> cell-list phases of a candidate rebuild
+       CNT_TICKET_COUNT = 9,  // k_filter_count -> row scan (row_ptr, piece numbering, edge / tile counters)
+       CNT_COUNT = 16 };
 // host-mapped, never cleared by the per-call memset: overflow must survive later steps of an enqueued MD run
 enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, STICKY_NCAND = 3,
        STICKY_NONFINITE = 4,   // the decoder produced a non-finite force component (NaN / inf positions, or an operand
@@ -119,8 +123,9 @@ struct NbrArgs {
     int use_small;         // the host's choice (gamd_api.hip: use_small, n <= 1024): k_step_small + k_filter_fill_small, CSR
                            // candidate rows.  Explicit, not inferred from cand_stride == 0 (an undersized candidate buffer must
                            // surface as an overflow on the grid-wide path, never send n > 1024 atoms into the one-workgroup kernel)
-    int cells_one_wg;      // candidate rebuild: the four cell-list phases in one single-workgroup launch (rebuilds are rare: one
-                           // gated launch per reuse step instead of four) or as four grid-wide kernels (rebuilds are frequent)
+    int cells_one_wg;      // candidate rebuild: the four cell-list phases by ONE workgroup — the last workgroup of k_skin_check to
+                           // finish, so a reuse step pays no launch for them (rebuilds are rare) — or as four gated grid-wide
+                           // kernels (rebuilds are frequent, or more than 16 384 atoms)
     float rc_build, rc2_build;   // rc + skin
 };
 struct MdArgs;
@@ -321,6 +326,8 @@ struct MdArgs {
 };
 int launch_baoab_first(const MdArgs& a, hipStream_t st);    // B A O A  (hack_integrator.py:141-165)
 int launch_baoab_second(const MdArgs& a, hipStream_t st);   // B        (hack_integrator.py:175-178)
+// B of the step a.step_index AND the per-block momentum sums (a.com) the NEXT step's CMMotionRemover needs, in one launch
+int launch_baoab_second_com(const MdArgs& a, hipStream_t st);
 
 // Nose-Hoover chain of the reference drivers (hack_integrator.py:182-330 first half, :334-493 second half;
 // one chain state shared by both halves, as copy_state_from_integrator does every step)

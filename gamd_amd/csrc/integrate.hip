@@ -84,6 +84,53 @@ __global__ void __launch_bounds__(256) k_com_partial(MdCom c, const float* __res
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// B of step s - 1 and the momentum sums of step s's CMMotionRemover in ONE launch (skin mode with remove_cm_motion: the B has
+// to be complete for every atom before the sums, and the sums before the first half that rides in the neighbour kernel — but
+// B and the sums themselves are per atom / per molecule, so one grid-stride pass does both).  Same grid, same partial layout
+// and same summation tree as k_com_partial: the sums have the bits the two launches gave.
+__global__ void __launch_bounds__(256) k_baoab_second_com(MdArgs a) {
+    GAMD_MD_GATE(1);                                        // a.step_index is the step whose second half this is
+    __shared__ double red[4][4];
+    const MdCom& c = a.com;
+    const int n = a.n, npb = a.bx.n_boxes > 1 ? a.bx.n_per_box : n, a0 = blockIdx.y * npb, a1 = a0 + npb;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    if (a.use_rigid) {
+        // k_com_partial walks atoms i = a0 + t, a0 + t + T, ... (T = threads of the box's blocks); a thread of this kernel must
+        // own whole molecules, so it takes molecule q = t, t + T, ... and adds its three atoms: another assignment of atoms
+        // to threads, hence other bits in the last place of the sums than two launches give — both are deterministic
+        for (int q = a0 / 3 + blockIdx.x * blockDim.x + threadIdx.x; 3 * q < a1; q += gridDim.x * blockDim.x) {
+            d_baoab_second_mol(a, q);
+            const float ms[3] = {a.rigid.m_o, a.rigid.m_h, a.rigid.m_h};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = 3 * q + k;
+                const double m = (double)ms[k];
+                s[0] += m * (double)a.v[3 * i]; s[1] += m * (double)a.v[3 * i + 1]; s[2] += m * (double)a.v[3 * i + 2]; s[3] += m;
+            }
+        }
+    } else {
+        for (int i = a0 + blockIdx.x * blockDim.x + threadIdx.x; i < a1; i += gridDim.x * blockDim.x) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) d_baoab_second_dof(a, 3 * i + d);
+            const double m = 1.0 / (double)atom_inv_mass(a.species, a.inv_mass, a.inv_mass_h, i);
+            s[0] += m * (double)a.v[3 * i]; s[1] += m * (double)a.v[3 * i + 1]; s[2] += m * (double)a.v[3 * i + 2]; s[3] += m;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s[k] += __shfl_down(s[k], d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        c.partial[((size_t)blockIdx.y * c.blocks + blockIdx.x) * 4 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // ---- Nose-Hoover chain -------------------------------------------------------------------------
 // sum of m v^2 (kJ/mol: v converted to nm/ps) per block, optionally after the half kick of the second half
 // (and, for rigid water, the velocity constraint that follows it: hack_integrator.py:427-428)
@@ -272,6 +319,13 @@ int launch_baoab_first(const MdArgs& a, hipStream_t st) {
     }
     if (a.use_rigid) hipLaunchKernelGGL(k_baoab_first_rigid, dim3((a.n / 3 + 255) / 256), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_baoab_first, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_baoab_second_com(const MdArgs& a, hipStream_t st) {
+    const int nb = a.bx.n_boxes > 1 ? a.bx.n_boxes : 1;
+    hipLaunchKernelGGL(k_baoab_second_com, dim3(a.com.blocks, nb), dim3(256), 0, st, a);
     GAMD_CHECK_LAUNCH();
     return 0;
 }

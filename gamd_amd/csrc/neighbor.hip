@@ -186,8 +186,9 @@ __device__ __forceinline__ float gamd_mask_d2(const float4& pc, const float4& pb
 // test the atoms of a cell in parallel.  visit(ok, b) is called by every lane for every pass; the
 // accepted neighbours of a pass are compacted in lane order with a ballot, so the CSR order is fixed:
 // cells in (dx,dy,dz) order, atoms by ascending original id inside a cell.
+// visit(valid, d2, b): lane's candidate b of this pass (valid: the pass has an atom for this lane) and its squared distance
 template <typename V>
-__device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit) {
+__device__ __forceinline__ void sweep_d2(const NbrArgs& a, int ctr, int l, V visit) {
     const float4 pc = a.pos_s[ctr];
     const int bi = box_id(a, ctr);
     const BoxDims B = box_dims(a, bi);
@@ -209,18 +210,22 @@ __device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit)
                 const int s = a.cell_start[c], e = a.cell_start[c + 1];
                 for (int b0 = s; b0 < e; b0 += 32) {
                     const int b = b0 + l;
-                    bool ok = false;
-                    if (b < e) {
-                        const float4 pb = a.pos_s[b];
-                        const float d2 = gamd_mask_d2(pc, pb, B);
-                        if (a.flavour == 0) ok = d2 < a.rc2;                      // graph_utils.py:59, self kept
-                        else ok = (sqrtf(d2) <= a.rc) && (b != ctr);              // md_module.py:111
-                    }
-                    visit(ok, b);
+                    float d2 = 0.f;
+                    if (b < e) d2 = gamd_mask_d2(pc, a.pos_s[b], B);
+                    visit(b < e, d2, b);
                 }
             }
         }
     }
+}
+// the cutoff test of the two flavours on a squared distance
+__device__ __forceinline__ bool in_range(int flavour, float d2, float rc, float rc2, bool is_self) {
+    return flavour == 0 ? d2 < rc2                                   // graph_utils.py:59 (strict, self pair kept)
+                        : (sqrtf(d2) <= rc) && !is_self;             // md_module.py:111
+}
+template <typename V>
+__device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit) {
+    sweep_d2(a, ctr, l, [&](bool valid, float d2, int b) { visit(valid && in_range(a.flavour, d2, a.rc, a.rc2, b == ctr), b); });
 }
 
 // my half-wave's 32-bit slice of a 64-lane ballot
@@ -503,6 +508,49 @@ __global__ void k_chunk_meta(NbrArgs a) {
 }
 
 // ---- Verlet-skin reuse ----------------------------------------------------------------------------
+// "Last workgroup done": every workgroup of the grid calls this once, behind its last store that the continuation reads.  It
+// returns true in exactly one workgroup — the one whose ticket is the last — and there every other workgroup's stores are
+// visible (release fence + device-scope ticket in each, acquire fence in the last one).  The single-workgroup phase that
+// follows used to be a kernel launch of its own (~4 us of stream time plus the boundary) that returned at once on most steps.
+// No workgroup waits for another, so there is nothing to deadlock and nothing like the device-wide barriers that made the
+// cooperative one-launch neighbour stage slower than its launches.
+__device__ __forceinline__ bool last_workgroup_done(int* ticket) {
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return false;
+    __threadfence();
+    return true;
+}
+
+// argument block of the candidate pass (rc + skin, candidate arrays, no self loops: the exact filter appends them)
+__device__ __forceinline__ NbrArgs cand_args(const NbrArgs& a) {
+    NbrArgs c = a;
+    c.cand_pass = 1;
+    c.rc = a.rc_build; c.rc2 = a.rc2_build;
+    c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
+    c.self_loop = 0;
+    c.gate = nullptr;
+    return c;
+}
+
+// bin | scan | fill | sort + gather of a candidate rebuild by ONE 1024-thread workgroup (the phases of k_step_small's rebuild
+// with loops over the atoms / cells); the cell counters are zero on entry (the previous rebuild's k_filter_count left them so)
+__device__ void d_cells_one_wg(const NbrArgs& c) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < c.n; i += 1024) d_bin(c, i);                      // also stores ref_pos
+    __syncthreads();
+    block_exclusive_scan(c.ncell, [&](int i) { return c.cell_cnt[i]; }, c.cell_start);
+    __syncthreads();
+    for (int i = tid; i < c.n; i += 1024) d_fill_cells(c, i);
+    __syncthreads();
+    for (int k = tid >> 6; k < c.ncell; k += 16) d_sort_gather(c, k, tid & 63);
+}
+
 // Every call: wrap the positions and raise the rebuild flag if any atom has moved more than skin/2 since the
 // candidate list was built (or the host forces it).  jax-md does the same test in update_neighbor_lst
 // (graph_utils.py:36-44) with dr_threshold = cutoff/6.
@@ -529,8 +577,10 @@ __device__ __forceinline__ bool d_skin_check(const NbrArgs& a, int i) {
 }
 
 // do_second / do_first: the B of the previous MD step and the B A O A of this one for atom i first (plain BAOAB, MdFuse) —
-// per-atom work in front of a per-atom check: two launches less per step
-__global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) {
+// per-atom work in front of a per-atom check: two launches less per step.  cells_one_wg (up to 16 384 atoms): the workgroup
+// that finishes last looks at the flag all of them have contributed to and, on the one step in 20-100 that needs it, runs the
+// four cell-list phases of the candidate rebuild itself — a reuse step no longer pays a launch that returns at once.
+__global__ void __launch_bounds__(1024) k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (a.counters_next && i < CNT_COUNT) a.counters_next[i] = 0;      // ping-pong counter blocks: no memset node
     if (do_second | do_first) {
@@ -550,13 +600,17 @@ __global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) 
             if (do_first) d_baoab_first_atom(md, i);
         }
     }
+    bool moved = false;
     if ((do_second | do_first) && md.use_rigid) {          // the thread that moved the molecule checks its three atoms
-        for (int k = 0; k < 3 && 3 * i + k < a.n; ++k)
-            if (d_skin_check(a, 3 * i + k)) a.counters[CNT_REBUILD] = 1;
-        return;
+        for (int k = 0; k < 3 && 3 * i + k < a.n; ++k) moved |= d_skin_check(a, 3 * i + k);
+    } else if (i < a.n) {
+        moved = d_skin_check(a, i);
     }
-    if (i >= a.n) return;
-    if (d_skin_check(a, i)) a.counters[CNT_REBUILD] = 1;
+    if (moved) a.counters[CNT_REBUILD] = 1;
+    if (!a.cells_one_wg) return;                           // grid-wide rebuild kernels follow, gated on the flag
+    if (!last_workgroup_done(a.counters + CNT_TICKET_CHECK)) return;
+    if (((volatile int*)a.counters)[CNT_REBUILD] == 0) return;
+    d_cells_one_wg(cand_args(a));
 }
 
 // ---- small systems (n <= 1024), Verlet-skin mode: everything in front of the exact filter in ONE workgroup ------------
@@ -597,11 +651,7 @@ __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int d
     if (!__syncthreads_or(moved ? 1 : 0)) return;
     if (tid == 0) a.counters[CNT_REBUILD] = 1;
     // candidate pass: rc + skin, candidate arrays, no self loops (the exact filter appends them)
-    NbrArgs c = a;
-    c.cand_pass = 1;
-    c.rc = a.rc_build; c.rc2 = a.rc2_build;
-    c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
-    c.self_loop = 0;
+    NbrArgs c = cand_args(a);
     for (int k = tid; k < c.ncell; k += 1024) { c.cell_cnt[k] = 0; c.cell_fill[k] = 0; }
     __syncthreads();
     if (tid < c.n) d_bin(c, tid);                           // also stores ref_pos
@@ -680,19 +730,6 @@ __device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPt
 
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
-    if (!FILL && a.cand_stride > 0 && blockIdx.x == 0 && threadIdx.x == 0 && a.counters[CNT_REBUILD]) {
-        // fixed-stride candidate rows were rebuilt in this call (k_cand_fill): publish its size; a row longer than the stride
-        // is an overflow (the list is truncated: freeze, the host regrows to 1.25 x longest row x n and resumes)
-        const int longest = a.counters[CNT_CAND_MAX];
-        a.sticky[STICKY_NCAND] = a.counters[CNT_NCAND];
-        a.sticky[STICKY_REBUILDS] += 1;
-        if (longest > a.cand_stride) {
-            const long long need = (long long)longest * a.n;
-            a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
-            a.sticky[STICKY_CAND_OVERFLOW] = 1;
-            a.devflags[DEVFLAG_FROZEN] = 1;
-        }
-    }
     d_filter<FILL>(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 5, threadIdx.x & 31, a.row_ptr);
     if (FILL && a.cand_stride > 0) {
         // Chunk metadata (first piece id, mask of the edges that close a destination segment) of the 16-edge chunks that START
@@ -727,55 +764,68 @@ __global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
     }
 }
 
-// ---- candidate rebuild for n > 1024 in two gated launches ----------------------------------------------------------
-// k_cells_one_wg: bin | scan | fill | sort + gather in ONE 1024-thread workgroup (the phases of k_step_small's rebuild with
-// loops over the atoms / cells; up to 16 384 atoms, the four-kernel sequence above that).  It runs once in 50-100 steps;
-// what counts is that a reuse step pays for two gated launches instead of seven.
-__global__ void __launch_bounds__(1024) k_cells_one_wg(NbrArgs c) {
-    if (c.gate && *c.gate == 0) return;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < c.n; i += 1024) d_bin(c, i);                      // cell counters are zero on entry (k_cand_fill)
-    __syncthreads();
-    block_exclusive_scan(c.ncell, [&](int i) { return c.cell_cnt[i]; }, c.cell_start);
-    __syncthreads();
-    for (int i = tid; i < c.n; i += 1024) d_fill_cells(c, i);
-    __syncthreads();
-    for (int k = tid >> 6; k < c.ncell; k += 16) d_sort_gather(c, k, tid & 63);
-}
-
-// k_cand_fill: one half-wave per centre atom sweeps its 27 cells once and writes the accepted neighbours straight into the
-// atom's fixed-width row; the row length, the total and the longest row go to cand_deg / counters.  Leaves the cell
-// counters zero for the next rebuild.
-__global__ void __launch_bounds__(256) k_cand_fill(NbrArgs c) {
-    if (c.gate && *c.gate == 0) return;
+// ---- count pass of the exact filter for n > 1024, carrying the candidate fill and the row scan ---------------------------
+// One half-wave per centre atom, 32 atoms per 1024-thread workgroup.
+//   reuse step    the exact cutoff on the atom's fixed-width candidate row -> deg
+//   rebuild step  (the flag k_skin_check raised; the cells are rebuilt) ONE sweep of the 27 cells computes every squared
+//                 distance once and uses it twice: < rc + skin -> the atom's new candidate row (what k_cand_fill did in a
+//                 launch of its own), < rc -> deg.  Row length, total and longest row go to cand_deg / counters; the cell
+//                 counters are left zero for the next rebuild.
+// The workgroup that finishes last then runs the row scan (row_ptr, the numbering of the partial-sum pieces, E / pieces /
+// tiles / overflow) that used to be the k_scan_deg launch behind this kernel.
+__global__ void __launch_bounds__(1024) k_filter_count(NbrArgs a) {
     const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
-    const bool live = ctr < c.n;
-    const int cc = live ? ctr : c.n - 1;
-    const long long row0 = (long long)cc * c.cand_stride;
-    int w = 0;
-    sweep(c, cc, l, [&](bool ok, int b) {
-        const unsigned m = half_ballot(ok);
-        if (ok && live) {
-            const int at = w + __popc(m & ((1u << l) - 1u));
-            if (at < c.cand_stride) c.cand_col[row0 + at] = b;
+    const bool rebuild = a.counters[CNT_REBUILD] != 0;
+    if (rebuild) {
+        const bool live = ctr < a.n;
+        const int cc = live ? ctr : a.n - 1;
+        const long long row0 = (long long)cc * a.cand_stride;
+        int w = 0, cnt = 0;
+        sweep_d2(a, cc, l, [&](bool valid, float d2, int b) {
+            const bool cand = valid && in_range(a.flavour, d2, a.rc_build, a.rc2_build, b == cc);
+            const bool edge = valid && in_range(a.flavour, d2, a.rc, a.rc2, b == cc);
+            const unsigned m = half_ballot(cand);
+            if (cand && live) {
+                const int at = w + __popc(m & ((1u << l) - 1u));
+                if (at < a.cand_stride) a.cand_col[row0 + at] = b;
+            }
+            w += __popc(m);
+            cnt += __popc(half_ballot(edge));
+        });
+        // total and longest row: one pair of global atomics per workgroup, not per atom (same-address atomics serialise)
+        __shared__ int s_tot, s_max;
+        if (threadIdx.x == 0) { s_tot = 0; s_max = 0; }
+        __syncthreads();
+        if (live && l == 0) {
+            a.cand_deg[ctr] = w;
+            a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
+            atomicAdd(&s_tot, w < a.cand_stride ? w : a.cand_stride);
+            atomicMax(&s_max, w);
         }
-        w += __popc(m);
-    });
-    // total and longest row: one pair of global atomics per workgroup, not per atom (same-address atomics serialise)
-    __shared__ int s_tot, s_max;
-    if (threadIdx.x == 0) { s_tot = 0; s_max = 0; }
-    __syncthreads();
-    if (live && l == 0) {
-        c.cand_deg[ctr] = w;
-        atomicAdd(&s_tot, w < c.cand_stride ? w : c.cand_stride);
-        atomicMax(&s_max, w);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&a.counters[CNT_NCAND], s_tot);
+            atomicMax(&a.counters[CNT_CAND_MAX], s_max);
+        }
+        for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.ncell; k += gridDim.x * blockDim.x) { a.cell_cnt[k] = 0; a.cell_fill[k] = 0; }
+    } else {
+        d_filter<false>(a, ctr, l, a.row_ptr);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&c.counters[CNT_NCAND], s_tot);
-        atomicMax(&c.counters[CNT_CAND_MAX], s_max);
+    if (!last_workgroup_done(a.counters + CNT_TICKET_COUNT)) return;
+    if (rebuild && threadIdx.x == 0) {
+        // the candidate rows were rebuilt in this call: publish their size; a row longer than the stride is an overflow (the
+        // list is truncated: freeze, the host regrows to 1.25 x longest row x n and resumes)
+        const int longest = ((volatile int*)a.counters)[CNT_CAND_MAX];
+        a.sticky[STICKY_NCAND] = ((volatile int*)a.counters)[CNT_NCAND];
+        a.sticky[STICKY_REBUILDS] += 1;
+        if (longest > a.cand_stride) {
+            const long long need = (long long)longest * a.n;
+            a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
+            a.sticky[STICKY_CAND_OVERFLOW] = 1;
+            a.devflags[DEVFLAG_FROZEN] = 1;
+        }
     }
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < c.ncell; k += gridDim.x * blockDim.x) { c.cell_cnt[k] = 0; c.cell_fill[k] = 0; }
+    d_scan_deg(a);
 }
 
 // Small systems (n <= 1024): exact-filter fill, the scan of the degrees and the chunk metadata in ONE launch.  Every
@@ -974,47 +1024,37 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
         hipLaunchKernelGGL(k_filter_fill_small, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
         return 0;
     }
-    // counters: ping-pong blocks (k_skin_check clears the other one) or one memset; the cell counters are left zero by k_fill
+    // counters: ping-pong blocks (k_skin_check clears the other one) or one memset; the cell counters are left zero by the
+    // rebuild's last kernel.  Three launches per reuse step: check (+ integrator halves) | count (+ row scan) | fill.
     if (!a.counters_next) { e = hipMemsetAsync(a.counters, 0, sizeof(int) * CNT_COUNT, st); if (e) return (int)e; }
+    NbrArgs k = a;
+    k.cells_one_wg = (a.cells_one_wg && a.n <= 16 * 1024) ? 1 : 0;
     {
         MdArgs md{};
         if (fuse) md = *fuse->md;
-        hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a, md, fuse ? fuse->do_second : 0, fuse ? fuse->do_first : 0);
+        hipLaunchKernelGGL(k_skin_check, dim3((a.n + 1023) / 1024), dim3(1024), 0, st, k, md, fuse ? fuse->do_second : 0,
+                           fuse ? fuse->do_first : 0);
         GAMD_CHECK_LAUNCH();
     }
-    // candidate rebuild with rc + skin, every kernel gated on the flag k_skin_check has just written
-    NbrArgs c = a;
-    c.gate = a.counters + CNT_REBUILD;
-    c.cand_pass = 1;
-    c.rc = a.rc_build; c.rc2 = a.rc2_build;
-    c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
-    c.self_loop = 0;                                          // loops are appended by the exact filter, not kept as candidates
-    if (a.cells_one_wg && a.n <= 16 * 1024) {
-        hipLaunchKernelGGL(k_cells_one_wg, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();          // also stores ref_pos
-    } else {
+    if (!k.cells_one_wg) {
+        // frequent rebuilds, or more atoms than one workgroup should bin: the four cell-list phases as grid-wide kernels, every
+        // one gated on the flag k_skin_check has just written
+        NbrArgs c = a;
+        c.gate = a.counters + CNT_REBUILD;
+        c.cand_pass = 1;
+        c.rc = a.rc_build; c.rc2 = a.rc2_build;
+        c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
+        c.self_loop = 0;
         hipLaunchKernelGGL(k_bin, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_fill_cells, dim3(gb), dim3(tb), 0, st, c); GAMD_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_sort_gather, dim3((a.ncell + 3) / 4), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
     }
-    if (a.cand_stride > 0) {
-        hipLaunchKernelGGL(k_cand_fill, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
-    } else {
-        hipLaunchKernelGGL(k_count, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, c); GAMD_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_fill, dim3(ga), dim3(256), 0, st, c); GAMD_CHECK_LAUNCH();
-    }
-    // exact list of this step
+    // exact list of this step (on a rebuild step the count pass also writes the new candidate rows)
     NbrArgs x = a;
     x.ref_pos = nullptr;
-    hipLaunchKernelGGL(k_filter<false>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, x); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_filter_count, dim3((a.n + 31) / 32), dim3(1024), 0, st, x); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter<true>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
-    if (a.cand_stride <= 0) {                                  // fixed-width mode: the fill pass wrote the chunk metadata
-        const long long nchunk_cap = (a.e_cap + GAMD_TILE) / GAMD_CHUNK;
-        hipLaunchKernelGGL(k_chunk_meta, dim3((unsigned)((nchunk_cap + 255) / 256)), dim3(256), 0, st, x);
-        GAMD_CHECK_LAUNCH();
-    }
     return 0;
 }
 
