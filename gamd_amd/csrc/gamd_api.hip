@@ -740,7 +740,7 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
                         do_second = 0;
                     }
                     if (do_first && (r = launch_com_partial(p.m.com, p.m.v, p.m.species, p.m.inv_mass, p.m.inv_mass_h, p.m.n, p.m.bx,
-                                                            p.m.devflags, p.st)))
+                                                            p.m.devflags, p.m.use_rigid, p.st)))
                         return fail(-1, "integrator launch failed (%d)", r);
                 }
             }

@@ -7,11 +7,7 @@
 
 enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD = 4, CNT_NCAND = 5,
        CNT_CAND_MAX = 6,      // fixed-stride candidate rows: the longest row of the rebuild of this call
-       // "last workgroup done" tickets of the skin path's first two kernels (neighbor.hip: last_workgroup_done): the
-       // workgroup that arrives last continues with the single-workgroup phase that used to be a launch of its own
-       CNT_TICKET_CHECK = 8,  // k_skin_check  -> cell-list phases of a candidate rebuild
-       CNT_TICKET_COUNT = 9,  // k_filter_count -> row scan (row_ptr, piece numbering, edge / tile counters)
-       CNT_COUNT = 16 };
+       CNT_COUNT = 8 };
 // host-mapped, never cleared by the per-call memset: overflow must survive later steps of an enqueued MD run
 enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, STICKY_NCAND = 3,
        STICKY_NONFINITE = 4,   // the decoder produced a non-finite force component (NaN / inf positions, or an operand
@@ -123,9 +119,8 @@ struct NbrArgs {
     int use_small;         // the host's choice (gamd_api.hip: use_small, n <= 1024): k_step_small + k_filter_fill_small, CSR
                            // candidate rows.  Explicit, not inferred from cand_stride == 0 (an undersized candidate buffer must
                            // surface as an overflow on the grid-wide path, never send n > 1024 atoms into the one-workgroup kernel)
-    int cells_one_wg;      // candidate rebuild: the four cell-list phases by ONE workgroup — the last workgroup of k_skin_check to
-                           // finish, so a reuse step pays no launch for them (rebuilds are rare) — or as four gated grid-wide
-                           // kernels (rebuilds are frequent, or more than 16 384 atoms)
+    int cells_one_wg;      // candidate rebuild: the four cell-list phases in one single-workgroup launch (rebuilds are rare: one
+                           // gated launch per reuse step instead of four) or as four grid-wide kernels (rebuilds are frequent)
     float rc_build, rc2_build;   // rc + skin
 };
 struct MdArgs;
@@ -356,6 +351,6 @@ struct NhcArgs {
 };
 // per-block momentum sums of the current velocities (first kernel of a step whose integrator removes the COM motion)
 int launch_com_partial(const MdCom& com, const float* v, const uint8_t* species, float inv_mass, float inv_mass_h, int n,
-                       const BoxRef& bx, const int* devflags, hipStream_t st);
+                       const BoxRef& bx, const int* devflags, int by_molecule, hipStream_t st);
 int launch_nhc_first(const NhcArgs& a, hipStream_t st);     // propagateNHC; v *= scale; v += dt/2 f/m; x += dt v
 int launch_nhc_second(const NhcArgs& a, hipStream_t st);    // v += dt/2 f/m; propagateNHC; v *= scale

@@ -59,15 +59,27 @@ __global__ void k_baoab_second_rigid(MdArgs a) {
 
 // ---- centre-of-mass motion removal (MdCom) ------------------------------------------------------
 // per-block sums of m v and m over this block's share of box blockIdx.y's atoms; double accumulation, fixed reduction tree
+// by_molecule (rigid water): a thread adds up whole O,H,H molecules q = t, t + T, ... instead of atoms i = t, t + T, ...: the
+// assignment k_baoab_second_com needs (its threads own molecules), so that the sums have the same bits whichever of the two
+// kernels produced them (a run enqueued in several gamd_md_run calls equals the same run in one)
+__device__ __forceinline__ void com_add_atom(double (&s)[4], const float* __restrict__ v, const uint8_t* __restrict__ species,
+                                             float inv_mass, float inv_mass_h, int i) {
+    const double m = 1.0 / (double)atom_inv_mass(species, inv_mass, inv_mass_h, i);
+    s[0] += m * (double)v[3 * i]; s[1] += m * (double)v[3 * i + 1]; s[2] += m * (double)v[3 * i + 2]; s[3] += m;
+}
 __global__ void __launch_bounds__(256) k_com_partial(MdCom c, const float* __restrict__ v, const uint8_t* __restrict__ species,
-                                                     float inv_mass, float inv_mass_h, int n, BoxRef bx, const int* devflags) {
+                                                     float inv_mass, float inv_mass_h, int n, BoxRef bx, const int* devflags,
+                                                     int by_molecule) {
     if (devflags[DEVFLAG_FROZEN]) return;                   // the first-half kernel behind this one records the position
     __shared__ double red[4][4];
     const int npb = bx.n_boxes > 1 ? bx.n_per_box : n, a0 = blockIdx.y * npb, a1 = a0 + npb;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = a0 + blockIdx.x * blockDim.x + threadIdx.x; i < a1; i += gridDim.x * blockDim.x) {
-        const double m = 1.0 / (double)atom_inv_mass(species, inv_mass, inv_mass_h, i);
-        s[0] += m * (double)v[3 * i]; s[1] += m * (double)v[3 * i + 1]; s[2] += m * (double)v[3 * i + 2]; s[3] += m;
+    if (by_molecule) {
+        for (int q = a0 / 3 + blockIdx.x * blockDim.x + threadIdx.x; 3 * q < a1; q += gridDim.x * blockDim.x)
+            for (int k = 0; k < 3; ++k) com_add_atom(s, v, species, inv_mass, inv_mass_h, 3 * q + k);
+    } else {
+        for (int i = a0 + blockIdx.x * blockDim.x + threadIdx.x; i < a1; i += gridDim.x * blockDim.x)
+            com_add_atom(s, v, species, inv_mass, inv_mass_h, i);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -95,25 +107,16 @@ __global__ void __launch_bounds__(256) k_baoab_second_com(MdArgs a) {
     const int n = a.n, npb = a.bx.n_boxes > 1 ? a.bx.n_per_box : n, a0 = blockIdx.y * npb, a1 = a0 + npb;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (a.use_rigid) {
-        // k_com_partial walks atoms i = a0 + t, a0 + t + T, ... (T = threads of the box's blocks); a thread of this kernel must
-        // own whole molecules, so it takes molecule q = t, t + T, ... and adds its three atoms: another assignment of atoms
-        // to threads, hence other bits in the last place of the sums than two launches give — both are deterministic
+        // a thread of this kernel owns whole molecules (q = t, t + T, ...): k_com_partial's by_molecule assignment
         for (int q = a0 / 3 + blockIdx.x * blockDim.x + threadIdx.x; 3 * q < a1; q += gridDim.x * blockDim.x) {
             d_baoab_second_mol(a, q);
-            const float ms[3] = {a.rigid.m_o, a.rigid.m_h, a.rigid.m_h};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int i = 3 * q + k;
-                const double m = (double)ms[k];
-                s[0] += m * (double)a.v[3 * i]; s[1] += m * (double)a.v[3 * i + 1]; s[2] += m * (double)a.v[3 * i + 2]; s[3] += m;
-            }
+            for (int k = 0; k < 3; ++k) com_add_atom(s, a.v, a.species, a.inv_mass, a.inv_mass_h, 3 * q + k);
         }
     } else {
         for (int i = a0 + blockIdx.x * blockDim.x + threadIdx.x; i < a1; i += gridDim.x * blockDim.x) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) d_baoab_second_dof(a, 3 * i + d);
-            const double m = 1.0 / (double)atom_inv_mass(a.species, a.inv_mass, a.inv_mass_h, i);
-            s[0] += m * (double)a.v[3 * i]; s[1] += m * (double)a.v[3 * i + 1]; s[2] += m * (double)a.v[3 * i + 2]; s[3] += m;
+            com_add_atom(s, a.v, a.species, a.inv_mass, a.inv_mass_h, i);
         }
     }
 #pragma unroll
@@ -282,9 +285,10 @@ __global__ void k_nhc_apply_second(NhcArgs a) {
 }  // namespace
 
 int launch_com_partial(const MdCom& com, const float* v, const uint8_t* species, float inv_mass, float inv_mass_h, int n,
-                       const BoxRef& bx, const int* devflags, hipStream_t st) {
+                       const BoxRef& bx, const int* devflags, int by_molecule, hipStream_t st) {
     const int nb = bx.n_boxes > 1 ? bx.n_boxes : 1;
-    hipLaunchKernelGGL(k_com_partial, dim3(com.blocks, nb), dim3(256), 0, st, com, v, species, inv_mass, inv_mass_h, n, bx, devflags);
+    hipLaunchKernelGGL(k_com_partial, dim3(com.blocks, nb), dim3(256), 0, st, com, v, species, inv_mass, inv_mass_h, n, bx, devflags,
+                       by_molecule);
     GAMD_CHECK_LAUNCH();
     return 0;
 }
@@ -293,7 +297,7 @@ int launch_nhc_first(const NhcArgs& a, hipStream_t st) {
     const int nb = a.bx.n_boxes > 1 ? a.bx.n_boxes : 1;
     if (a.com.enabled) {
         int r = launch_com_partial(a.com, a.v, a.species, 1.0f / a.mass, a.mass_h > 0.f ? 1.0f / a.mass_h : 0.f, a.n, a.bx,
-                                   a.devflags, st);
+                                   a.devflags, a.use_rigid, st);
         if (r) return r;
     }
     hipLaunchKernelGGL(k_nhc_ke2<false>, dim3(a.n_blocks, nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH();
@@ -314,7 +318,7 @@ int launch_nhc_second(const NhcArgs& a, hipStream_t st) {
 
 int launch_baoab_first(const MdArgs& a, hipStream_t st) {
     if (a.com.enabled) {
-        int r = launch_com_partial(a.com, a.v, a.species, a.inv_mass, a.inv_mass_h, a.n, a.bx, a.devflags, st);
+        int r = launch_com_partial(a.com, a.v, a.species, a.inv_mass, a.inv_mass_h, a.n, a.bx, a.devflags, a.use_rigid, st);
         if (r) return r;
     }
     if (a.use_rigid) hipLaunchKernelGGL(k_baoab_first_rigid, dim3((a.n / 3 + 255) / 256), dim3(256), 0, st, a);

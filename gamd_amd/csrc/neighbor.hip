@@ -440,6 +440,20 @@ __device__ void d_scan_deg(const NbrArgs& a) {
 
 __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
     GAMD_GATE();
+    if (!a.cand_pass && a.cand_stride > 0 && threadIdx.x == 0 && a.counters[CNT_REBUILD]) {
+        // skin path, the fixed-stride candidate rows were rebuilt in this call (k_filter_count): publish their size; a row
+        // longer than the stride is an overflow (the list is truncated: freeze, the host regrows to 1.25 x longest row x n
+        // and resumes)
+        const int longest = a.counters[CNT_CAND_MAX];
+        a.sticky[STICKY_NCAND] = a.counters[CNT_NCAND];
+        a.sticky[STICKY_REBUILDS] += 1;
+        if (longest > a.cand_stride) {
+            const long long need = (long long)longest * a.n;
+            a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
+            a.sticky[STICKY_CAND_OVERFLOW] = 1;
+            a.devflags[DEVFLAG_FROZEN] = 1;
+        }
+    }
     d_scan_deg(a);
 }
 
@@ -508,25 +522,6 @@ __global__ void k_chunk_meta(NbrArgs a) {
 }
 
 // ---- Verlet-skin reuse ----------------------------------------------------------------------------
-// "Last workgroup done": every workgroup of the grid calls this once, behind its last store that the continuation reads.  It
-// returns true in exactly one workgroup — the one whose ticket is the last — and there every other workgroup's stores are
-// visible (release fence + device-scope ticket in each, acquire fence in the last one).  The single-workgroup phase that
-// follows used to be a kernel launch of its own (~4 us of stream time plus the boundary) that returned at once on most steps.
-// No workgroup waits for another, so there is nothing to deadlock and nothing like the device-wide barriers that made the
-// cooperative one-launch neighbour stage slower than its launches.
-__device__ __forceinline__ bool last_workgroup_done(int* ticket) {
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return false;
-    __threadfence();
-    return true;
-}
-
 // argument block of the candidate pass (rc + skin, candidate arrays, no self loops: the exact filter appends them)
 __device__ __forceinline__ NbrArgs cand_args(const NbrArgs& a) {
     NbrArgs c = a;
@@ -577,10 +572,8 @@ __device__ __forceinline__ bool d_skin_check(const NbrArgs& a, int i) {
 }
 
 // do_second / do_first: the B of the previous MD step and the B A O A of this one for atom i first (plain BAOAB, MdFuse) —
-// per-atom work in front of a per-atom check: two launches less per step.  cells_one_wg (up to 16 384 atoms): the workgroup
-// that finishes last looks at the flag all of them have contributed to and, on the one step in 20-100 that needs it, runs the
-// four cell-list phases of the candidate rebuild itself — a reuse step no longer pays a launch that returns at once.
-__global__ void __launch_bounds__(1024) k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) {
+// per-atom work in front of a per-atom check: two launches less per step
+__global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (a.counters_next && i < CNT_COUNT) a.counters_next[i] = 0;      // ping-pong counter blocks: no memset node
     if (do_second | do_first) {
@@ -607,9 +600,13 @@ __global__ void __launch_bounds__(1024) k_skin_check(NbrArgs a, MdArgs md, int d
         moved = d_skin_check(a, i);
     }
     if (moved) a.counters[CNT_REBUILD] = 1;
-    if (!a.cells_one_wg) return;                           // grid-wide rebuild kernels follow, gated on the flag
-    if (!last_workgroup_done(a.counters + CNT_TICKET_CHECK)) return;
-    if (((volatile int*)a.counters)[CNT_REBUILD] == 0) return;
+}
+
+// The four cell-list phases of a candidate rebuild in ONE gated single-workgroup launch (up to 16 384 atoms; the four
+// grid-wide kernels above that or when rebuilds are frequent): it runs once in 10-100 steps, what counts is that a reuse step
+// pays for one launch that returns at once instead of four.
+__global__ void __launch_bounds__(1024) k_cells_one_wg(NbrArgs a) {
+    if (a.counters[CNT_REBUILD] == 0) return;
     d_cells_one_wg(cand_args(a));
 }
 
@@ -764,68 +761,51 @@ __global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
     }
 }
 
-// ---- count pass of the exact filter for n > 1024, carrying the candidate fill and the row scan ---------------------------
-// One half-wave per centre atom, 32 atoms per 1024-thread workgroup.
+// ---- count pass of the exact filter for n > 1024, carrying the candidate fill ---------------------------------------------
+// One half-wave per centre atom.
 //   reuse step    the exact cutoff on the atom's fixed-width candidate row -> deg
 //   rebuild step  (the flag k_skin_check raised; the cells are rebuilt) ONE sweep of the 27 cells computes every squared
 //                 distance once and uses it twice: < rc + skin -> the atom's new candidate row (what k_cand_fill did in a
-//                 launch of its own), < rc -> deg.  Row length, total and longest row go to cand_deg / counters; the cell
-//                 counters are left zero for the next rebuild.
-// The workgroup that finishes last then runs the row scan (row_ptr, the numbering of the partial-sum pieces, E / pieces /
-// tiles / overflow) that used to be the k_scan_deg launch behind this kernel.
-__global__ void __launch_bounds__(1024) k_filter_count(NbrArgs a) {
+//                 gated launch of its own on every step), < rc -> deg.  Row length, total and longest row go to cand_deg /
+//                 counters (published by the row scan behind this kernel); the cell counters are left zero for the next
+//                 rebuild.
+__global__ void __launch_bounds__(256) k_filter_count(NbrArgs a) {
     const int ctr = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, l = threadIdx.x & 31;
-    const bool rebuild = a.counters[CNT_REBUILD] != 0;
-    if (rebuild) {
-        const bool live = ctr < a.n;
-        const int cc = live ? ctr : a.n - 1;
-        const long long row0 = (long long)cc * a.cand_stride;
-        int w = 0, cnt = 0;
-        sweep_d2(a, cc, l, [&](bool valid, float d2, int b) {
-            const bool cand = valid && in_range(a.flavour, d2, a.rc_build, a.rc2_build, b == cc);
-            const bool edge = valid && in_range(a.flavour, d2, a.rc, a.rc2, b == cc);
-            const unsigned m = half_ballot(cand);
-            if (cand && live) {
-                const int at = w + __popc(m & ((1u << l) - 1u));
-                if (at < a.cand_stride) a.cand_col[row0 + at] = b;
-            }
-            w += __popc(m);
-            cnt += __popc(half_ballot(edge));
-        });
-        // total and longest row: one pair of global atomics per workgroup, not per atom (same-address atomics serialise)
-        __shared__ int s_tot, s_max;
-        if (threadIdx.x == 0) { s_tot = 0; s_max = 0; }
-        __syncthreads();
-        if (live && l == 0) {
-            a.cand_deg[ctr] = w;
-            a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
-            atomicAdd(&s_tot, w < a.cand_stride ? w : a.cand_stride);
-            atomicMax(&s_max, w);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(&a.counters[CNT_NCAND], s_tot);
-            atomicMax(&a.counters[CNT_CAND_MAX], s_max);
-        }
-        for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.ncell; k += gridDim.x * blockDim.x) { a.cell_cnt[k] = 0; a.cell_fill[k] = 0; }
-    } else {
+    if (a.counters[CNT_REBUILD] == 0) {
         d_filter<false>(a, ctr, l, a.row_ptr);
+        return;
     }
-    if (!last_workgroup_done(a.counters + CNT_TICKET_COUNT)) return;
-    if (rebuild && threadIdx.x == 0) {
-        // the candidate rows were rebuilt in this call: publish their size; a row longer than the stride is an overflow (the
-        // list is truncated: freeze, the host regrows to 1.25 x longest row x n and resumes)
-        const int longest = ((volatile int*)a.counters)[CNT_CAND_MAX];
-        a.sticky[STICKY_NCAND] = ((volatile int*)a.counters)[CNT_NCAND];
-        a.sticky[STICKY_REBUILDS] += 1;
-        if (longest > a.cand_stride) {
-            const long long need = (long long)longest * a.n;
-            a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
-            a.sticky[STICKY_CAND_OVERFLOW] = 1;
-            a.devflags[DEVFLAG_FROZEN] = 1;
+    const bool live = ctr < a.n;
+    const int cc = live ? ctr : a.n - 1;
+    const long long row0 = (long long)cc * a.cand_stride;
+    int w = 0, cnt = 0;
+    sweep_d2(a, cc, l, [&](bool valid, float d2, int b) {
+        const bool cand = valid && in_range(a.flavour, d2, a.rc_build, a.rc2_build, b == cc);
+        const bool edge = valid && in_range(a.flavour, d2, a.rc, a.rc2, b == cc);
+        const unsigned m = half_ballot(cand);
+        if (cand && live) {
+            const int at = w + __popc(m & ((1u << l) - 1u));
+            if (at < a.cand_stride) a.cand_col[row0 + at] = b;
         }
+        w += __popc(m);
+        cnt += __popc(half_ballot(edge));
+    });
+    // total and longest row: one pair of global atomics per workgroup, not per atom (same-address atomics serialise)
+    __shared__ int s_tot, s_max;
+    if (threadIdx.x == 0) { s_tot = 0; s_max = 0; }
+    __syncthreads();
+    if (live && l == 0) {
+        a.cand_deg[ctr] = w;
+        a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
+        atomicAdd(&s_tot, w < a.cand_stride ? w : a.cand_stride);
+        atomicMax(&s_max, w);
     }
-    d_scan_deg(a);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&a.counters[CNT_NCAND], s_tot);
+        atomicMax(&a.counters[CNT_CAND_MAX], s_max);
+    }
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.ncell; k += gridDim.x * blockDim.x) { a.cell_cnt[k] = 0; a.cell_fill[k] = 0; }
 }
 
 // Small systems (n <= 1024): exact-filter fill, the scan of the degrees and the chunk metadata in ONE launch.  Every
@@ -1025,18 +1005,18 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
         return 0;
     }
     // counters: ping-pong blocks (k_skin_check clears the other one) or one memset; the cell counters are left zero by the
-    // rebuild's last kernel.  Three launches per reuse step: check (+ integrator halves) | count (+ row scan) | fill.
+    // rebuild's last kernel.  Five launches per reuse step: check (+ integrator halves) | gated cell build | count (+ candidate
+    // fill on a rebuild step) | row scan | fill (+ chunk metadata).
     if (!a.counters_next) { e = hipMemsetAsync(a.counters, 0, sizeof(int) * CNT_COUNT, st); if (e) return (int)e; }
-    NbrArgs k = a;
-    k.cells_one_wg = (a.cells_one_wg && a.n <= 16 * 1024) ? 1 : 0;
     {
         MdArgs md{};
         if (fuse) md = *fuse->md;
-        hipLaunchKernelGGL(k_skin_check, dim3((a.n + 1023) / 1024), dim3(1024), 0, st, k, md, fuse ? fuse->do_second : 0,
-                           fuse ? fuse->do_first : 0);
+        hipLaunchKernelGGL(k_skin_check, dim3(gb), dim3(tb), 0, st, a, md, fuse ? fuse->do_second : 0, fuse ? fuse->do_first : 0);
         GAMD_CHECK_LAUNCH();
     }
-    if (!k.cells_one_wg) {
+    if (a.cells_one_wg && a.n <= 16 * 1024) {
+        hipLaunchKernelGGL(k_cells_one_wg, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();
+    } else {
         // frequent rebuilds, or more atoms than one workgroup should bin: the four cell-list phases as grid-wide kernels, every
         // one gated on the flag k_skin_check has just written
         NbrArgs c = a;
@@ -1053,7 +1033,8 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     // exact list of this step (on a rebuild step the count pass also writes the new candidate rows)
     NbrArgs x = a;
     x.ref_pos = nullptr;
-    hipLaunchKernelGGL(k_filter_count, dim3((a.n + 31) / 32), dim3(1024), 0, st, x); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_filter_count, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, x); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter<true>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
     return 0;
 }

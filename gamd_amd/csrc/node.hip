@@ -374,14 +374,13 @@ int launch_node(const NodeArgs& a, hipStream_t st) {
 #ifdef GAMD_PROFILING
     static int v = -1;
     if (v < 0) { const char* e = getenv("GAMD_NODE_VARIANT"); v = e ? atoi(e) : 0; }
+#define NODE_CASE(V) case V: if (a.f16x3) hipLaunchKernelGGL((k_node<V, true>), dim3(nb), dim3(256), 0, st, a); \
+                                 else hipLaunchKernelGGL((k_node<V, false>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0
     switch (v) {
-        case 1: hipLaunchKernelGGL((k_node<1>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
-        case 2: hipLaunchKernelGGL((k_node<2>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
-        case 3: hipLaunchKernelGGL((k_node<3>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
-        case 4: hipLaunchKernelGGL((k_node<4>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
-        case 7: hipLaunchKernelGGL((k_node<7>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0;
+        NODE_CASE(1); NODE_CASE(2); NODE_CASE(3); NODE_CASE(4); NODE_CASE(7);
         default: break;
     }
+#undef NODE_CASE
 #endif
     if (a.f16x3) hipLaunchKernelGGL((k_node<0, true>), dim3(nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_node<0, false>), dim3(nb), dim3(256), 0, st, a);

@@ -15,13 +15,29 @@ from gamd_amd.engine import GamdForce
 from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS
 from gamd_amd.workloads import lj_box
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-pos, box = lj_box(n)
-sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
-eng = GamdForce(sd, n, box, 3.0 * 3.4, scaler=SHIPPED_SCALERS["lj"])
+arg = sys.argv[1] if len(sys.argv) > 1 else "10000"
+species = None
+if arg in ("c5", "c3"):
+    # the water workloads of bench.py: C5 = 2 000 molecules, bf16 edge MLP (the node GEMMs then run in split-fp16, k_node<0, true>)
+    from gamd_amd.workloads import water_box
+    nmol, dens, scal, seed, dtype = {"c3": (1390, 258.0, "tip3p", 2345, "f32"), "c5": (2000, 251.0, "tip4p", 3456, "bf16")}[arg]
+    pos, box, species, bonds = water_box(nmol, mol_per_20A3=dens, seed=seed, jitter=0.0, wrap=False)
+    n = pos.shape[0]
+    sd = make_state_dict(ModelConfig(kind="water", use_bond=True), 3, 2.9, 1.1)
+    eng = GamdForce(sd, n, box, 4.2, bond=bonds, scaler=SHIPPED_SCALERS[scal], edge_dtype=dtype)
+elif arg == "c1":
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lj258_seed0.npz"))
+    pos, box, n = np.mod(g["pos"], 27.27), 27.27, 258
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    eng = GamdForce(sd, n, box, 7.5, scaler=SHIPPED_SCALERS["lj"])
+else:
+    n = int(arg)
+    pos, box = lj_box(n)
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    eng = GamdForce(sd, n, box, 3.0 * 3.4, scaler=SHIPPED_SCALERS["lj"])
 p = torch.from_numpy(pos).float().cuda()
 for _ in range(3):
-    eng.forward(p, inplace=True)
+    eng.forward(p, species=species, inplace=True)
 torch.cuda.synchronize()
 t = eng._dbg(5, (256 * 8, 16), np.int64).reshape(512, 4, 16).astype(np.float64)
 nwg = min(512, (n + 15) // 16)
