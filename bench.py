@@ -47,12 +47,48 @@ PMC_SOURCES = ("gamd_amd/csrc/conv_edge.hip", "gamd_amd/csrc/gamd_common.h", "ga
                "gamd_amd/csrc/neighbor.hip")
 
 
-def kernel_source_hash():
+# ... and the conv-layer edge kernels whose gather traffic profiles/gather_hbm.json records at 10^5 / 10^6 atoms
+GATHER_SOURCES = ("gamd_amd/csrc/conv_edge.hip", "gamd_amd/csrc/conv_edge_bf16.hip", "gamd_amd/csrc/gamd_common.h",
+                  "gamd_amd/csrc/gamd_bf16.h", "gamd_amd/csrc/gamd_internal.h")
+
+
+def _source_hash(files):
     h = hashlib.sha256()
-    for rel in PMC_SOURCES:
+    for rel in files:
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def kernel_source_hash():
+    return _source_hash(PMC_SOURCES)
+
+
+def gather_source_hash():
+    return _source_hash(GATHER_SOURCES)
+
+
+def gather_hbm_block():
+    """roofline.neighbour_gather_hbm: the conv-layer edge kernel's memory-side traffic (rocprofv3 counters) / kernel time /
+    8 TB/s where the node tables it gathers from no longer fit the L2s / the Infinity Cache (10^5 - 10^6 atoms; at the
+    BASELINE sizes they are L2-resident and the SURVEY's gather figure is algorithmic).  Measured by tools/gpu_pmc_gather.sh,
+    kept in profiles/gather_hbm.json, reported only for the kernel sources it was taken on."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "gather_hbm.json")))
+    except Exception as exc:
+        return {"note": f"no record: {exc}"}
+    if rec.get("kernel_source_sha256_16") != gather_source_hash():
+        return {"note": f"profiles/gather_hbm.json was taken on other kernel sources ({rec.get('kernel_source_sha256_16')} != "
+                        f"{gather_source_hash()}): not reported"}
+    out = {k: {"atoms": v["n_atoms"], "edges": v["edges"], "kernel": v["kernel"], "kernel_ms": v["conv_ms_per_launch_live"],
+               "counter_bytes_per_launch": v["hbm_bytes_per_launch"], "GB_per_s": v["hbm_GB_per_s"],
+               "frac_of_hbm_peak": v["hbm_frac_of_8TBs"], "traffic_over_mandatory": v["hbm_over_mandatory"],
+               "l2_hit_rate": v["l2_hit_rate"], "algorithmic_gather_frac": v["algorithmic_gather_frac_of_8TBs"]}
+           for k, v in rec["records"].items()}
+    out["source"] = rec["source"]
+    out["bound"] = ("fp32: matrix-bound at every size (0.09 of the HBM peak); bf16: bound by each wave's chain of GEMM / SiLU / "
+                    "gather-issue segments, per edge faster at 10^6 atoms than at the L2-resident C5 size (profiles/r05_gather_hbm.md)")
+    return out
 
 
 def parse_args():
@@ -519,6 +555,7 @@ def main():
                                   "bound": "mfma-bound in fp32: the gather rides inside k_conv_edge, whose time is set by "
                                            "the fp32 matrix pipe; the north star's >= 50 % of the memory roofline on the "
                                            "gather is reachable only by the bf16 kernel (see secondary c5)"}
+        rl["neighbour_gather_hbm"] = gather_hbm_block()
     single = ctx.world == 1
     if single and not args.no_secondary:
         # the other MFMA kernels, from the same live HIP events of the timed region as the conv kernel: the edge encoder has

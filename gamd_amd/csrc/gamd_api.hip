@@ -587,6 +587,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     no.devflags = h->devflags.as<int>();
     no.sticky = h->sticky_dev;
     no.n = h->n;
+    no.n_cu = h->n_cu;
     no.pos_s = h->pos_s.as<float4>();
     no.node_emb = h->node_emb; no.enc_w = h->nenc_w; no.enc_b = h->nenc_b;
     no.row_ptr = h->row_ptr.as<int>(); no.na_excl = h->na_excl.as<int>(); no.deg = h->deg.as<int>();

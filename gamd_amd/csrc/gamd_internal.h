@@ -256,6 +256,7 @@ struct NodeArgs {
     const int* devflags;       // DEVFLAG_FROZEN set: same
     int* sticky;               // host-mapped; STICKY_NONFINITE is raised by the decoder
     int n;
+    int n_cu;                  // compute units of the device (launch_node: which prefetch depth keeps every tile resident)
     int mode;                  // 0: first (embed + pre(0)); 1: post(l-1) + pre(l); 2: post(L-1) + decoder
     // inputs
     const float4* pos_s;       // .w = species feature

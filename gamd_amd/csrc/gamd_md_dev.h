@@ -5,6 +5,12 @@
 #include "gamd_common.h"
 #include "gamd_internal.h"
 
+// No floating-point contraction in the integrator code: the same per-atom / per-molecule function is inlined into several
+// kernels (k_baoab_*, k_baoab_second_com, k_skin_check, k_step_small), which multiply-add pairs hipcc fuses depends on the
+// kernel around it, and a trajectory must not depend on which of them carried a half step (a run enqueued in several
+// gamd_md_run calls equals the same run in one; fused == stand-alone launches).  Restored at the end of this header.
+#pragma clang fp contract(off)
+
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
     const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
@@ -225,3 +231,5 @@ __device__ __forceinline__ void d_baoab_second_mol(const MdArgs& a, int m) {
 }
 
 }  // namespace gamd_md
+
+#pragma clang fp contract(fast)

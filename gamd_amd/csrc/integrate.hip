@@ -64,6 +64,7 @@ __global__ void k_baoab_second_rigid(MdArgs a) {
 // kernels produced them (a run enqueued in several gamd_md_run calls equals the same run in one)
 __device__ __forceinline__ void com_add_atom(double (&s)[4], const float* __restrict__ v, const uint8_t* __restrict__ species,
                                              float inv_mass, float inv_mass_h, int i) {
+#pragma clang fp contract(off)                              // the same bits in k_com_partial and k_baoab_second_com
     const double m = 1.0 / (double)atom_inv_mass(species, inv_mass, inv_mass_h, i);
     s[0] += m * (double)v[3 * i]; s[1] += m * (double)v[3 * i + 1]; s[2] += m * (double)v[3 * i + 2]; s[3] += m;
 }

@@ -6,6 +6,9 @@
     python tools/profile_summary.py gather <dir> <n_atoms> <edge dtype>
         tools/gpu_pmc_gather.sh's passes (<dir>/live.json, trace/, fetch/, write/, tcc/) -> the conv-layer edge kernel's HBM
         traffic per launch, its L2 hit rate and the neighbour-gather figure in counter bytes (<dir>/gather.json + markdown)
+    python tools/profile_summary.py gatherjson <out.json> <dir> [<dir> ...]
+        merge the gather.json records of several `gather` directories into the record bench.py reports as
+        roofline.neighbour_gather_hbm (profiles/gather_hbm.json), stamped with the hash of the kernel sources
     python tools/profile_summary.py pmcjson <fetch_dir> <write_dir> <kernel substring> <out.json>
         HBM bytes per launch of one kernel (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), stamped with
         the hash of the kernel sources (bench.kernel_source_hash) so that bench.py only reports it for the build it was taken on
@@ -148,6 +151,25 @@ def gather(d, n_atoms, dtype):
     print(f"| SURVEY 8d gather figure (algorithmic: E x 1 028 B + N x 1 024 B) | {alg_gather / 1e6:.4g} MB per launch = {alg_gather / t_live / 1e9:.4g} GB/s = {rec['algorithmic_gather_frac_of_8TBs']:.3f} of 8 TB/s |")
 
 
+def gatherjson(out, dirs):
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    keep = ("n_atoms", "edges", "kernel", "conv_ms_per_launch_live", "conv_us_per_launch_rocprofv3", "hbm_bytes_per_launch",
+            "hbm_GB_per_s", "hbm_frac_of_8TBs", "hbm_over_mandatory", "l2_hit_rate", "algorithmic_gather_frac_of_8TBs",
+            "FETCH_SIZE_KB", "WRITE_SIZE_KB", "atom_steps_per_s")
+    rec = {"records": {}}
+    for d in dirs:
+        r = json.load(open(os.path.join(d, "gather.json")))
+        rec["records"][f"{r['edge_dtype']}_{r['n_atoms']}"] = {k: r[k] for k in keep}
+    rec["source"] = ("tools/gpu_pmc_gather.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum in separate passes "
+                     "(each with --kernel-trace only) on the LJ workload at 10^5 / 10^6 atoms (node tables beyond L2 / Infinity Cache); "
+                     "FETCH_SIZE x 2 (gfx950); fabric-side counters, Infinity-Cache hits included; profiles/r05_gather_hbm.md")
+    rec["kernel_source_sha256_16"] = bench.gather_source_hash()
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps(rec, indent=1))
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
     if cmd == "stats":
@@ -156,5 +178,7 @@ if __name__ == "__main__":
         pmc(sys.argv[2:])
     elif cmd == "gather":
         gather(*sys.argv[2:5])
+    elif cmd == "gatherjson":
+        gatherjson(sys.argv[2], sys.argv[3:])
     elif cmd == "pmcjson":
         pmcjson(*sys.argv[2:6])
