@@ -37,10 +37,10 @@ typedef _Float16 nf16x2 __attribute__((ext_vector_type(2)));
 typedef float nf32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NT = 16;                         // atoms per tile
-// Row stride of the exchange buffers in floats.  A ds_write_b128 / ds_read_b128 is served in four groups of 16 lanes
-// ({0-3, 12-15, 20-27}, ..., MI355X_MICROARCH.md section LDS); lane (a, g) touches dword a * XLD + 4 g (+ const): with 132
-// (round 2 - 4) lanes with equal a + g met in a bank (2.1e5 conflicts per launch, rocprofv3 SQ_LDS_BANK_CONFLICT), with 136
-// every group covers 16 different 4-bank slots.
+// Row stride of the exchange buffer in floats.  A ds_write_b128 / ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15,
+// 20-27}, ...: MI355X_MICROARCH.md section LDS); lane (a, g) touches dword a * XLD + 4 g (+ const).  With 132 (rounds 2 - 4)
+// lanes with equal a + g met in a bank: 1.3e5 - 2.1e5 two-way conflicts per launch (SQ_LDS_BANK_CONFLICT); with 136 every group
+// covers 16 different 4-bank slots.  (Worth nothing measurable next to the kernel's memory round trips; fixed because it is free.)
 constexpr int XLD = 136;
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -110,49 +110,26 @@ __device__ __forceinline__ void gemm16_half_f16(const WHalf& h, int half, const 
     }
 }
 
-// One 128x128 GEMM.  DEEP = false (more than two tiles per CU: the fp32 headline size): on entry `wn.h[0]` holds (or has in
-// flight) the FIRST K half of this GEMM's weights W; on exit it holds the first half of `next` (the matrix of the GEMM that
-// follows; NEXT = false: none) — a half's 32 fp32 MFMAs (1 024 matrix cycles) cover the L2 round trip of the next half, and
-// 64 live weight registers keep three workgroups on a CU.  DEEP = true (at most two tiles per CU: every water / small-system
-// configuration, and all split-fp16 node GEMMs, whose halves are 12 MFMAs = 200 cycles and hide nothing): `wn` holds BOTH halves
-// of W on entry and both halves of `next` on exit, fetched a whole GEMM + exchange ahead (128 live weight registers, two
-// workgroups per CU).  The compiler barriers pin the fetches where they are written: hipcc otherwise hoists every load to the
-// top of the kernel.  (The (hi | lo) fp16 image of a matrix has the size and the quarter / half structure of the fp32 one.)
-struct WFull { WHalf h[2]; };
-template <bool DEEP>
-__device__ __forceinline__ void load_wfirst(const float* W, int w, int lane, WFull& wn) {
-    load_whalf(W, w, lane, 0, wn.h[0]);
-    if (DEEP) load_whalf(W, w, lane, 1, wn.h[1]);
-}
-template <bool NEXT, bool SKIP, bool F16, bool DEEP, typename XT>
-__device__ __forceinline__ void gemm16(const float* W, const float* next, WFull& wn, const XT& XB, f32x4 (&acc)[2], int w, int lane) {
-    if constexpr (DEEP) {
-        const WFull cur = wn;
-        if (NEXT) {
-            asm volatile("" ::: "memory");
-            load_whalf(next, w, lane, 0, wn.h[0]);
-            load_whalf(next, w, lane, 1, wn.h[1]);
-            asm volatile("" ::: "memory");
-        }
-        if constexpr (F16) gemm16_half_f16(cur.h[0], 0, XB, acc, SKIP); else gemm16_half(cur.h[0], 0, XB, acc, SKIP);
-        if constexpr (F16) gemm16_half_f16(cur.h[1], 1, XB, acc, SKIP); else gemm16_half(cur.h[1], 1, XB, acc, SKIP);
-        __builtin_amdgcn_sched_barrier(0);
-    } else {
-        WHalf cur = wn.h[0];
+// One 128x128 GEMM.  On entry `wn` holds (or has in flight) the FIRST K half of this GEMM's weights W; on exit it holds the
+// first half of `next` (the matrix of the GEMM that follows; NEXT = false: none).  The compiler barriers pin the fetches
+// where they are written: hipcc otherwise hoists every load to the top of the kernel and pays with 50 more registers.
+// (The (hi | lo) fp16 image of a matrix has the size and the quarter / half structure of the fp32 one: same fetches.)
+template <bool NEXT, bool SKIP, bool F16, typename XT>
+__device__ __forceinline__ void gemm16(const float* W, const float* next, WHalf& wn, const XT& XB, f32x4 (&acc)[2], int w, int lane) {
+    WHalf cur = wn;
+    asm volatile("" ::: "memory");
+    load_whalf(W, w, lane, 1, wn);                          // second half: lands during the first half's 32 MFMAs
+    asm volatile("" ::: "memory");
+    if constexpr (F16) gemm16_half_f16(cur, 0, XB, acc, SKIP); else gemm16_half(cur, 0, XB, acc, SKIP);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = wn;
+    if (NEXT) {
         asm volatile("" ::: "memory");
-        load_whalf(W, w, lane, 1, wn.h[0]);                     // second half: lands during the first half's 32 MFMAs
+        load_whalf(next, w, lane, 0, wn);                   // next GEMM's first half: lands during the second half + exchange
         asm volatile("" ::: "memory");
-        if constexpr (F16) gemm16_half_f16(cur, 0, XB, acc, SKIP); else gemm16_half(cur, 0, XB, acc, SKIP);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = wn.h[0];
-        if (NEXT) {
-            asm volatile("" ::: "memory");
-            load_whalf(next, w, lane, 0, wn.h[0]);              // next GEMM's first half: lands during the second half + exchange
-            asm volatile("" ::: "memory");
-        }
-        if constexpr (F16) gemm16_half_f16(cur, 1, XB, acc, SKIP); else gemm16_half(cur, 1, XB, acc, SKIP);
-        __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (F16) gemm16_half_f16(cur, 1, XB, acc, SKIP); else gemm16_half(cur, 1, XB, acc, SKIP);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // this lane's 2 x 4 floats of a plain row-major [128] row: features 16 (2 w + o) + 4 g + 0..3
@@ -165,10 +142,9 @@ __device__ __forceinline__ void store16(float* __restrict__ row, int w, int g, c
     *reinterpret_cast<f32x4*>(row + 32 * w + 16 + 4 * g) = v[1];
 }
 
-// every wave contributes its 32 features; afterwards every lane holds its share of the full rows in chain16 layout.  ONE
-// workgroup barrier: consecutive exchanges alternate between two buffers, and a wave can only arrive at exchange k + 2 (which
-// overwrites the buffer of exchange k) through the barrier of exchange k + 1, which every wave passes after it has read k.
+// every wave contributes its 32 features; afterwards every lane holds its share of the full rows in chain16 layout
 __device__ __forceinline__ void exchange16(float* xbuf, int w, int a, int g, const f32x4 (&mine)[2], f32x4 (&XB)[8]) {
+    __syncthreads();                                        // previous readers are done
     store16(xbuf + a * XLD, w, g, mine);
     __syncthreads();
 #pragma unroll
@@ -184,12 +160,11 @@ __device__ __forceinline__ float group_sum(float v) {
 // NABL (profiling build only, GAMD_NODE_VARIANT; wrong results): 1 = no piece loads (agg = 0: the bound of letting the conv kernels
 // write agg), 2 = every weight fragment from one cache-hot kilobyte (the bound of any better weight prefetch), 4 = no GEMMs
 // F16: the five GEMMs in split-fp16 (the reduced-precision edge modes; weights packed by pack16_f16x3)
-// DEEP: whole-GEMM-ahead weight prefetch, two workgroups per CU (launch_node picks it when every tile is resident that way)
-template <int NABL, bool F16, bool DEEP>
-__global__ void __launch_bounds__(256, DEEP ? 2 : 3) k_node(NodeArgs a) {
-    __shared__ __attribute__((aligned(16))) float xbuf[2][NT * XLD];
-    __shared__ __attribute__((aligned(16))) float s_ln[2][GAMD_H];   // LayerNorm weight / bias of pre(l): every lane needs all 128
+template <int NABL, bool F16 = false>
+__global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
+    __shared__ __attribute__((aligned(16))) float xbuf[NT * XLD];
     __shared__ float obuf[4][NT][3];
+    __shared__ float red[2][4][NT];
 
     if (a.counters[CNT_OVERFLOW] || a.devflags[DEVFLAG_FROZEN]) return;
 
@@ -214,20 +189,11 @@ __global__ void __launch_bounds__(256, DEEP ? 2 : 3) k_node(NodeArgs a) {
     }
     f32x4 XB[8];          // full activation rows (chain16 layout)
     XSplit XS;            // F16: their (hi, lo) fp16 operand images
-#define GEMM16(NEXT, W, NXT) do { if constexpr (F16) gemm16<NEXT, (NABL & 4) != 0, true, DEEP>(W, NXT, wn, XS, mine, w, lane); \
-                                  else gemm16<NEXT, (NABL & 4) != 0, false, DEEP>(W, NXT, wn, XB, mine, w, lane); } while (0)
+#define GEMM16(NEXT, W, NXT) do { if constexpr (F16) gemm16<NEXT, (NABL & 4) != 0, true>(W, NXT, wn, XS, mine, w, lane); \
+                                  else gemm16<NEXT, (NABL & 4) != 0, false>(W, NXT, wn, XB, mine, w, lane); } while (0)
 #define SPLIT16() do { if constexpr (F16) split16(XB, XS); } while (0)
     f32x4 mine[2];        // this wave's 32 output features
-    WFull wn;             // the weights the next MFMAs need (DEEP: a whole GEMM ahead; otherwise one K half ahead in wn.h[0])
-    int xb = 0;           // exchange buffer of the next exchange (they alternate)
-#define EXCHANGE() do { exchange16(xbuf[xb], w, la, g, mine, XB); xb ^= 1; } while (0)
-
-    if (a.mode != 2 && threadIdx.x < 64) {
-        // pre(l)'s LayerNorm parameters -> LDS (visible behind the first exchange barrier): after the exchange every lane
-        // normalises its share of the FULL rows, i.e. needs the parameters of 32 features of all four waves' slices
-        const float* src = threadIdx.x < 32 ? a.pre.ln_g : a.pre.ln_b;
-        *reinterpret_cast<f32x4*>(&s_ln[threadIdx.x >> 5][4 * (threadIdx.x & 31)]) = *reinterpret_cast<const f32x4*>(src + 4 * (threadIdx.x & 31));
-    }
+    WHalf wn;             // the weight half that the next 32 MFMAs need (fetched one half ahead)
 
     if (a.mode == 0) {
         if (a.node_emb) {
@@ -243,23 +209,17 @@ __global__ void __launch_bounds__(256, DEEP ? 2 : 3) k_node(NodeArgs a) {
                 for (int r = 0; r < 4; ++r) mine[o][r] = f * ww[o][r] + mine[o][r];
         }
         if (valid) store16(a.h_out + row, w, g, mine);
-        load_wfirst<DEEP>(a.pre.wsp, w, lane, wn);
+        load_whalf(a.pre.wsp, w, lane, 0, wn);
     } else {
         // ---- post(l-1): aggregate this wave's slice of the atom's pieces, in order -------------------
-        // the three index loads lead: the piece loads depend on them, everything else (P, the residual row, the weights of the
-        // first GEMM) is independent and is issued behind them
-        const int rp0 = a.row_ptr[atom], dg = a.deg[atom], nax = a.na_excl[atom];
-        f32x4 p_in[2], h_res[2];
-        load16(a.P_in + row, w, g, p_in);
-        load16(a.h_in + row, w, g, h_res);                        // residual: needed after the second GEMM
-        asm volatile("" ::: "memory");
-        if (DEEP) load_wfirst<true>(a.post.wpep, w, lane, wn);    // lands during the two round trips of the aggregation
-        asm volatile("" ::: "memory");
-        const int na_incl = nax + ((dg > 0 && (rp0 % GAMD_CHUNK) != 0) ? 1 : 0);
+        const int rp0 = a.row_ptr[atom], dg = a.deg[atom];
+        const int na_incl = a.na_excl[atom] + ((dg > 0 && (rp0 % GAMD_CHUNK) != 0) ? 1 : 0);
         const int p0 = rp0 / GAMD_CHUNK + na_incl;
         const int np = dg > 0 ? ((rp0 + dg - 1) / GAMD_CHUNK - rp0 / GAMD_CHUNK + 1) : 0;
         mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         mine[1] = mine[0];
+        f32x4 p_in[2], h_res[2];
+        load16(a.P_in + row, w, g, p_in);                          // in flight during the aggregation
         // pieces are fetched in batches of 8 (one memory round trip for the usual 4-6 pieces per atom), summed in piece order
         for (int k0 = 0; !(NABL & 1) && __any(k0 < np); k0 += 8) {
             f32x4 pc[8][2];
@@ -273,11 +233,9 @@ __global__ void __launch_bounds__(256, DEEP ? 2 : 3) k_node(NodeArgs a) {
                 if (k0 + k < np) { mine[0] += pc[k][0]; mine[1] += pc[k][1]; }
         }
         NMARK(1);                                                  // 1: pieces summed
-        if (!DEEP) {
-            asm volatile("" ::: "memory");                        // the weight fetch stays behind the piece loads (registers)
-            load_wfirst<false>(a.post.wpep, w, lane, wn);         // in flight during the exchange
-        }
-        EXCHANGE();                                               // XB = agg
+        asm volatile("" ::: "memory");                            // the weight fetch stays behind the piece loads (registers)
+        load_whalf(a.post.wpep, w, lane, 0, wn);                  // in flight during the exchange
+        exchange16(xbuf, w, la, g, mine, XB);                     // XB = agg
         SPLIT16();
         NMARK(2);                                                  // 2: exchange 1
         mine[0] = p_in[0]; mine[1] = p_in[1];
@@ -287,71 +245,69 @@ __global__ void __launch_bounds__(256, DEEP ? 2 : 3) k_node(NodeArgs a) {
         for (int o = 0; o < 2; ++o)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[o][r] = gamd_silu_hw(mine[o][r]);
-        EXCHANGE();                                               // XB = SiLU(P + phi_edge(agg))
+        exchange16(xbuf, w, la, g, mine, XB);                     // XB = SiLU(P + phi_edge(agg))
         SPLIT16();
         NMARK(4);                                                  // 4: SiLU + exchange 2
         load16(a.post.bphi, w, g, mine);
+        load16(a.h_in + row, w, g, h_res);                        // residual: lands during the GEMM
         GEMM16(true, a.post.wphip, a.mode != 2 ? a.pre.wsp : a.dec_w1p);
         mine[0] += h_res[0]; mine[1] += h_res[1];                 // residual
         if (valid) store16(a.h_out + row, w, g, mine);
         NMARK(5);                                                  // 5: GEMM phi + residual
     }
 
-    EXCHANGE();                                                   // XB = h (mode 0) / h' (modes 1, 2): the rows the next stage reads
     if (a.mode != 2) {
-        // ---- pre(l): LayerNorm of the assembled rows, in registers ------------------------------------
-        // Every lane holds 32 of its atom's 128 features (the four lane groups g of an atom the four quarters), so the row
-        // statistics are two shuffle reductions and no workgroup barrier (rounds 2-4 normalised each wave's 32-feature slice
-        // before the exchange: two LDS reductions with a barrier each).  Two-pass form, as torch's.
+        // ---- pre(l): LayerNorm over the row = reductions over the 4 lane groups and the 4 waves ----
         // (use_layer_norm=False checkpoints: eval-mode BatchNorm1d is a per-feature affine map; the host folded the running
         //  statistics into ln_g = w / sqrt(var + eps), ln_b = b - mean * ln_g, and the row statistics are not needed)
         float mean = 0.f, rstd = 1.0f;
         if (!a.norm_bn) {
             float ps = 0.f;
 #pragma unroll
-            for (int blk = 0; blk < 8; ++blk)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ps += XB[blk][r];
-            mean = group_sum(ps) * a.ln_inv_width;
+                for (int r = 0; r < 4; ++r) ps += mine[o][r];
+            ps = group_sum(ps);
+            if (g == 0) red[0][w][la] = ps;
+            __syncthreads();
+            mean = ((red[0][0][la] + red[0][1][la]) + (red[0][2][la] + red[0][3][la])) * a.ln_inv_width;
             float pv = 0.f;
 #pragma unroll
-            for (int blk = 0; blk < 8; ++blk)
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = XB[blk][r] - mean; pv += d * d; }
+                for (int r = 0; r < 4; ++r) { const float d = mine[o][r] - mean; pv += d * d; }
+            pv = group_sum(pv);
+            if (g == 0) red[1][w][la] = pv;
+            __syncthreads();
             // zero-padded features (width < 128) each added mean^2 to the sum of squared deviations: taken out again (n_pad = 0: x - 0)
-            const float var = (group_sum(pv) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width;
+            const float var = (((red[1][0][la] + red[1][1][la]) + (red[1][2][la] + red[1][3][la])) - a.ln_n_pad * (mean * mean)) * a.ln_inv_width;
             rstd = 1.0f / sqrtf(var + 1e-5f);
         }
+        {
+            f32x4 gg[2], bb[2];
+            load16(a.pre.ln_g, w, g, gg);
+            load16(a.pre.ln_b, w, g, bb);
 #pragma unroll
-        for (int blk = 0; blk < 8; ++blk) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(&s_ln[0][16 * blk + 4 * g]);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(&s_ln[1][16 * blk + 4 * g]);
+            for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) XB[blk][r] = (XB[blk][r] - mean) * rstd * gg[r] + bb[r];
+                for (int r = 0; r < 4; ++r) mine[o][r] = (mine[o][r] - mean) * rstd * gg[o][r] + bb[o][r];
         }
-        // hn: every wave stores its own 32-feature slice (blocks 2 w, 2 w + 1 of the rows it now holds)
-        if (valid && !a.hn_perm) {
-            f32x4 hs[2];
-#pragma unroll
-            for (int blk = 0; blk < 8; ++blk)
-                if (blk >> 1 == w) hs[blk & 1] = XB[blk];
-            store16(a.hn_out + row, w, g, hs);
-        }
-        if (a.hn_perm && valid) {
-            // feature-permuted copy for the row-layout gather of conv_edge_f16x3.hip: position 4 c + j holds feature 32 j + c.
-            // Feature 16 blk + 4 g + r = 32 j + c with blk = 2 j + hi, c = 16 hi + 4 g + r: the four j of a (hi, r) sit in ONE
-            // lane -> one 16-byte store per (hi, r); wave w writes hi = w >> 1, r = 2 (w & 1), 2 (w & 1) + 1
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (hi == (w >> 1) && (r >> 1) == (w & 1)) {
-                        const f32x4 v = {XB[hi][r], XB[2 + hi][r], XB[4 + hi][r], XB[6 + hi][r]};
-                        *reinterpret_cast<f32x4*>(a.hn_out + row + 4 * (16 * hi + 4 * g + r)) = v;
-                    }
-        }
+        if (valid && !a.hn_perm) store16(a.hn_out + row, w, g, mine);
+        exchange16(xbuf, w, la, g, mine, XB);                     // XB = hn
         SPLIT16();
-        NMARK(6);                                                  // 6: exchange 3 + LayerNorm
+        NMARK(6);                                                  // 6: LayerNorm + exchange 3
+        if (a.hn_perm) {
+            // feature-permuted copy for the row-layout gather of conv_edge_f16x3.hip, written from the assembled rows
+            // in the exchange buffer: position 4 c + j holds feature 32 j + c, one coalesced 16-byte store per (atom, c)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = k * 256 + threadIdx.x, at = idx >> 5, c = idx & 31;
+                const float* xr = xbuf + at * XLD + c;
+                const f32x4 v = {xr[0], xr[32], xr[64], xr[96]};
+                const int atom_k = blockIdx.x * NT + at;
+                if (atom_k < a.n) *reinterpret_cast<f32x4*>(a.hn_out + (size_t)atom_k * GAMD_H + 4 * c) = v;
+            }
+        }
         load16(a.pre.bS, w, g, mine);
         GEMM16(true, a.pre.wsp, a.pre.wdp);
         if (valid) store16(a.S_out + row, w, g, mine);
@@ -373,6 +329,7 @@ __global__ void __launch_bounds__(256, DEEP ? 2 : 3) k_node(NodeArgs a) {
 #endif
     } else {
         // ---- decoder: Lin(128,128) GELU Lin(128,3); denormalise -------------------------------
+        exchange16(xbuf, w, la, g, mine, XB);                     // XB = h'
         SPLIT16();
         load16(a.dec_b1, w, g, mine);
         GEMM16(false, a.dec_w1p, nullptr);
@@ -413,40 +370,24 @@ __global__ void __launch_bounds__(256, DEEP ? 2 : 3) k_node(NodeArgs a) {
 #undef NMARK
 #undef GEMM16
 #undef SPLIT16
-#undef EXCHANGE
 
 }  // namespace
 
-// Two workgroups per CU hold every tile of up to 2 x 256 x ... tiles at once: then the whole-GEMM-ahead prefetch (128 weight
-// registers) costs no occupancy that matters.  More tiles (the 10 000-atom headline: 625) keep the lighter kernel, three per CU.
-template <int NABL>
-static int launch_node_variant(const NodeArgs& a, int nb, int n_cu, hipStream_t st) {
-    const bool deep = nb <= 2 * n_cu;
-    if (a.f16x3) {
-        if (deep) hipLaunchKernelGGL((k_node<NABL, true, true>), dim3(nb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_node<NABL, true, false>), dim3(nb), dim3(256), 0, st, a);
-    } else {
-        if (deep) hipLaunchKernelGGL((k_node<NABL, false, true>), dim3(nb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k_node<NABL, false, false>), dim3(nb), dim3(256), 0, st, a);
-    }
-    GAMD_CHECK_LAUNCH();
-    return 0;
-}
-
 int launch_node(const NodeArgs& a, hipStream_t st) {
     const int nb = (a.n + NT - 1) / NT;
-    const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
 #ifdef GAMD_PROFILING
     static int v = -1;
     if (v < 0) { const char* e = getenv("GAMD_NODE_VARIANT"); v = e ? atoi(e) : 0; }
+#define NODE_CASE(V) case V: if (a.f16x3) hipLaunchKernelGGL((k_node<V, true>), dim3(nb), dim3(256), 0, st, a); \
+                                 else hipLaunchKernelGGL((k_node<V, false>), dim3(nb), dim3(256), 0, st, a); GAMD_CHECK_LAUNCH(); return 0
     switch (v) {
-        case 1: return launch_node_variant<1>(a, nb, n_cu, st);
-        case 2: return launch_node_variant<2>(a, nb, n_cu, st);
-        case 3: return launch_node_variant<3>(a, nb, n_cu, st);
-        case 4: return launch_node_variant<4>(a, nb, n_cu, st);
-        case 7: return launch_node_variant<7>(a, nb, n_cu, st);
+        NODE_CASE(1); NODE_CASE(2); NODE_CASE(3); NODE_CASE(4); NODE_CASE(7);
         default: break;
     }
+#undef NODE_CASE
 #endif
-    return launch_node_variant<0>(a, nb, n_cu, st);
+    if (a.f16x3) hipLaunchKernelGGL((k_node<0, true>), dim3(nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_node<0, false>), dim3(nb), dim3(256), 0, st, a);
+    GAMD_CHECK_LAUNCH();
+    return 0;
 }

@@ -4,7 +4,7 @@
 set -eu
 src=gpurun_out/$1; dst=profiles; name=$2
 hdr='`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --steps 50 --warmup 5 --workload <w>` (tools/gpu_profile_round.sh)'
-for w in c1 c1_batch c2 c3 c5 c5b dft; do { echo "# $name — $hdr"; echo; cat $src/trace_$w.md; } > $dst/${name}_trace_$w.md; done
+for w in c1 c1_batch c2 c2_batch8 c3 c5 c5b dft; do { echo "# $name — $hdr"; echo; cat $src/trace_$w.md; } > $dst/${name}_trace_$w.md; done
 hdr2='`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --steps 50 --warmup 5 --workload <w> --edge-dtype f16x3` (tools/gpu_profile_round.sh)'
 for w in c2 dft; do { echo "# $name — $hdr2"; echo; cat $src/trace_${w}_f16x3.md; } > $dst/${name}_trace_${w}_f16x3.md; done
 { echo "# $name — ${hdr2/f16x3/bf16}"; echo; cat $src/trace_dft_bf16.md; } > $dst/${name}_trace_dft_bf16.md
@@ -12,8 +12,10 @@ for w in c2 c5 c2_f16x3; do cp $src/pmc_$w.md $dst/${name}_pmc_$w.md; done
 tail -1 $src/bench_default.json > $dst/${name}_bench_default.json
 tail -1 $src/bench_f16x3.json > $dst/${name}_bench_f16x3.json
 cp $src/pmc_conv_edge.json $dst/pmc_conv_edge.json
+if [ -f $src/gather_hbm.json ]; then cp $src/gather_hbm.json $dst/gather_hbm.json; cp $src/gather_summary.md $dst/${name}_gather_summary.md; fi
 raw=$dst/${name%%_*}_raw
 mkdir -p $raw
 cp $src/conv_variants_sched.log $raw/${name}_conv_variants_sched.log
 cp $src/conv_variants_cycles.log $raw/${name}_conv_variants_cycles.log
 cp $src/f16x3_marks.log $raw/${name}_f16x3_marks.log
+for f in node_variants.log node_marks_c5.log node_marks_c1.log node_marks_10000.log; do [ -f $src/$f ] && cp $src/$f $raw/${name}_$f; done

@@ -9,7 +9,7 @@ cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 B="python3 bench.py --no-cpu-baseline --no-secondary"
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --no-cpu-baseline --no-secondary --edge-dtype f16x3 > $out/bench_f16x3.json 2>> $out/bench_default.err
-for w in c2 c3 c5 c5b c1 c1_batch dft; do
+for w in c2 c3 c5 c5b c1 c1_batch c2_batch8 dft; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -- $B --steps 50 --warmup 5 --workload $w > $out/trace_$w.log 2>&1
   python3 tools/profile_summary.py stats $out/trace_$w > $out/trace_$w.md
 done
@@ -32,6 +32,13 @@ for w in c2 c5; do
   python3 tools/profile_summary.py pmc $out/pmc_sq_$w $out/pmc_fetch_$w $out/pmc_write_$w > $out/pmc_$w.md
 done
 python3 tools/profile_summary.py pmcjson $out/pmc_fetch_c2 $out/pmc_write_c2 k_conv_edge $out/pmc_conv_edge.json > /dev/null
+# the neighbour gather where it reaches HBM (10^5 / 10^6 atoms): live run + trace + three separate --pmc passes each
+for cfg in "100000 bf16" "1000000 bf16" "1000000 f32"; do set -- $cfg; bash tools/gpu_pmc_gather.sh $tag/gather $1 $2 > /dev/null 2>&1; done
+python3 tools/profile_summary.py gatherjson $out/gather_hbm.json $out/gather/100000_bf16 $out/gather/1000000_bf16 $out/gather/1000000_f32 > /dev/null
+cat $out/gather/*/summary.md > $out/gather_summary.md
+# k_node at the shapes where it weighs most (C5: 375 tiles in split-fp16, C1: 17 tiles): timing ablations and segment marks
+python3 tools/node_variants.py c5 c1 c2 > $out/node_variants.log 2>&1
+for w in c5 c1 10000; do python3 tools/node_marks.py $w > $out/node_marks_$w.log 2>&1; done
 # conv-layer kernel: scheduling variants A/B and the s_memtime marks (profiling build)
 python3 tools/conv_variants.py 3592 0 8 520 1544 3848 > $out/conv_variants_sched.log 2>&1
 python3 tools/conv_variants.py 3593 --cycles > $out/conv_variants_cycles.log 2>&1
