@@ -70,15 +70,18 @@ class _ModelLevel:
         else:
             raise TypeError("expected ([pos], [edge_idx]), ([pos], feat, [edge_idx]) or ([pos], feat, [box], cutoff)")
         species = None if feat is None else _node_feature(feat)
-        return self._owner._get_engine().forward_edges(pos_lst[0], edge_lst[0], species=species)
+        # a given edge list needs no neighbour search: a graph of any size runs (dgl.graph takes whatever it is handed)
+        return self._owner._get_engine(n_atoms=int(pos_lst[0].shape[0])).forward_edges(pos_lst[0], edge_lst[0], species=species)
 
     def _batched(self, pos_lst, *rest):
         """``len(pos_lst) > 1``: the reference builds one graph per entry and runs the network on their disjoint union
         (build_graph_batches + dgl.batch, nn_module.py:655-661, :520-527; edge indices are local to each graph, `feat`
         is the concatenation of the per-graph node features) and returns the outputs concatenated in order.  Here the
         graphs are the boxes of ONE batched engine (GamdForce(n_boxes=len(pos_lst))): a single set of launches, results
-        bit-identical to the graphs evaluated one by one.  Every graph must have the atom count the wrapper was built
-        for."""
+        bit-identical to the graphs evaluated one by one.  Graphs of DIFFERENT sizes (dgl.batch takes any, nn_module.py:655-661)
+        on the edge-list forms: runs of equal-sized graphs share a batched engine, the outputs are concatenated in list order
+        (independent graphs: the same numbers as one disjoint union); the dynamic-box form (its own neighbour search, one
+        atom count per engine) takes equal sizes."""
         if len(pos_lst) == 0:
             raise ValueError("empty pos_lst")
         if len(rest) not in (1, 2, 3):
@@ -91,10 +94,25 @@ class _ModelLevel:
         sizes = [int(p.shape[0]) for p in pos_lst]
         if len(rest) == 3 and len(set(sizes)) == 1:
             self._owner._size_for(sizes[0])
-        n, nb = self._owner.num_atoms, len(pos_lst)
-        if any(k != n for k in sizes):
-            raise ValueError(f"every graph of a batch must have {n} atoms (the wrapper's size), got {sizes}")
-        eng = self._owner._get_engine(n_boxes=nb)
+        if len(set(sizes)) > 1:
+            if len(rest) == 3:
+                raise ValueError(f"the dynamic-box form takes graphs of one size per call, got {sizes}")
+            # maximal runs of equal-sized graphs, each as one batch, outputs in list order
+            outs, i, off = [], 0, 0
+            while i < len(sizes):
+                j = i
+                while j < len(sizes) and sizes[j] == sizes[i]:
+                    j += 1
+                cnt = sizes[i] * (j - i)
+                sub_rest = (lst[i:j],) if len(rest) == 1 else (rest[0][off:off + cnt], lst[i:j])
+                outs.append(self.__call__(pos_lst[i:j], *sub_rest))
+                off += cnt
+                i = j
+            return torch.cat(outs, dim=0)
+        n, nb = sizes[0], len(pos_lst)
+        if len(rest) == 3 and n != self._owner.num_atoms:
+            raise ValueError(f"every graph of a batch must have {self._owner.num_atoms} atoms (the wrapper's size), got {sizes}")
+        eng = self._owner._get_engine(n_boxes=nb, n_atoms=n)
         dev = eng.device
         pos = torch.cat([(torch.from_numpy(np.ascontiguousarray(p, dtype=np.float32)) if isinstance(p, np.ndarray) else p)
                          .to(device=dev, dtype=torch.float32) for p in pos_lst], dim=0)
@@ -243,18 +261,23 @@ class _ForceFieldBase:
         self._drop_engines()
         self.num_atoms = int(n)
 
-    def _get_engine(self, n_boxes: int = 1) -> GamdForce:
+    def _get_engine(self, n_boxes: int = 1, n_atoms: Optional[int] = None) -> GamdForce:
         """n_boxes = 1: the engine behind predict_forces / single-graph model calls; n_boxes = B: the batched engine a
-        model-level call with B graphs runs on (built on first use, kept)."""
-        if n_boxes not in self._engines:
+        model-level call with B graphs runs on (built on first use, kept).  ``n_atoms`` other than the wrapper's size: an
+        engine for graphs of that size on the edge-list forms of the model-level call (no neighbour search involved; the bond
+        table of a water model is rebuilt for that many atoms, O,H,H order)."""
+        n = self.num_atoms if n_atoms is None else int(n_atoms)
+        key = n_boxes if n == self.num_atoms else (n_boxes, n)
+        if key not in self._engines:
             if self._sd is None:
                 raise RuntimeError("no weights loaded: call load_from_checkpoint / load_state_dict first")
-            self._engines[n_boxes] = GamdForce(
-                self._sd, self.num_atoms, self.box_size, self.cutoff, bond=self.bond,
+            bond = self.bond if (n == self.num_atoms or self.bond is None) else create_water_bond(n)
+            self._engines[key] = GamdForce(
+                self._sd, n, self.box_size, self.cutoff, bond=bond,
                 scaler=(self.training_mean, self.training_var), device=self.device_index,
-                nbr_flavour=self._nbr_flavour, neighbor_skin=self._skin if n_boxes == 1 else 0.0,
+                nbr_flavour=self._nbr_flavour, neighbor_skin=self._skin if (n_boxes == 1 and n == self.num_atoms) else 0.0,
                 edge_dtype=self.edge_dtype, self_loop_mode=self.self_loop_mode, n_boxes=n_boxes)
-        return self._engines[n_boxes]
+        return self._engines[key]
 
     def denormalize(self, normalized_force, var, mean):
         return normalized_force * np.sqrt(var) + mean         # LJ/train_network_lj.py:128-131

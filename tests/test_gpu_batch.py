@@ -374,3 +374,28 @@ def test_three_boxes_with_one_non_cubic_box_argument():
     cubic = eng.forward(pos3, box=box.reshape(3, 1), species=species).cpu().numpy()
     assert rel_err(cubic[n:2 * n], g["out_norm"]) > 1e-3
     eng.close()
+
+
+def test_model_level_call_with_graphs_of_different_sizes():
+    """dgl.batch takes graphs of any sizes (nn_module.py:655-661): `pnet_model([pos_a, pos_b, pos_c], [e_a, e_b, e_c])` with 258,
+    200 and 258 atoms.  Runs of equal size share a batched engine; the output is the concatenation in list order and equals
+    the graphs one by one bit for bit (independent graphs) and the oracle within the fp32 bar."""
+    from gamd_amd.compat import ParticleNetLightningLJ
+    g, cfg, sd = load_golden("lj258_seed0")
+    box, rc = float(g["box"]), float(g["cutoff"])
+    rng = np.random.default_rng(21)
+    pa = np.mod(g["pos"], box).astype(np.float32)
+    pb = np.mod(g["pos"][:200] + rng.normal(0, 0.2, (200, 3)), box).astype(np.float32)
+    pc = np.mod(g["pos"] + rng.normal(0, 0.2, (258, 3)), box).astype(np.float32)
+    poss = [torch.from_numpy(p) for p in (pa, pb, pc)]
+    edges = [orc.neighbor_edges(p, box, rc, "jaxmd") for p in poss]
+    m = ParticleNetLightningLJ(state_dict=sd, num_atoms=258, box_size=box, cutoff=rc)
+    out = m.pnet_model(poss, edges).cpu().numpy()
+    assert out.shape == (258 + 200 + 258, 3)
+    assert rel_err(out[:258], g["out_norm"]) < TOL                       # graph 0 is the reference golden
+    off = 0
+    for p, e in zip(poss, edges):
+        one = m.pnet_model([p], [e]).cpu().numpy()
+        assert np.array_equal(out[off:off + p.shape[0]], one)
+        assert rel_err(one, orc.forward(sd, p, e, box).numpy()) < TOL
+        off += p.shape[0]
