@@ -116,12 +116,6 @@ def test_the_eight_rank_boxes_as_one_batch_are_bit_identical_to_the_ranks(rank_b
 two_devices = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible HIP devices (one-GPU box)")
 
 
-def _golden_case():
-    from helpers import load_golden
-    g, cfg, sd = load_golden("lj258_seed0")
-    return g, sd, float(g["box"]), float(g["cutoff"]), np.mod(g["pos"], float(g["box"])).astype(np.float32)
-
-
 @two_devices
 def test_a_handle_on_device_1_gives_the_bits_of_device_0():
     """gamd_config.device = 1 while the caller's current device stays 0: every kernel family that needs more than 64 KiB of
