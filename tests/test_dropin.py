@@ -137,3 +137,23 @@ def test_a_checkpoint_of_other_widths_than_args_is_refused(dropin, tmp_path):
     assert D(ARGS_DFT).load_from_checkpoint(PATH3, args=ARGS_DFT).state_dict().keys() == dsd.keys()
     with pytest.raises(RuntimeError, match="conv_layer"):
         D(ARGS_DFT).load_from_checkpoint(PATH3, args=SimpleNamespace(**{**vars(ARGS_DFT), "conv_layer": 4}))
+
+
+def test_only_the_dropin_directory_on_pythonpath_is_enough(tmp_path):
+    """What INTEGRATION.md section 1 tells a maintainer to do: PYTHONPATH=<gamd_amd/dropin> in front of the reference's own
+    sys.path.append('../') — from another working directory, without the repository root on the path (the drop-in modules find
+    the package themselves)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env["PYTHONPATH"] = DROPIN
+    code = ("import sys; sys.path.append('../'); sys.path.append('../../')\n"      # the drivers' own lines (test_langevin.py:24-25)
+            "from types import SimpleNamespace\n"
+            "from train_network_lj import ParticleNetLightning, NUM_OF_ATOMS, BOX_SIZE, CUTOFF_RADIUS\n"
+            "from train_network_tip3p import create_water_bond\n"
+            "import train_network_tip4p, train_network_real_large\n"
+            "m = ParticleNetLightning(SimpleNamespace(use_layer_norm=True, encoding_size=128, hidden_dim=128, edge_embedding_dim=128,\n"
+            "    drop_edge=False, conv_layer=4, rotate_aug=False, update_edge=False, use_part=False, data_dir='', loss='mae'))\n"
+            "print('OK', NUM_OF_ATOMS, BOX_SIZE, CUTOFF_RADIUS, m.num_atoms, type(m).__module__)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "OK 258 27.27 7.5 258 train_network_lj" in r.stdout
