@@ -535,15 +535,107 @@ __device__ __forceinline__ NbrArgs cand_args(const NbrArgs& a) {
 
 // bin | scan | fill | sort + gather of a candidate rebuild by ONE 1024-thread workgroup (the phases of k_step_small's rebuild
 // with loops over the atoms / cells); the cell counters are zero on entry (the previous rebuild's k_filter_count left them so)
+//
+// One workgroup means every phase is a loop of dependent memory round trips per thread (6 atoms per thread at 6 000 atoms, 32
+// cells per wave at 512 cells: ~140 us per rebuild, ~100 of them in the per-cell sort, at a rebuild every 11 steps 4 % of the C5
+// step).  The loops are therefore BATCHED: the loads (and the returning atomics) of up to 8 iterations are issued together and
+// waited for once, so a phase costs two or three round trips per batch instead of per atom / per cell.  Same stores, same
+// values: the sorted order, perm / inv_perm and the cell bounds are what the one-by-one form writes.
+constexpr int CELL_BATCH = 8;
+
+__device__ void d_bin_batch(const NbrArgs& a, int tid) {
+    for (int base = tid; base < a.n; base += 1024 * CELL_BATCH) {
+        float px[CELL_BATCH], py[CELL_BATCH], pz[CELL_BATCH];
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) {
+            const int i = base + 1024 * b;
+            if (i < a.n) { px[b] = a.pos[3 * i + 0]; py[b] = a.pos[3 * i + 1]; pz[b] = a.pos[3 * i + 2]; }
+        }
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) {
+            const int i = base + 1024 * b;
+            if (i < a.n) {
+                const int bi = box_id(a, i);
+                const BoxDims B = box_dims(a, bi);
+                float4 p;
+                p.x = gamd_remainder(px[b], B.bx);           // graph_utils.py:31 jnp.mod(pos, box)
+                p.y = gamd_remainder(py[b], B.by);
+                p.z = gamd_remainder(pz[b], B.bz);
+                p.w = 0.f;
+                a.pos_w[i] = p;
+                if (a.ref_pos) a.ref_pos[i] = p;
+                const BoxCells G = box_cells(a, bi);
+                const int c = G.base + (cell_coord(p.x, B.bx, G.nx) * G.ny + cell_coord(p.y, B.by, G.ny)) * G.nz + cell_coord(p.z, B.bz, G.nz);
+                a.cell_of[i] = c;
+                atomicAdd(&a.cell_cnt[c], 1);
+            }
+        }
+    }
+}
+
+__device__ void d_fill_cells_batch(const NbrArgs& a, int tid) {
+    for (int base = tid; base < a.n; base += 1024 * CELL_BATCH) {
+        int c[CELL_BATCH], s[CELL_BATCH], st[CELL_BATCH];
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) { const int i = base + 1024 * b; c[b] = i < a.n ? a.cell_of[i] : -1; }
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b)
+            if (c[b] >= 0) { s[b] = atomicAdd(&a.cell_fill[c[b]], 1); st[b] = a.cell_start[c[b]]; }
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b)
+            if (c[b] >= 0) a.perm[st[b] + s[b]] = base + 1024 * b;
+    }
+}
+
+// d_sort_gather for the cells wave, wave + 16, wave + 32, ... of this workgroup, CELL_BATCH cells at a time
+__device__ void d_sort_gather_batch(const NbrArgs& a, int wave, int lane) {
+    for (int k0 = wave; k0 < a.ncell; k0 += 16 * CELL_BATCH) {
+        int s[CELL_BATCH], cnt[CELL_BATCH], v[CELL_BATCH], rank[CELL_BATCH];
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) {
+            const int k = k0 + 16 * b;
+            s[b] = k < a.ncell ? a.cell_start[k] : 0;
+            cnt[b] = k < a.ncell ? a.cell_start[k + 1] - s[b] : 0;
+        }
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) v[b] = (cnt[b] <= 64 && lane < cnt[b]) ? a.perm[s[b] + lane] : 0x7fffffff;
+        // rank by counting, all cells of the batch in step (lanes beyond a cell's count hold INT_MAX: they never count)
+        int maxc = 0;
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) { rank[b] = 0; if (cnt[b] <= 64 && cnt[b] > maxc) maxc = cnt[b]; }
+        for (int j = 0; j < maxc; ++j) {
+#pragma unroll
+            for (int b = 0; b < CELL_BATCH; ++b) rank[b] += (__shfl(v[b], j, 64) < v[b]) ? 1 : 0;
+        }
+        float4 p[CELL_BATCH];
+        float f[CELL_BATCH];
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b)
+            if (cnt[b] <= 64 && lane < cnt[b]) { p[b] = a.pos_w[v[b]]; f[b] = node_feature(a, v[b]); }
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b)
+            if (cnt[b] <= 64 && lane < cnt[b]) {
+                a.perm[s[b] + rank[b]] = v[b];            // ids are distinct -> ranks are a permutation
+                a.pos_s[s[b] + rank[b]] = make_float4(p[b].x, p[b].y, p[b].z, f[b]);
+                a.inv_perm[v[b]] = s[b] + rank[b];
+            }
+        unsigned over = 0;                                             // over-full cells (cutoff >> spacing): the serial form
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) over |= cnt[b] > 64 ? 1u << b : 0u;
+        for (int b = 0; over >> b; ++b)
+            if ((over >> b) & 1u) d_sort_gather(a, k0 + 16 * b, lane);
+    }
+}
+
 __device__ void d_cells_one_wg(const NbrArgs& c) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < c.n; i += 1024) d_bin(c, i);                      // also stores ref_pos
+    d_bin_batch(c, tid);                                                     // also stores ref_pos
     __syncthreads();
     block_exclusive_scan(c.ncell, [&](int i) { return c.cell_cnt[i]; }, c.cell_start);
     __syncthreads();
-    for (int i = tid; i < c.n; i += 1024) d_fill_cells(c, i);
+    d_fill_cells_batch(c, tid);
     __syncthreads();
-    for (int k = tid >> 6; k < c.ncell; k += 16) d_sort_gather(c, k, tid & 63);
+    d_sort_gather_batch(c, tid >> 6, tid & 63);
 }
 
 // Every call: wrap the positions and raise the rebuild flag if any atom has moved more than skin/2 since the
