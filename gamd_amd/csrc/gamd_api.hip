@@ -697,7 +697,7 @@ int check_rigid_layout(gamd_handle* h, const uint8_t* species_dev, hipStream_t s
 }
 
 int clear_devflags(gamd_handle* h) {
-    const int init[DEVFLAG_COUNT] = {0, -1, 0, 0};
+    const int init[2] = {0, -1};                             // FROZEN, FROZEN_AT; the rebuild counter behind them stays
     HIP_TRY(hipMemcpy(h->devflags.p, init, sizeof(init), hipMemcpyHostToDevice));
     return 0;
 }

@@ -19,7 +19,10 @@ enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, 
 //                      run stops at the last consistent state instead of integrating stale forces
 //   DEVFLAG_FROZEN_AT  2 * (index of the step inside the md_run call) + (0: before its first half, 1: before its second
 //                      half) of the first integrator kernel that found the flag set, -1 if none did: where to resume
-enum { DEVFLAG_FROZEN = 0, DEVFLAG_FROZEN_AT = 1, DEVFLAG_COUNT = 4 };
+//   DEVFLAG_REBUILDS   candidate rebuilds so far, counted HERE (device memory) and published to the host-mapped sticky block by a
+//                      plain store: a read-modify-write on the host-mapped word is a PCIe read in the middle of a single-
+//                      workgroup kernel — measured ~200 us per rebuild step (round 5).  Never cleared.
+enum { DEVFLAG_FROZEN = 0, DEVFLAG_FROZEN_AT = 1, DEVFLAG_REBUILDS = 2, DEVFLAG_COUNT = 4 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (kernel, DEVICE): a process that holds handles on several
 // devices (gamd_config.device; SURVEY.md 8e "one stream per device from one process") must raise the limit on each of them, or

@@ -32,11 +32,27 @@ __device__ __forceinline__ float node_feature(const NbrArgs& a, int v) {
 
 // box of atom i (caller's order or sorted order: box b owns [b n_per_box, (b + 1) n_per_box) in both) and its dimensions
 __device__ __forceinline__ int box_id(const NbrArgs& a, int i) { return a.bx.n_boxes > 1 ? gamd_box_of(a.bx, i) : 0; }
-__device__ __forceinline__ BoxDims box_dims(const NbrArgs& a, int b) { return gamd_box_dims(a.bx, a.box, a.half, b); }
+// (The single-box values pass through an empty asm: without it hipcc folds the two branches into loads through
+// select(&a.box, &boxes[3 b]) — the address of a member of the argument block escapes, scalar replacement gives up, and a kernel
+// that works on a modified copy of the block (k_step_small's candidate pass) keeps all 376 bytes of it in scratch memory and reads
+// every field back from there inside its sweep loops: a 258-atom rebuild took 0.5 ms instead of 0.1.)
+__device__ __forceinline__ BoxDims box_dims(const NbrArgs& a, int b) {
+    if (a.bx.n_boxes <= 1) {
+        float bx = a.box[0], by = a.box[1], bz = a.box[2], hx = a.half[0], hy = a.half[1], hz = a.half[2];
+        asm volatile("" : "+r"(bx), "+r"(by), "+r"(bz), "+r"(hx), "+r"(hy), "+r"(hz));
+        return BoxDims{bx, by, bz, hx, hy, hz};
+    }
+    const float4 B = a.bx.boxes[3 * b], H = a.bx.boxes[3 * b + 1];
+    return BoxDims{B.x, B.y, B.z, H.x, H.y, H.z};
+}
 // cell grid of box b: cells along x, y, z and the index of its first cell
 struct BoxCells { int nx, ny, nz, base; };
 __device__ __forceinline__ BoxCells box_cells(const NbrArgs& a, int b) {
-    if (a.bx.n_boxes <= 1) return BoxCells{a.nc[0], a.nc[1], a.nc[2], 0};
+    if (a.bx.n_boxes <= 1) {
+        int nx = a.nc[0], ny = a.nc[1], nz = a.nc[2];
+        asm volatile("" : "+r"(nx), "+r"(ny), "+r"(nz));
+        return BoxCells{nx, ny, nz, 0};
+    }
     const int4 c = reinterpret_cast<const int4*>(a.bx.boxes)[3 * b + 2];
     return BoxCells{c.x, c.y, c.z, c.w};
 }
@@ -67,7 +83,7 @@ __global__ void k_bin(NbrArgs a) {
 // single-block exclusive scan, any length; out has n+1 entries (out[n] = total).  4 consecutive items per thread per
 // pass (4 096 per pass), wave shuffles + one LDS hop.
 template <typename F>
-__device__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
+__device__ __forceinline__ void block_exclusive_scan(int n, F load, int* __restrict__ out) {
     constexpr int IPT = 4;
     __shared__ int wave_tot[16];
     __shared__ int carry_s;
@@ -186,10 +202,20 @@ __device__ __forceinline__ float gamd_mask_d2(const float4& pc, const float4& pb
 // test the atoms of a cell in parallel.  visit(ok, b) is called by every lane for every pass; the
 // accepted neighbours of a pass are compacted in lane order with a ballot, so the CSR order is fixed:
 // cells in (dx,dy,dz) order, atoms by ascending original id inside a cell.
+// position tables of the sweeps: the argument block's global table, or k_step_small's LDS copy through a pointer typed with the
+// LDS address space (ds_read_b128 instead of a flat load; float4 is a class type without address-space-qualified copies, so the
+// LDS side is read as a plain 4-vector)
+typedef __attribute__((address_space(3))) const f32x4* LdsPos;
+typedef __attribute__((address_space(3))) const int* LdsCells;
+__device__ __forceinline__ float4 pos_at(const float4* p, int i) { return p[i]; }
+__device__ __forceinline__ float4 pos_at(LdsPos p, int i) { const f32x4 v = p[i]; return make_float4(v[0], v[1], v[2], v[3]); }
+
 // visit(valid, d2, b): lane's candidate b of this pass (valid: the pass has an atom for this lane) and its squared distance
-template <typename V>
-__device__ __forceinline__ void sweep_d2(const NbrArgs& a, int ctr, int l, V visit) {
-    const float4 pc = a.pos_s[ctr];
+template <typename V, typename PosPtr, typename CellPtr>
+__device__ __forceinline__ void sweep_d2(const NbrArgs& a, int ctr, int l, V visit, PosPtr pos_s, CellPtr cell_start) {
+    // pos_s / cell_start: the argument block's tables, or the LDS copies k_step_small sweeps — as pointers of their own, typed
+    // with the LDS address space there (ds_read instead of flat loads: three dependent loads per visited cell)
+    const float4 pc = pos_at(pos_s, ctr);
     const int bi = box_id(a, ctr);
     const BoxDims B = box_dims(a, bi);
     const BoxCells G = box_cells(a, bi);
@@ -207,26 +233,31 @@ __device__ __forceinline__ void sweep_d2(const NbrArgs& a, int ctr, int l, V vis
             for (int dz = lz; dz <= hz; ++dz) {
                 int z = cz + dz; z += z < 0 ? G.nz : 0; z -= z >= G.nz ? G.nz : 0;
                 const int c = G.base + (x * G.ny + y) * G.nz + z;
-                const int s = a.cell_start[c], e = a.cell_start[c + 1];
+                const int s = cell_start[c], e = cell_start[c + 1];
                 for (int b0 = s; b0 < e; b0 += 32) {
                     const int b = b0 + l;
                     float d2 = 0.f;
-                    if (b < e) d2 = gamd_mask_d2(pc, a.pos_s[b], B);
+                    if (b < e) { const float4 pb = pos_at(pos_s, b); d2 = gamd_mask_d2(pc, pb, B); }
                     visit(b < e, d2, b);
                 }
             }
         }
     }
 }
+template <typename V>
+__device__ __forceinline__ void sweep_d2(const NbrArgs& a, int ctr, int l, V visit) { sweep_d2(a, ctr, l, visit, a.pos_s, a.cell_start); }
 // the cutoff test of the two flavours on a squared distance
 __device__ __forceinline__ bool in_range(int flavour, float d2, float rc, float rc2, bool is_self) {
     return flavour == 0 ? d2 < rc2                                   // graph_utils.py:59 (strict, self pair kept)
                         : (sqrtf(d2) <= rc) && !is_self;             // md_module.py:111
 }
-template <typename V>
-__device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit) {
-    sweep_d2(a, ctr, l, [&](bool valid, float d2, int b) { visit(valid && in_range(a.flavour, d2, a.rc, a.rc2, b == ctr), b); });
+template <typename V, typename PosPtr, typename CellPtr>
+__device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit, PosPtr pos_s, CellPtr cell_start) {
+    sweep_d2(a, ctr, l, [&](bool valid, float d2, int b) { visit(valid && in_range(a.flavour, d2, a.rc, a.rc2, b == ctr), b); },
+             pos_s, cell_start);
 }
+template <typename V>
+__device__ __forceinline__ void sweep(const NbrArgs& a, int ctr, int l, V visit) { sweep(a, ctr, l, visit, a.pos_s, a.cell_start); }
 
 // my half-wave's 32-bit slice of a 64-lane ballot
 __device__ __forceinline__ unsigned half_ballot(bool p) {
@@ -235,13 +266,15 @@ __device__ __forceinline__ unsigned half_ballot(bool p) {
 }
 
 // one half-wave per centre atom `ctr` (both halves of a wave must call this together, live or not)
-__device__ __forceinline__ void d_count(const NbrArgs& a, int ctr, int l) {
+template <typename PosPtr, typename CellPtr>
+__device__ __forceinline__ void d_count(const NbrArgs& a, int ctr, int l, PosPtr pos_s, CellPtr cell_start) {
     const bool live = ctr < a.n;
     int cnt = 0;
     // both halves of a wave must run the same number of ballots: sweep a clamped atom, discard below
-    sweep(a, live ? ctr : a.n - 1, l, [&](bool ok, int) { cnt += __popc(half_ballot(ok)); });
+    sweep(a, live ? ctr : a.n - 1, l, [&](bool ok, int) { cnt += __popc(half_ballot(ok)); }, pos_s, cell_start);
     if (live && l == 0) a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
 }
+__device__ __forceinline__ void d_count(const NbrArgs& a, int ctr, int l) { d_count(a, ctr, l, a.pos_s, a.cell_start); }
 
 __global__ void __launch_bounds__(256) k_count(NbrArgs a) {
     GAMD_GATE();
@@ -253,7 +286,7 @@ __global__ void __launch_bounds__(256) k_count(NbrArgs a) {
 // updated; the fill pass points them at the all-zero row).  The partial-sum pieces of an atom are cut at chunk boundaries, so
 // with aligned starts box b's rows are cut exactly where a single-box evaluation cuts them: the forces of a batch are
 // bit-identical to the boxes evaluated one by one.  Whole 1024-thread workgroup; at most 15 slots per box.
-__device__ void d_box_align(const NbrArgs& a) {
+__device__ __forceinline__ void d_box_align(const NbrArgs& a) {
     const int nb = a.bx.n_boxes, npb = a.bx.n_per_box;
     block_exclusive_scan(nb, [&](int b) {
         const int T = a.row_ptr[(b + 1) * npb] - a.row_ptr[b * npb];
@@ -275,7 +308,7 @@ __device__ void d_box_align(const NbrArgs& a) {
 // The same two scans for n <= 16 384 in ONE pass over registers: 16 consecutive rows per thread (four 16-byte loads), row_ptr
 // and the off-boundary flags derived from it never leave the thread between the two scans — the multi-pass form above
 // re-reads row_ptr through L2 and needs 6 passes with 4 workgroup barriers each at n = 10 000 (17 us -> see DESIGN).
-__device__ void d_scan_deg_fast(const NbrArgs& a) {
+__device__ __forceinline__ void d_scan_deg_fast(const NbrArgs& a) {
     constexpr int IPT = 16;
     __shared__ int s_tot[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -376,7 +409,7 @@ __device__ void d_scan_deg_fast(const NbrArgs& a) {
             a.counters[CNT_NCAND] = E_all;
             a.sticky[STICKY_NCAND] = E_all;
             if ((long long)E_all > a.e_cap) { a.sticky[STICKY_CAND_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1; }
-            a.sticky[STICKY_REBUILDS] += 1;
+            a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
         }
         return;
     }
@@ -409,7 +442,7 @@ __device__ void d_scan_deg_fast(const NbrArgs& a) {
     }
 }
 
-__device__ void d_scan_deg(const NbrArgs& a) {
+__device__ __forceinline__ void d_scan_deg(const NbrArgs& a) {
     if (a.n <= 16 * 1024) { d_scan_deg_fast(a); return; }
     block_exclusive_scan(a.n, [&](int i) { return a.deg[i]; }, a.row_ptr);
     __syncthreads();
@@ -420,7 +453,7 @@ __device__ void d_scan_deg(const NbrArgs& a) {
             a.counters[CNT_NCAND] = nc;
             a.sticky[STICKY_NCAND] = nc;
             if ((long long)nc > a.e_cap) { a.sticky[STICKY_CAND_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1; }
-            a.sticky[STICKY_REBUILDS] += 1;
+            a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
         }
         return;
     }
@@ -446,7 +479,7 @@ __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
         // and resumes)
         const int longest = a.counters[CNT_CAND_MAX];
         a.sticky[STICKY_NCAND] = a.counters[CNT_NCAND];
-        a.sticky[STICKY_REBUILDS] += 1;
+        a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
         if (longest > a.cand_stride) {
             const long long need = (long long)longest * a.n;
             a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
@@ -469,7 +502,8 @@ __device__ __forceinline__ void d_fill_padding(const NbrArgs& a, int c, int l, l
     for (long long x = w_end + l; x < end; x += 32) { a.col[x] = a.n; if (a.erow) a.erow[x] = c; }
 }
 
-__device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l) {
+template <typename PosPtr, typename CellPtr>
+__device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l, PosPtr pos_s, CellPtr cell_start) {
     const bool live = ctr < a.n;
     const int c = live ? ctr : a.n - 1;
     long long w = a.row_ptr[c];
@@ -480,11 +514,12 @@ __device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l) {
             if (at < a.e_cap) { a.col[at] = b; if (a.erow) a.erow[at] = c; }
         }
         w += __popc(m);
-    });
+    }, pos_s, cell_start);
     // self_loop_mode 1: the loop DGL's in-place add_self_loop would append (nn_module.py:650-652), last in the row
     if (a.self_loop && live && l == 0 && w < a.e_cap) { a.col[w] = c; if (a.erow) a.erow[w] = c; }
     if (live && !a.cand_pass) d_fill_padding(a, c, l, w + (a.self_loop ? 1 : 0));
 }
+__device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l) { d_fill(a, ctr, l, a.pos_s, a.cell_start); }
 
 __global__ void __launch_bounds__(256) k_fill(NbrArgs a) {
     GAMD_GATE();
@@ -757,19 +792,21 @@ __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int d
     // LDS round trip instead.  (Flat pointers into LDS: the sweep code is shared with the grid-wide kernels.)
     __shared__ float4 s_pos[1024];
     __shared__ int s_cell_start[SMALL_CELLS_LDS + 1];
-    NbrArgs cl = c;
-    if (c.ncell <= SMALL_CELLS_LDS) {
+    const bool lds_tables = c.ncell <= SMALL_CELLS_LDS;
+    if (lds_tables) {
         if (tid < c.n) s_pos[tid] = c.pos_s[tid];
         for (int k = tid; k <= c.ncell; k += 1024) s_cell_start[k] = c.cell_start[k];
         __syncthreads();
-        cl.pos_s = s_pos;
-        cl.cell_start = s_cell_start;
     }
-    for (int base = 0; base < c.n; base += 32) d_count(cl, base + (tid >> 5), tid & 31);
+    const LdsPos lpos = (LdsPos)(const void*)s_pos;
+    const LdsCells lcells = (LdsCells)(const void*)s_cell_start;
+    if (lds_tables) { for (int base = 0; base < c.n; base += 32) d_count(c, base + (tid >> 5), tid & 31, lpos, lcells); }
+    else { for (int base = 0; base < c.n; base += 32) d_count(c, base + (tid >> 5), tid & 31, c.pos_s, c.cell_start); }
     __syncthreads();
-    d_scan_deg(c);
+    d_scan_deg(c);       // (forced inline: as a real call its argument block would have to live in scratch memory)
     __syncthreads();
-    for (int base = 0; base < c.n; base += 32) d_fill(cl, base + (tid >> 5), tid & 31);
+    if (lds_tables) { for (int base = 0; base < c.n; base += 32) d_fill(c, base + (tid >> 5), tid & 31, lpos, lcells); }
+    else { for (int base = 0; base < c.n; base += 32) d_fill(c, base + (tid >> 5), tid & 31, c.pos_s, c.cell_start); }
 }
 
 // exact cutoff on the candidate rows: one half-wave per centre atom, candidates keep their order

@@ -1,0 +1,19 @@
+import csv,glob,collections,sys
+d0=sys.argv[1]
+rows=[]
+for f in glob.glob(d0+"/**/*kernel_trace.csv", recursive=True):
+    rows+=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+d=collections.defaultdict(list)
+for r in rows:
+    d[r["Kernel_Name"].split("(")[0][-40:]].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
+for k,v in d.items():
+    if len(v)>50:
+        v2=sorted(v); print(k, len(v), "p50 %.1f p99 %.1f max %.1f top5 %s"%(v2[len(v2)//2], v2[int(len(v2)*0.99)], v2[-1], [round(x,1) for x in v2[-5:]]))
+idx=[i for i,r in enumerate(rows) if "k_step_small" in r["Kernel_Name"] and (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))>100000]
+print("slow k_step_small calls:", len(idx))
+for i in idx[1:3]:
+    t0=int(rows[i]["Start_Timestamp"])
+    for r in rows[i:i+16]:
+        print("   %8.1f us  +%6.1f  %s"%((int(r["Start_Timestamp"])-t0)/1e3,(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3,r["Kernel_Name"].split("(")[0][-44:]))
+    print()
