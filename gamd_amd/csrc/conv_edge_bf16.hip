@@ -44,6 +44,7 @@ constexpr int CONVB_LDS_BYTES = 4 * GAMD_WFRAG_BF16_BYTES + 3 * 128 * 4;
 
 // ABL (profiling build only, wrong results by construction): timing ablations selected with GAMD_BF16_VARIANT
 //   1 SiLU -> x / 2   2 every gather from the zero row   4 no piece stores   8 no LDS weight fill   16 no MFMAs
+//   32 the S / D (chain-layout) gathers alone from the zero row
 template <int ABL>
 __device__ __forceinline__ float silu_abl(float x) { return (ABL & 1) ? 0.5f * x : gamd_silu_hw(x); }
 
@@ -182,8 +183,9 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
         BT(0);                                         // bias init (+ wait for e)
         if (!(ABL & 16)) gemm128_bf16_pf<false, BF16_RING>(W1, lane, P, RC);
         BT(1);                                         // GEMM 1
-        load_row_chain_off(a.S, ((unsigned)src << 9) + half16, RA);
-        load_row_chain_off(a.D, ((unsigned)dst << 9) + half16, RB);
+        // (ABL 32: only the S / D gathers from the zero row, the hn gather as it is: what the chain-layout gather alone costs)
+        load_row_chain_off(a.S, ((unsigned)((ABL & 32) ? a.zero_row : src) << 9) + half16, RA);
+        load_row_chain_off(a.D, ((unsigned)((ABL & 32) ? a.zero_row : dst) << 9) + half16, RB);
         BT(2);                                         // S / D gather issue
         silu_pack_bf16<ABL>(RC, P, sk);
         BT(3);                                         // SiLU 1 + pack
@@ -322,6 +324,7 @@ int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
         case 7: return launch_bf16_abl<7>(a, n_blocks, st);
         case 23: return launch_bf16_abl<23>(a, n_blocks, st);
         case 31: return launch_bf16_abl<31>(a, n_blocks, st);
+        case 32: return launch_bf16_abl<32>(a, n_blocks, st);
         case 64: return launch_bf16_abl<64>(a, n_blocks, st);
         default: break;
     }
