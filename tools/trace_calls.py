@@ -1,3 +1,12 @@
+#!/usr/bin/env python3
+"""Per-CALL kernel durations of a rocprofv3 --kernel-trace run (the --stats summary only gives averages, which hide a kernel
+that takes 7 us on 99 calls and 260 us on the hundredth):
+
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --workload c1 --steps 300 ...
+    python tools/trace_calls.py <dir>
+
+prints p50 / p99 / max and the five longest calls of every kernel with more than 50 calls, and the kernels that follow the
+slow k_step_small calls (the small-system candidate rebuild, profiles/r05_experiments.md section 8)."""
 import csv,glob,collections,sys
 d0=sys.argv[1]
 rows=[]
