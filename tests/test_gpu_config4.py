@@ -112,6 +112,67 @@ def test_the_eight_rank_boxes_as_one_batch_are_bit_identical_to_the_ranks(rank_b
     batch.close(); single.close()
 
 
+def test_two_handles_in_one_process_with_runs_in_flight_on_two_streams():
+    """The one-GPU analogue of 'one stream per device from one process' (SURVEY 8e): two handles — an LJ box and a bf16 rigid
+    water box, so different kernel families, dynamic-LDS sizes and neighbour paths — with MD runs enqueued on two streams at
+    the same time give the bits each gives alone (nothing mutable is shared between handles: launch-attribute guards, error
+    slots, counters, scratch)."""
+    from helpers import load_golden
+    pos, box = workloads.lj_box(N, seed=1236)
+    sd = _sd()
+    _, _, wsd = load_golden("tip3p774_seed3")
+    n_mol = 216
+    wpos, wbox, species, bonds = workloads.water_box(n_mol, seed=31, jitter=0.0, wrap=False)
+    nw = 3 * n_mol
+    mass = np.where(species == 1, workloads.MASS_O, workloads.MASS_H).astype(np.float64).reshape(-1, 1)
+    pairs, _ = orc.water_constraints(nw, workloads.TIP3P_R_OH, workloads.TIP3P_R_HH)
+    wv0 = np.random.default_rng(32).normal(0, 1.0, (nw, 3)) * 10.0 * np.sqrt(workloads.KB * 300.0 / mass)
+    wv0 = orc.rattle_velocities(wpos, wv0, (1.0 / mass).reshape(-1), pairs)
+    wmd = dict(dt_ps=0.0005, mass_amu=workloads.MASS_O, mass_h_amu=workloads.MASS_H, temperature_k=300.0, rigid_water=True,
+               r_oh=workloads.TIP3P_R_OH, r_hh=workloads.TIP3P_R_HH, species=species, seed=5)
+
+    def run(which, stream_a=None, stream_b=None):
+        out = {}
+        cur = torch.cuda.current_stream()
+        sa, sb = (stream_a or cur), (stream_b or cur)
+        a = b = None
+        if "a" in which:
+            a = _engine(sd, N, box, RC, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=RC / 6.0)
+            xa = torch.from_numpy(pos).float().cuda()
+            va = torch.from_numpy(workloads.maxwell_boltzmann(N, seed=3)).float().cuda()
+            fa = a.forward(xa, denormalize=True).clone()
+        if "b" in which:
+            b = _engine(wsd, nw, wbox, 4.2, bond=bonds, scaler=SHIPPED_SCALERS["tip3p"], edge_dtype="bf16", neighbor_skin=0.7)
+            xb = torch.from_numpy(wpos).float().cuda()
+            vb = torch.from_numpy(wv0).float().cuda()
+            fb = b.forward(xb, species=species, denormalize=True).clone()
+        torch.cuda.synchronize()
+        for _ in range(3):                                             # interleaved enqueues, nothing synchronised in between
+            if a is not None:
+                with torch.cuda.stream(sa):
+                    a.md_run(xa, va, fa, 10, seed=9, sync=False)
+            if b is not None:
+                with torch.cuda.stream(sb):
+                    b.md_run(xb, vb, fb, 25, sync=False, **wmd)
+        if a is not None:
+            with torch.cuda.stream(sa):
+                assert a.sync_status() == 0
+            out["a"] = (xa.cpu(), fa.cpu())
+            a.close()
+        if b is not None:
+            with torch.cuda.stream(sb):
+                assert b.sync_status() == 0
+            out["b"] = (xb.cpu(), fb.cpu())
+            b.close()
+        return out
+
+    alone_a, alone_b = run("a")["a"], run("b")["b"]
+    both = run("ab", torch.cuda.Stream(), torch.cuda.Stream())
+    assert torch.isfinite(both["b"][1]).all() and torch.isfinite(both["a"][1]).all()
+    assert torch.equal(both["a"][0], alone_a[0]) and torch.equal(both["a"][1], alone_a[1])
+    assert torch.equal(both["b"][0], alone_b[0]) and torch.equal(both["b"][1], alone_b[1])
+
+
 # ---- >= 2 devices: switch themselves on where a second GPU is visible ---------------------------------------------------
 two_devices = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible HIP devices (one-GPU box)")
 
