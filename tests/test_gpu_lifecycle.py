@@ -1,0 +1,117 @@
+"""Handle life cycle: `gamd_create` ... `gamd_destroy` gives back what it took.
+
+A force provider in a serving process is created and destroyed many times (one handle per system size / per request class).
+Everything a handle owns is allocated by the library itself (`hipMalloc`, `hipHostMalloc`, event pools), not through torch's
+caching allocator, so `hipMemGetInfo` before and after a run of create / use / destroy cycles shows a leak directly.
+"""
+import gc
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS
+from gamd_amd import workloads
+
+pytestmark = pytest.mark.gpu
+MB = 1 << 20
+
+
+def _free_bytes():
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return torch.cuda.mem_get_info()[0]
+
+
+def _rss_bytes():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE")
+
+
+def _cycle(i):
+    """One create / use / destroy cycle; the configuration rotates through every kernel family and buffer set."""
+    from gamd_amd.engine import GamdForce
+    k = i % 6
+    if k == 0:      # LJ, exact rebuild every call, timing pools on
+        pos, box = workloads.lj_box(2000, seed=10 + i)
+        eng = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2), 2000, box, 10.2, scaler=SHIPPED_SCALERS["lj"])
+        eng.timing_enable(True)
+        x = torch.from_numpy(pos).float().cuda()
+        eng.forward(x)
+        eng.timing_read()
+    elif k == 1:    # LJ, Verlet skin + on-device Langevin run (candidate buffers, reference positions, event pools of the steps)
+        pos, box = workloads.lj_box(3000, seed=10 + i)
+        eng = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2), 3000, box, 10.2, scaler=SHIPPED_SCALERS["lj"],
+                        neighbor_skin=1.7)
+        x = torch.from_numpy(pos).float().cuda()
+        v = torch.from_numpy(workloads.maxwell_boltzmann(3000, seed=i)).float().cuda()
+        f = eng.forward(x, denormalize=True).clone()
+        eng.md_run(x, v, f, 20, seed=i)
+    elif k == 2:    # water, bond feature, bf16 edge MLP, Nose-Hoover chain (ke partials, chain state)
+        pos, box, species, bonds = workloads.water_box(300, seed=10 + i)
+        eng = GamdForce(make_state_dict(ModelConfig(kind="water", use_bond=True), 1, 2.9, 1.1), 900, box, 4.2, bond=bonds,
+                        scaler=SHIPPED_SCALERS["tip3p"], edge_dtype="bf16", neighbor_skin=0.7)
+        x = torch.from_numpy(pos).float().cuda()
+        v = torch.zeros_like(x)
+        f = eng.forward(x, species=species, denormalize=True).clone()
+        eng.md_run_nhc(x, v, f, 5, dt_ps=0.0005, mass_amu=workloads.MASS_O, mass_h_amu=workloads.MASS_H, temperature_k=300.0,
+                       species=species)
+    elif k == 3:    # several boxes per launch (per-box tables, scan scratch)
+        boxes = [workloads.lj_box(500, seed=100 + i + b) for b in range(4)]
+        eng = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 5.3, 1.6), 500, boxes[0][1], 7.5, n_boxes=4,
+                        scaler=SHIPPED_SCALERS["lj"])
+        x = torch.from_numpy(np.stack([p for p, _ in boxes])).float().cuda()
+        eng.forward(x)
+    elif k == 4:    # the 256 / 256 / 128 x 5 dynamic-box model (generic-width kernels), split-fp16
+        pos, box, species, _ = workloads.water_box(200, seed=10 + i)
+        cfg = ModelConfig(kind="dynbox", encoding_size=256, hidden_dim=128, edge_embedding_dim=256, conv_layer=5)
+        eng = GamdForce(make_state_dict(cfg, 2, 2.9, 1.1), 600, box, 4.2, edge_dtype="f16x3")
+        x = torch.from_numpy(pos).float().cuda()
+        eng.forward(x, species=species)
+    else:           # the reference's own 258-atom size (single-workgroup neighbour path), skin mode
+        pos, box = workloads.lj_box(258, seed=10 + i)
+        eng = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 5.3, 1.6), 258, box, 7.5, scaler=SHIPPED_SCALERS["lj"],
+                        neighbor_skin=1.25)
+        x = torch.from_numpy(pos).float().cuda()
+        v = torch.from_numpy(workloads.maxwell_boltzmann(258, seed=i)).float().cuda()
+        f = eng.forward(x, denormalize=True).clone()
+        eng.md_run(x, v, f, 50, seed=i)
+    torch.cuda.synchronize()
+    eng.close()
+
+
+def test_create_use_destroy_cycles_give_device_and_host_memory_back():
+    from gamd_amd.engine import GamdForce
+    for i in range(6):                       # first pass: code objects, torch's context, the library's lazy state
+        _cycle(i)
+    free0, rss0 = _free_bytes(), _rss_bytes()
+    # the instrument sees the library's allocations: a live 10 000-atom handle holds several hundred MiB
+    pos, box = workloads.lj_box(10000)
+    eng = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2), 10000, box, 10.2, scaler=SHIPPED_SCALERS["lj"])
+    eng.forward(torch.from_numpy(pos).float().cuda())
+    held = free0 - _free_bytes()
+    eng.close()
+    assert held > 300 * MB, held
+    assert free0 - _free_bytes() < 8 * MB
+    n = 30
+    for i in range(6, 6 + n):
+        _cycle(i)
+    free1, rss1 = _free_bytes(), _rss_bytes()
+    print(f"{n} cycles: device free {free0 / MB:.1f} -> {free1 / MB:.1f} MiB, host RSS {rss0 / MB:.1f} -> {rss1 / MB:.1f} MiB")
+    assert free0 - free1 < 8 * MB, (free0, free1)            # a leaked 2 000-atom handle alone is > 100 MiB
+    assert rss1 - rss0 < 64 * MB, (rss0, rss1)
+
+
+def test_close_is_idempotent_and_a_closed_engine_fails_loudly():
+    from gamd_amd.engine import GamdForce
+    from gamd_amd._lib import GamdError
+    pos, box = workloads.lj_box(500, seed=3)
+    eng = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 5.3, 1.6), 500, box, 7.5)
+    x = torch.from_numpy(pos).float().cuda()
+    eng.forward(x)
+    eng.close()
+    eng.close()
+    with pytest.raises((GamdError, ValueError, RuntimeError)):
+        eng.forward(x)
