@@ -14,8 +14,10 @@
  *     buffers overflowed and were regrown (the analogue of jax-md's
  *     did_buffer_overflow -> re-allocate, graph_utils.py:41-42), < 0 = error
  *     (text via gamd_last_error).  No exceptions cross the ABI.
- *   - one handle per GPU (holding one box, or gamd_config.n_boxes independent boxes), not thread-safe (the reference
- *     is single-threaded too).
+ *   - one handle per box (or per gamd_config.n_boxes independent boxes), any number of handles per GPU and per
+ *     process.  A HANDLE is not thread-safe (one caller at a time; the reference is single-threaded too); DIFFERENT
+ *     handles may be driven from different threads at the same time — the library keeps no mutable state outside the
+ *     handle, and gamd_last_error is per thread.
  *   - atoms keep the CALLER's order at the boundary; internally they are renumbered
  *     in cell order every call.
  */

@@ -115,3 +115,54 @@ def test_close_is_idempotent_and_a_closed_engine_fails_loudly():
     eng.close()
     with pytest.raises((GamdError, ValueError, RuntimeError)):
         eng.forward(x)
+
+
+def test_two_threads_each_with_its_own_handle_and_stream():
+    """include/gamd_hip.h: a handle is for one caller at a time, different handles may be driven from different threads at once
+    (ctypes releases the GIL around every call).  Two threads, two handles of different kernel families, own streams, 40 calls
+    each, against the same calls made one after the other."""
+    import threading
+    from gamd_amd.engine import GamdForce
+    pos, box = workloads.lj_box(4000, seed=5)
+    wpos, wbox, species, bonds = workloads.water_box(400, seed=6)
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    wsd = make_state_dict(ModelConfig(kind="water", use_bond=True), 1, 2.9, 1.1)
+    rng = np.random.default_rng(0)
+    xs = [torch.from_numpy(pos + rng.normal(0, 0.05, pos.shape)).float().cuda() for _ in range(8)]
+    ws = [torch.from_numpy(wpos + rng.normal(0, 0.01, wpos.shape)).float().cuda() for _ in range(8)]
+
+    def work_a(out, stream):
+        eng = GamdForce(sd, 4000, box, 10.2, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=1.7)
+        with torch.cuda.stream(stream):
+            for k in range(40):
+                out.append(eng.forward(xs[k % 8]).clone())
+            stream.synchronize()
+        eng.close()
+
+    def work_b(out, stream):
+        eng = GamdForce(wsd, 1200, wbox, 4.2, bond=bonds, scaler=SHIPPED_SCALERS["tip3p"], edge_dtype="f16x3")
+        with torch.cuda.stream(stream):
+            for k in range(40):
+                out.append(eng.forward(ws[k % 8], species=species).clone())
+            stream.synchronize()
+        eng.close()
+
+    ref_a, ref_b, got_a, got_b = [], [], [], []
+    work_a(ref_a, torch.cuda.Stream())
+    work_b(ref_b, torch.cuda.Stream())
+    errs = []
+
+    def guarded(fn, *a):
+        try:
+            fn(*a)
+        except Exception as e:                                         # surfaces in the main thread below
+            errs.append(e)
+
+    ta = threading.Thread(target=guarded, args=(work_a, got_a, torch.cuda.Stream()))
+    tb = threading.Thread(target=guarded, args=(work_b, got_b, torch.cuda.Stream()))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errs, errs
+    assert len(got_a) == 40 and len(got_b) == 40
+    assert all(torch.equal(g, r) for g, r in zip(got_a, ref_a))
+    assert all(torch.equal(g, r) for g, r in zip(got_b, ref_b))
+    assert torch.isfinite(got_a[-1]).all() and torch.isfinite(got_b[-1]).all()
