@@ -585,6 +585,22 @@ def main():
                          "bytes_algorithmic": 12.0 * w.n_atoms + 8.0 * n_edges})
         rl["kernels"] = kern
         rl["kernels_note"] = "k_edge_encode / k_node: live HIP events over the timed region; neighbour stage: 4 event-timed replays"
+    if single:
+        # "report also force-eval-only atom-evals/s" — the call the rollout drivers make once per step
+        # (predict_forces: neighbour stage + GNN, no integrator), synchronous like theirs, on the state the timed run left
+        # behind; device-resident positions (the PCIe-inclusive form of the call is in DESIGN.md section 5)
+        reps = 20
+        w.eng.forward(w.x, species=w.species, inplace=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            w.eng.forward(w.x, species=w.species, inplace=True)
+        torch.cuda.synchronize(dev)
+        fe = (time.perf_counter() - t0) / reps
+        line["force_eval_only"] = {"ms_per_eval": fe * 1e3, "value": w.n_atoms / fe, "unit": "atom-evals/s", "evals": reps,
+                                   "what": "gamd_forces: neighbour stage (" + ("Verlet-skin reuse" if w.uses_skin else "exact rebuild")
+                                           + ") + edge encoder + conv layers + decoder, one synchronous call per evaluation, "
+                                           "positions resident on the device, no integrator"}
     if single and not args.no_cpu_baseline and args.workload == "c2":
         line["cpu_baseline"] = cpu_baseline(w, dev)
     if single and not args.no_secondary and args.workload == "c2":

@@ -51,6 +51,11 @@ def test_default_line_has_the_contract_keys():
     assert abs(tr["step_ms"]["mean"] - d["ms_per_step"]) / d["ms_per_step"] < 0.05      # device events vs the host clock
     assert tr["regrown_in_timed"] is False and 0 <= tr["rebuilds_in_timed"] <= 6
     assert 0.0 < tr["rebuild_ms"] < 1.0 and tr["neighbour_stage_ms"]["reuse_step"] < tr["neighbour_stage_ms"]["rebuild_step"]
+    # the force-evaluation-only figure beside the MD step (one synchronous call = a step without the integrator
+    # plus the host round trip of the call)
+    fe = d["force_eval_only"]
+    assert fe["unit"] == "atom-evals/s" and abs(fe["value"] - 10000 / (fe["ms_per_eval"] * 1e-3)) / fe["value"] < 1e-6
+    assert 0.8 * d["ms_per_step"] < fe["ms_per_eval"] < 1.3 * d["ms_per_step"]
 
 
 def test_headline_steps_are_evenly_paced():
