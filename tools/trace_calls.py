@@ -13,6 +13,8 @@ rows=[]
 for f in glob.glob(d0+"/**/*kernel_trace.csv", recursive=True):
     rows+=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+for r in rows:
+    r["Kernel_Name"]=r["Kernel_Name"].replace("(anonymous namespace)::","").replace("void ","")
 d=collections.defaultdict(list)
 for r in rows:
     d[r["Kernel_Name"].split("(")[0][-40:]].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
