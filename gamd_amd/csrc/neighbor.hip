@@ -622,15 +622,15 @@ __device__ void d_fill_cells_batch(const NbrArgs& a, int tid) {
     }
 }
 
-// d_sort_gather for the cells wave, wave + 16, wave + 32, ... of this workgroup, CELL_BATCH cells at a time
-__device__ void d_sort_gather_batch(const NbrArgs& a, int wave, int lane) {
-    for (int k0 = wave; k0 < a.ncell; k0 += 16 * CELL_BATCH) {
+// d_sort_gather for the cells c_begin + wave, + 16, + 32, ... < c_end of this workgroup, CELL_BATCH cells at a time
+__device__ void d_sort_gather_batch(const NbrArgs& a, int wave, int lane, int c_begin, int c_end) {
+    for (int k0 = c_begin + wave; k0 < c_end; k0 += 16 * CELL_BATCH) {
         int s[CELL_BATCH], cnt[CELL_BATCH], v[CELL_BATCH], rank[CELL_BATCH];
 #pragma unroll
         for (int b = 0; b < CELL_BATCH; ++b) {
             const int k = k0 + 16 * b;
-            s[b] = k < a.ncell ? a.cell_start[k] : 0;
-            cnt[b] = k < a.ncell ? a.cell_start[k + 1] - s[b] : 0;
+            s[b] = k < c_end ? a.cell_start[k] : 0;
+            cnt[b] = k < c_end ? a.cell_start[k + 1] - s[b] : 0;
         }
 #pragma unroll
         for (int b = 0; b < CELL_BATCH; ++b) v[b] = (cnt[b] <= 64 && lane < cnt[b]) ? a.perm[s[b] + lane] : 0x7fffffff;
@@ -670,12 +670,22 @@ __device__ void d_cells_one_wg(const NbrArgs& c) {
     __syncthreads();
     d_fill_cells_batch(c, tid);
     __syncthreads();
-    d_sort_gather_batch(c, tid >> 6, tid & 63);
+    d_sort_gather_batch(c, tid >> 6, tid & 63, 0, c.ncell);
 }
 
 // Every call: wrap the positions and raise the rebuild flag if any atom has moved more than skin/2 since the
 // candidate list was built (or the host forces it).  jax-md does the same test in update_neighbor_lst
 // (graph_utils.py:36-44) with dr_threshold = cutoff/6.
+// has the atom at p moved more than skin / 2 from r?  (NaN positions count as moved.)  Without fp contraction: the one-atom and the
+// molecule form of the check then decide every borderline case alike, whatever kernel they are inlined into.
+__device__ __forceinline__ bool d_moved_beyond(const float4& p, const float4& r, const BoxDims& B, float skin_half2) {
+#pragma clang fp contract(off)
+    const float dx = gamd_min_image_wrapped(p.x - r.x, B.bx, B.hx);
+    const float dy = gamd_min_image_wrapped(p.y - r.y, B.by, B.hy);
+    const float dz = gamd_min_image_wrapped(p.z - r.z, B.bz, B.hz);
+    return !(((dx * dx + dy * dy) + dz * dz) <= skin_half2);
+}
+
 __device__ __forceinline__ bool d_skin_check(const NbrArgs& a, int i) {
     const BoxDims B = box_dims(a, box_id(a, i));
     float4 p;
@@ -686,15 +696,47 @@ __device__ __forceinline__ bool d_skin_check(const NbrArgs& a, int i) {
     a.pos_w[i] = p;
     bool moved = a.force_rebuild != 0;
     if (!moved) {
-        const float4 r = a.ref_pos[i];
-        const float dx = gamd_min_image_wrapped(p.x - r.x, B.bx, B.hx);
-        const float dy = gamd_min_image_wrapped(p.y - r.y, B.by, B.hy);
-        const float dz = gamd_min_image_wrapped(p.z - r.z, B.bz, B.hz);
-        moved = !(((dx * dx + dy * dy) + dz * dz) <= a.skin_half2);      // NaN positions force a rebuild too
+        moved = d_moved_beyond(p, a.ref_pos[i], B, a.skin_half2);       // NaN positions force a rebuild too
     }
     // current position in the (so far frozen) sorted order; a rebuild later in this call overwrites pos_s and the order
     p.w = node_feature(a, i);
     a.pos_s[a.inv_perm[i]] = p;
+    return moved;
+}
+
+// The same check for the (up to) three atoms i0 .. i0 + 2 of a rigid molecule with every load issued before the first store: the
+// one-atom form called three times is three dependent chains (position -> stores -> next position ...) behind the integrator,
+// because the compiler may not move a load across the stores of the previous atom.  Same operations per atom, same bits.
+__device__ __forceinline__ bool d_skin_check_mol(const NbrArgs& a, int i0) {
+    float px[3][3];
+    float4 r[3];
+    int ip[3];
+    float w[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = i0 + k < a.n ? i0 + k : a.n - 1;
+        px[k][0] = a.pos[3 * i + 0]; px[k][1] = a.pos[3 * i + 1]; px[k][2] = a.pos[3 * i + 2];
+        r[k] = a.ref_pos[i];
+        ip[k] = a.inv_perm[i];
+        w[k] = node_feature(a, i);
+    }
+    bool moved = a.force_rebuild != 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = i0 + k;
+        if (i < a.n) {
+            const BoxDims B = box_dims(a, box_id(a, i));
+            float4 p;
+            p.x = gamd_remainder(px[k][0], B.bx);
+            p.y = gamd_remainder(px[k][1], B.by);
+            p.z = gamd_remainder(px[k][2], B.bz);
+            p.w = 0.f;
+            a.pos_w[i] = p;
+            if (!a.force_rebuild) moved |= d_moved_beyond(p, r[k], B, a.skin_half2);
+            p.w = w[k];
+            a.pos_s[ip[k]] = p;
+        }
+    }
     return moved;
 }
 
@@ -722,7 +764,7 @@ __global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) 
     }
     bool moved = false;
     if ((do_second | do_first) && md.use_rigid) {          // the thread that moved the molecule checks its three atoms
-        for (int k = 0; k < 3 && 3 * i + k < a.n; ++k) moved |= d_skin_check(a, 3 * i + k);
+        if (3 * i < a.n) moved = d_skin_check_mol(a, 3 * i);
     } else if (i < a.n) {
         moved = d_skin_check(a, i);
     }
@@ -735,6 +777,104 @@ __global__ void k_skin_check(NbrArgs a, MdArgs md, int do_second, int do_first) 
 __global__ void __launch_bounds__(1024) k_cells_one_wg(NbrArgs a) {
     if (a.counters[CNT_REBUILD] == 0) return;
     d_cells_one_wg(cand_args(a));
+}
+
+// The same rebuild by CELLS_SL_WGS workgroups that never wait for each other.  One workgroup is bound by what ONE compute unit's
+// vector-memory path can do with ~10 scattered passes over the atoms (74-80 us at 6 000 atoms, a rebuild every ~10 steps at C5:
+// profiles/r05_experiments.md section 7); several workgroups normally need device-wide barriers between bin | scan | fill | sort.
+// They do not if every workgroup repeats the cheap part: each one histograms ALL atoms into its own LDS copy of the cell
+// counters (a coalesced stream of 12 B per atom, LDS atomics) and scans it, so each knows every cell's first slot; then it takes
+// the cells whose first slot lies in its 1 / CELLS_SL_WGS share of the sorted order, streams the atoms a second time to collect
+// the members of those cells (LDS fill counters, perm in its own slots of global memory) and sorts / gathers them as above.
+// Everything a workgroup reads back from global memory it has written itself.  Outputs (pos_w, ref_pos, cell_of, cell_start,
+// perm, pos_s, inv_perm) are the values the one-workgroup form writes: the order inside a cell is by atom id in both.
+constexpr int CELLS_SL_MAXCELL = 4096;
+constexpr int CELLS_SL_WGS = 32;
+
+struct BinOut { float4 p; int c; };
+__device__ __forceinline__ BinOut d_wrap_cell(const NbrArgs& a, int i, float px, float py, float pz) {
+    const int bi = box_id(a, i);
+    const BoxDims B = box_dims(a, bi);
+    BinOut o;
+    o.p.x = gamd_remainder(px, B.bx);                 // graph_utils.py:31 jnp.mod(pos, box)
+    o.p.y = gamd_remainder(py, B.by);
+    o.p.z = gamd_remainder(pz, B.bz);
+    o.p.w = 0.f;
+    const BoxCells G = box_cells(a, bi);
+    o.c = G.base + (cell_coord(o.p.x, B.bx, G.nx) * G.ny + cell_coord(o.p.y, B.by, G.ny)) * G.nz + cell_coord(o.p.z, B.bz, G.nz);
+    return o;
+}
+
+__global__ void __launch_bounds__(1024) k_cells_sliced(NbrArgs a0) {
+    if (a0.counters[CNT_REBUILD] == 0) return;
+    __shared__ int s_cnt[CELLS_SL_MAXCELL];           // histogram, later the fill counters of this workgroup's cells
+    __shared__ int s_start[CELLS_SL_MAXCELL + 1];
+    __shared__ int s_range[2];
+    const NbrArgs a = cand_args(a0);
+    const int tid = threadIdx.x, w = blockIdx.x, nwg = gridDim.x;
+    for (int k = tid; k < a.ncell; k += 1024) s_cnt[k] = 0;
+    __syncthreads();
+    // pass 1: histogram of all atoms
+    for (int base = tid; base < a.n; base += 1024 * CELL_BATCH) {
+        float px[CELL_BATCH], py[CELL_BATCH], pz[CELL_BATCH];
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) {
+            const int i = base + 1024 * b;
+            if (i < a.n) { px[b] = a.pos[3 * i + 0]; py[b] = a.pos[3 * i + 1]; pz[b] = a.pos[3 * i + 2]; }
+        }
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) {
+            const int i = base + 1024 * b;
+            if (i < a.n) atomicAdd(&s_cnt[d_wrap_cell(a, i, px[b], py[b], pz[b]).c], 1);
+        }
+    }
+    __syncthreads();
+    block_exclusive_scan(a.ncell, [&](int i) { return s_cnt[i]; }, s_start);
+    __syncthreads();
+    // this workgroup's cells: first slot in [w, w + 1) * chunk of the sorted order (trailing empty cells go to the last one)
+    if (tid < 2) {
+        const int which = w + tid;
+        int c;
+        if (which == 0) c = 0;
+        else if (which >= nwg) c = a.ncell;
+        else {
+            const int chunk = (a.n + nwg - 1) / nwg;
+            const int target = which * chunk < a.n ? which * chunk : a.n;
+            int lo = 0, hi = a.ncell;                 // first c in [0, ncell] with s_start[c] >= target (s_start[ncell] = n)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_start[mid] >= target) hi = mid; else lo = mid + 1; }
+            c = lo;
+        }
+        s_range[tid] = c;
+    }
+    for (int k = tid; k < a.ncell; k += 1024) s_cnt[k] = 0;
+    __syncthreads();
+    const int c0 = s_range[0], c1 = s_range[1];
+    // (cell_start[c1] is written by this workgroup AND by the owner of cell c1, with the same value: the sort below reads it)
+    for (int k = c0 + tid; k <= c1; k += 1024) a.cell_start[k] = s_start[k];
+    // pass 2: the members of my cells -> my slots of perm; their wrapped positions / cell ids
+    for (int base = tid; base < a.n; base += 1024 * CELL_BATCH) {
+        float px[CELL_BATCH], py[CELL_BATCH], pz[CELL_BATCH];
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) {
+            const int i = base + 1024 * b;
+            if (i < a.n) { px[b] = a.pos[3 * i + 0]; py[b] = a.pos[3 * i + 1]; pz[b] = a.pos[3 * i + 2]; }
+        }
+#pragma unroll
+        for (int b = 0; b < CELL_BATCH; ++b) {
+            const int i = base + 1024 * b;
+            if (i < a.n) {
+                const BinOut o = d_wrap_cell(a, i, px[b], py[b], pz[b]);
+                if (o.c >= c0 && o.c < c1) {
+                    a.pos_w[i] = o.p;
+                    if (a.ref_pos) a.ref_pos[i] = o.p;
+                    a.cell_of[i] = o.c;
+                    a.perm[s_start[o.c] + atomicAdd(&s_cnt[o.c], 1)] = i;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    d_sort_gather_batch(a, tid >> 6, tid & 63, c0, c1);
 }
 
 // ---- small systems (n <= 1024), Verlet-skin mode: everything in front of the exact filter in ONE workgroup ------------
@@ -767,7 +907,7 @@ __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int d
     }
     bool moved = false;
     if ((do_second | do_first) && md.use_rigid) {          // the thread that moved the molecule checks its three atoms
-        for (int k = 0; k < 3 && 3 * tid + k < a.n; ++k) moved |= d_skin_check(a, 3 * tid + k);
+        if (3 * tid < a.n) moved = d_skin_check_mol(a, 3 * tid);
     } else if (tid < a.n) {
         moved = d_skin_check(a, tid);
     }
@@ -1144,7 +1284,9 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
         GAMD_CHECK_LAUNCH();
     }
     if (a.cells_one_wg && a.n <= 16 * 1024) {
-        hipLaunchKernelGGL(k_cells_one_wg, dim3(1), dim3(1024), 0, st, a); GAMD_CHECK_LAUNCH();
+        if (a.ncell <= CELLS_SL_MAXCELL) hipLaunchKernelGGL(k_cells_sliced, dim3(CELLS_SL_WGS), dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL(k_cells_one_wg, dim3(1), dim3(1024), 0, st, a);
+        GAMD_CHECK_LAUNCH();
     } else {
         // frequent rebuilds, or more atoms than one workgroup should bin: the four cell-list phases as grid-wide kernels, every
         // one gated on the flag k_skin_check has just written

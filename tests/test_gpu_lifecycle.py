@@ -166,3 +166,60 @@ def test_two_threads_each_with_its_own_handle_and_stream():
     assert all(torch.equal(g, r) for g, r in zip(got_a, ref_a))
     assert all(torch.equal(g, r) for g, r in zip(got_b, ref_b))
     assert torch.isfinite(got_a[-1]).all() and torch.isfinite(got_b[-1]).all()
+
+
+@pytest.mark.parametrize("case", ["water6000", "lj10000", "batch38x258", "dilute_many_cells", "overfull_cells", "tiny_box_one_cell"])
+def test_candidate_rebuild_by_sliced_workgroups_sorts_like_the_exact_build(case):
+    """neighbor.hip k_cells_sliced: 32 workgroups that each histogram all atoms and then sort their own share of the cells, with no
+    barrier between them.  The sorted order (perm) of a skin-mode handle after a candidate rebuild equals that of an exact build
+    on the same cell grid (a handle with cutoff = rc + skin), its edge set and forces those of the handle that rebuilds exactly
+    every call — for the BASELINE water / LJ sizes, a batch of boxes
+    (cells numbered box after box), a grid of more than 4 096 cells (the one-workgroup form still serves those), cells with more
+    than 64 atoms (serial sort fallback inside a slice) and a box that is one cell."""
+    from gamd_amd.engine import GamdForce
+    kw, fkw = dict(scaler=SHIPPED_SCALERS["lj"]), {}
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+    if case == "water6000":
+        pos, box, species, bonds = workloads.water_box(2000, mol_per_20A3=251.0, seed=3456)
+        sd = make_state_dict(ModelConfig(kind="water", use_bond=True), 1, 2.9, 1.1)
+        n, rc, skin = 6000, 4.2, 0.7
+        kw, fkw = dict(bond=bonds, scaler=SHIPPED_SCALERS["tip3p"]), dict(species=species)
+    elif case == "lj10000":
+        pos, box = workloads.lj_box(10000)
+        n, rc, skin = 10000, 10.2, 1.7
+    elif case == "batch38x258":
+        boxes = [workloads.lj_box(258, seed=50 + b) for b in range(38)]
+        pos, box = np.concatenate([p for p, _ in boxes]), boxes[0][1]
+        n, rc, skin = 258, 7.5, 1.25
+        kw["n_boxes"] = 38
+    elif case == "dilute_many_cells":
+        rng = np.random.default_rng(7)
+        box = 120.0
+        pos = rng.uniform(0, box, (5000, 3))
+        n, rc, skin = 5000, 5.0, 1.0                     # 20^3 = 8 000 cells > 4 096: k_cells_one_wg
+    elif case == "overfull_cells":
+        rng = np.random.default_rng(8)
+        box = 24.0
+        pos = rng.uniform(0, box, (1500, 3))             # 2^3 cells of ~190 atoms
+        n, rc, skin = 1500, 9.0, 1.5
+    else:
+        rng = np.random.default_rng(9)
+        box = 9.0
+        pos = rng.uniform(0, box, (1100, 3))
+        n, rc, skin = 1100, 7.0, 1.0
+    from helpers import edge_set, rel_err
+    x = torch.from_numpy(np.ascontiguousarray(pos)).float().cuda()
+    exact = GamdForce(sd, n, box, rc, **kw)
+    grid = GamdForce(sd, n, box, rc + skin, **kw)          # exact build on the candidate pass's cell grid (cells >= rc + skin)
+    skinned = GamdForce(sd, n, box, rc, neighbor_skin=skin, **kw)
+    for step, xs in enumerate((x, x + torch.from_numpy(np.random.default_rng(1).normal(0, 0.6 * skin, pos.shape)).float().cuda())):
+        # (second round: the atoms have moved by more than half the skin: another rebuild, from a used state)
+        f0 = exact.forward(xs, **fkw)
+        grid.forward(xs, **fkw)
+        f1 = skinned.forward(xs, **fkw)
+        assert skinned.skin_stats()[0] == step + 1                        # the call rebuilt the candidate list
+        assert np.array_equal(grid.debug_perm(), skinned.debug_perm())    # same cells, same order inside every cell
+        e0, e1 = edge_set(exact.debug_edges()), edge_set(skinned.debug_edges())
+        assert len(e0) == len(e1) and np.array_equal(np.sort(e0), np.sort(e1))
+        assert torch.isfinite(f0).all() and rel_err(f1.cpu().numpy(), f0.cpu().numpy()) < 1e-5
+    exact.close(); grid.close(); skinned.close()
