@@ -7,8 +7,6 @@ out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 B="python3 bench.py --no-cpu-baseline --no-secondary"
-python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-python3 bench.py --no-cpu-baseline --no-secondary --edge-dtype f16x3 > $out/bench_f16x3.json 2>> $out/bench_default.err
 for w in c2 c3 c5 c5b c1 c1_batch c2_batch8 dft; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -- $B --steps 50 --warmup 5 --workload $w > $out/trace_$w.log 2>&1
   python3 tools/profile_summary.py stats $out/trace_$w > $out/trace_$w.md
@@ -42,6 +40,11 @@ for w in c5 c1 10000; do python3 tools/node_marks.py $w > $out/node_marks_$w.log
 # conv-layer kernel: scheduling variants A/B and the s_memtime marks (profiling build)
 python3 tools/conv_variants.py 3592 0 8 520 1544 3848 > $out/conv_variants_sched.log 2>&1
 python3 tools/conv_variants.py 3593 --cycles > $out/conv_variants_cycles.log 2>&1
+# the bench records LAST, with this run's counter records in place: bench.py reports roofline.traffic / neighbour_gather_hbm only
+# for the kernel sources they were measured on (hash), and on this box profiles/ still holds the previous sources' records
+cp $out/pmc_conv_edge.json profiles/pmc_conv_edge.json; cp $out/gather_hbm.json profiles/gather_hbm.json
+python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
+python3 bench.py --no-cpu-baseline --no-secondary --edge-dtype f16x3 > $out/bench_f16x3.json 2>> $out/bench_default.err
 # keep the merge-back small: only the summaries and the per-kernel stats csv
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*agent_info.csv" -delete
 ls -la $out | head -50
