@@ -473,19 +473,42 @@ __device__ __forceinline__ void d_scan_deg(const NbrArgs& a) {
 
 __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
     GAMD_GATE();
-    if (!a.cand_pass && a.cand_stride > 0 && threadIdx.x == 0 && a.counters[CNT_REBUILD]) {
+    if (!a.cand_pass && a.cand_stride > 0 && a.counters[CNT_REBUILD]) {
         // skin path, the fixed-stride candidate rows were rebuilt in this call (k_filter_count): publish their size; a row
         // longer than the stride is an overflow (the list is truncated: freeze, the host regrows to 1.25 x longest row x n
-        // and resumes)
-        const int longest = a.counters[CNT_CAND_MAX];
-        a.sticky[STICKY_NCAND] = a.counters[CNT_NCAND];
-        a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
-        if (longest > a.cand_stride) {
-            const long long need = (long long)longest * a.n;
-            a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
-            a.sticky[STICKY_CAND_OVERFLOW] = 1;
-            a.devflags[DEVFLAG_FROZEN] = 1;
+        // and resumes).  Total and longest row are reduced HERE from the row lengths (one coalesced pass of this workgroup
+        // over cand_deg): as a pair of global atomics per workgroup of the count pass they were 1 500 operations on two
+        // addresses at 6 000 atoms, which the L2 serialises — 13 of the 36 us of that kernel on a rebuild step.
+        __shared__ int s_ctot[16], s_cmax[16];
+        int tot = 0, longest = 0;
+        for (int i = threadIdx.x; i < a.n; i += 1024) {
+            const int w = a.cand_deg[i];
+            tot += w < a.cand_stride ? w : a.cand_stride;
+            longest = w > longest ? w : longest;
         }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            tot += __shfl_xor(tot, d, 64);
+            const int o = __shfl_xor(longest, d, 64);
+            longest = o > longest ? o : longest;
+        }
+        if ((threadIdx.x & 63) == 0) { s_ctot[threadIdx.x >> 6] = tot; s_cmax[threadIdx.x >> 6] = longest; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            tot = 0; longest = 0;
+            for (int w = 0; w < 16; ++w) { tot += s_ctot[w]; longest = s_cmax[w] > longest ? s_cmax[w] : longest; }
+            a.counters[CNT_NCAND] = tot;
+            a.counters[CNT_CAND_MAX] = longest;
+            a.sticky[STICKY_NCAND] = tot;
+            a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
+            if (longest > a.cand_stride) {
+                const long long need = (long long)longest * a.n;
+                a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
+                a.sticky[STICKY_CAND_OVERFLOW] = 1;
+                a.devflags[DEVFLAG_FROZEN] = 1;
+            }
+        }
+        __syncthreads();
     }
     d_scan_deg(a);
 }
@@ -1059,20 +1082,10 @@ __global__ void __launch_bounds__(256) k_filter_count(NbrArgs a) {
         w += __popc(m);
         cnt += __popc(half_ballot(edge));
     });
-    // total and longest row: one pair of global atomics per workgroup, not per atom (same-address atomics serialise)
-    __shared__ int s_tot, s_max;
-    if (threadIdx.x == 0) { s_tot = 0; s_max = 0; }
-    __syncthreads();
+    // (total and longest row: k_scan_deg reduces them from cand_deg)
     if (live && l == 0) {
         a.cand_deg[ctr] = w;
         a.deg[ctr] = cnt + (a.self_loop ? 1 : 0);
-        atomicAdd(&s_tot, w < a.cand_stride ? w : a.cand_stride);
-        atomicMax(&s_max, w);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&a.counters[CNT_NCAND], s_tot);
-        atomicMax(&a.counters[CNT_CAND_MAX], s_max);
     }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.ncell; k += gridDim.x * blockDim.x) { a.cell_cnt[k] = 0; a.cell_fill[k] = 0; }
 }
