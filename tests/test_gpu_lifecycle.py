@@ -1,8 +1,12 @@
-"""Handle life cycle: `gamd_create` ... `gamd_destroy` gives back what it took.
+"""Handle life cycle, threads, and the barrier-free multi-workgroup cell build.
+
+`gamd_create` ... `gamd_destroy` gives back what it took:
 
 A force provider in a serving process is created and destroyed many times (one handle per system size / per request class).
 Everything a handle owns is allocated by the library itself (`hipMalloc`, `hipHostMalloc`, event pools), not through torch's
 caching allocator, so `hipMemGetInfo` before and after a run of create / use / destroy cycles shows a leak directly.
+Different handles may be driven from different threads at once (include/gamd_hip.h).  The candidate rebuild's cell build runs on
+32 workgroups that never wait for each other (neighbor.hip, k_cells_sliced): checked against the exact build on the same grid.
 """
 import gc
 import os
