@@ -1053,6 +1053,154 @@ __global__ void __launch_bounds__(256) k_filter(NbrArgs a) {
     }
 }
 
+// ---- fill pass of the exact filter that scans the degrees itself (one box, 1 024 < n <= 16 384) ---------------------------
+// k_filter_count | k_scan_deg | k_filter<true> is count | one workgroup | fill: the single-workgroup scan costs ~6 us plus a
+// kernel boundary on every step.  Here every fill workgroup (8 rows) computes the exclusive prefixes it needs itself — the sum of
+// deg[] and the number of off-boundary segment starts over the rows in front of it, 4 096 rows per pass through registers (the
+// arithmetic of d_scan_deg_fast) — publishes row_ptr / na_excl of its own rows, fills them, and writes the chunk metadata of the
+// chunks that start in them from deg[] alone.  The workgroup that holds the last row publishes the totals (and, on a rebuild
+// step, the size of the new candidate rows: what k_scan_deg did).  Same row_ptr / na_excl / col / erow / chunk arrays.
+struct ShiftedRows {
+    const int* p; int r0;
+    __device__ __forceinline__ int operator[](int i) const { return p[i - r0]; }
+};
+
+__global__ void __launch_bounds__(256) k_filter_fill_scan(NbrArgs a) {
+    constexpr int IPT = 16, SPAN = 256 * IPT, ROWS = 8;
+    __shared__ int s_w[2][4];
+    __shared__ int s_rp[ROWS + 1], s_na[ROWS + 1];               // exclusive prefixes at rows r0 .. r0 + 8
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r0 = blockIdx.x * ROWS;
+    const int r_end = r0 + ROWS < a.n ? r0 + ROWS : a.n;         // rows [0, r_end) are summed; prefixes wanted at r0 .. r_end
+    const bool last = r_end == a.n;
+    int carry_rp = 0, carry_na = 0;
+    for (int base = 0; base < r_end; base += SPAN) {
+        const int i0 = base + tid * IPT;
+        int v[IPT];
+        if (i0 + IPT <= r_end) {
+#pragma unroll
+            for (int q = 0; q < IPT / 4; ++q) {
+                const int4 t = *reinterpret_cast<const int4*>(a.deg + i0 + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) v[k] = (i0 + k < r_end) ? a.deg[i0 + k] : 0;
+        }
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) mine += v[k];
+        int x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        if (lane == 63) s_w[0][wv] = x;
+        __syncthreads();
+        int run = carry_rp + x - mine, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int t = s_w[0][w]; if (w < wv) run += t; tot += t; }
+        int f[IPT], mine2 = 0;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int i = i0 + k;
+            if (i >= r0 && i < r_end) s_rp[i - r0] = run;
+            f[k] = (i < r_end && v[k] > 0 && (run % GAMD_CHUNK) != 0) ? 1 : 0;
+            mine2 += f[k];
+            run += v[k];
+        }
+        int y2 = mine2;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(y2, d, 64); if (lane >= d) y2 += y; }
+        if (lane == 63) s_w[1][wv] = y2;
+        __syncthreads();
+        int run2 = carry_na + y2 - mine2, tot2 = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int t = s_w[1][w]; if (w < wv) run2 += t; tot2 += t; }
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int i = i0 + k;
+            if (i >= r0 && i < r_end) s_na[i - r0] = run2;
+            run2 += f[k];
+        }
+        carry_rp += tot; carry_na += tot2;
+        __syncthreads();                                         // s_w is rewritten by the next pass
+    }
+    if (tid == 0) { s_rp[r_end - r0] = carry_rp; s_na[r_end - r0] = carry_na; }
+    __syncthreads();
+    if (tid <= r_end - r0 && (tid < r_end - r0 || last)) { a.row_ptr[r0 + tid] = s_rp[tid]; a.na_excl[r0 + tid] = s_na[tid]; }
+    const int E_all = carry_rp;                                  // (only the last workgroup's value is the total)
+    if (last) {
+        if (a.counters[CNT_REBUILD]) {
+            // the fixed-stride candidate rows were rebuilt in this call (k_filter_count): publish their size; a row longer than
+            // the stride is an overflow (the list is truncated: freeze, the host regrows to 1.25 x longest row x n and resumes)
+            int ctot = 0, longest = 0;
+            for (int i = tid; i < a.n; i += 256) {
+                const int w = a.cand_deg[i];
+                ctot += w < a.cand_stride ? w : a.cand_stride;
+                longest = w > longest ? w : longest;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                ctot += __shfl_xor(ctot, d, 64);
+                const int o = __shfl_xor(longest, d, 64);
+                longest = o > longest ? o : longest;
+            }
+            if (lane == 0) { s_w[0][wv] = ctot; s_w[1][wv] = longest; }
+            __syncthreads();
+            if (tid == 0) {
+                ctot = (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]);
+                longest = 0;
+                for (int w = 0; w < 4; ++w) longest = s_w[1][w] > longest ? s_w[1][w] : longest;
+                a.counters[CNT_NCAND] = ctot;
+                a.counters[CNT_CAND_MAX] = longest;
+                a.sticky[STICKY_NCAND] = ctot;
+                a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
+                if (longest > a.cand_stride) {
+                    const long long need = (long long)longest * a.n;
+                    a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
+                    a.sticky[STICKY_CAND_OVERFLOW] = 1;
+                    a.devflags[DEVFLAG_FROZEN] = 1;
+                }
+            }
+        }
+        if (tid == 0) {
+            a.counters[CNT_E] = E_all;
+            a.counters[CNT_PIECES] = (E_all + GAMD_CHUNK - 1) / GAMD_CHUNK + carry_na;
+            if ((long long)E_all > a.e_cap) {
+                a.counters[CNT_OVERFLOW] = 1; a.sticky[STICKY_EDGE_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1;
+            }
+            a.counters[CNT_TILES] = (E_all + GAMD_TILE - 1) / GAMD_TILE;
+            // the second chunk of a last tile that is at most half full
+            const long long E = (long long)E_all > a.e_cap ? a.e_cap : (long long)E_all;
+            const long long n_chunks = 2 * ((E + GAMD_TILE - 1) / GAMD_TILE);
+            if (n_chunks > 0 && (n_chunks - 1) * GAMD_CHUNK >= E) { a.chunk_piece[n_chunks - 1] = 0; a.chunk_mask[n_chunks - 1] = 0; }
+        }
+    }
+    // rows of this workgroup: one half-wave per atom
+    const int ctr = (blockIdx.x * 256 + tid) >> 5, l = tid & 31;
+    d_filter<true>(a, ctr, l, ShiftedRows{s_rp, r0});
+    // chunk metadata of the 16-edge chunks that START in this half-wave's row, one lane per chunk: an edge closes a segment iff it
+    // is the last of its row; the rows behind this one are walked through deg[] (complete since the count pass)
+    if (ctr < a.n) {
+        const long long rp = s_rp[ctr - r0], re = s_rp[ctr - r0 + 1];
+        const int na_incl = s_na[ctr - r0] + ((re > rp && (rp % GAMD_CHUNK) != 0) ? 1 : 0);
+        for (long long c = (rp + GAMD_CHUNK - 1) / GAMD_CHUNK + l; c * GAMD_CHUNK < re && c * GAMD_CHUNK < a.e_cap; c += 32) {
+            const long long x0 = c * GAMD_CHUNK;
+            a.chunk_piece[c] = (int)c + na_incl;
+            unsigned mask = 0;
+            int at = ctr;
+            long long end = re;                                  // end of row `at`
+            for (int r = 0; r < GAMD_CHUNK; ++r) {
+                const long long xe = x0 + r;
+                if (xe >= a.e_cap) break;
+                while (end <= xe && at + 1 < a.n) { ++at; end += a.deg[at]; }
+                if (end <= xe) break;                            // behind the last edge
+                if (xe == end - 1) mask |= 1u << r;
+            }
+            a.chunk_mask[c] = mask;
+        }
+    }
+}
+
 // ---- count pass of the exact filter for n > 1024, carrying the candidate fill ---------------------------------------------
 // One half-wave per centre atom.
 //   reuse step    the exact cutoff on the atom's fixed-width candidate row -> deg
@@ -1287,8 +1435,8 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
         return 0;
     }
     // counters: ping-pong blocks (k_skin_check clears the other one) or one memset; the cell counters are left zero by the
-    // rebuild's last kernel.  Five launches per reuse step: check (+ integrator halves) | gated cell build | count (+ candidate
-    // fill on a rebuild step) | row scan | fill (+ chunk metadata).
+    // rebuild's last kernel.  Four launches per reuse step: check (+ integrator halves) | gated cell build | count (+ candidate
+    // fill on a rebuild step) | fill with its own row scan (+ chunk metadata); batches of boxes and n > 16 384: row scan | fill.
     if (!a.counters_next) { e = hipMemsetAsync(a.counters, 0, sizeof(int) * CNT_COUNT, st); if (e) return (int)e; }
     {
         MdArgs md{};
@@ -1318,6 +1466,11 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
     NbrArgs x = a;
     x.ref_pos = nullptr;
     hipLaunchKernelGGL(k_filter_count, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
+    if (a.bx.n_boxes <= 1 && a.n <= 16 * 1024 && a.cand_stride > 0) {
+        // one box: the fill pass scans the degrees itself (4 launches per reuse step)
+        hipLaunchKernelGGL(k_filter_fill_scan, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(k_scan_deg, dim3(1), dim3(1024), 0, st, x); GAMD_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_filter<true>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
     return 0;
