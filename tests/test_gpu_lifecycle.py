@@ -227,3 +227,29 @@ def test_candidate_rebuild_by_sliced_workgroups_sorts_like_the_exact_build(case)
         assert len(e0) == len(e1) and np.array_equal(np.sort(e0), np.sort(e1))
         assert torch.isfinite(f0).all() and rel_err(f1.cpu().numpy(), f0.cpu().numpy()) < 1e-5
     exact.close(); grid.close(); skinned.close()
+
+
+@pytest.mark.parametrize("n,box,rc", [(3000, 100.0, 6.0), (1030, 60.0, 5.0), (16384, 150.0, 6.0), (5000, 40.0, 6.0)])
+def test_fill_pass_with_its_own_row_scan_on_rows_of_every_kind(n, box, rc):
+    """neighbor.hip k_filter_fill_scan (one box, 1 024 < n <= 16 384): the fill workgroups compute their own row pointers.  The
+    `md_module.get_neighbor` flavour has no self edges, so a dilute gas has EMPTY rows, rows that start on and off 16-edge chunk
+    boundaries and chunks spanning many rows; sizes just above 1 024, at 16 384 (the last size on this path) and a dense box.
+    Edge set, per-row degrees and forces against the handle that rebuilds exactly (k_count | k_scan_deg | k_fill | k_chunk_meta),
+    over three calls with moving atoms."""
+    from gamd_amd.engine import GamdForce
+    from helpers import edge_set, rel_err
+    rng = np.random.default_rng(n)
+    pos = rng.uniform(0, box, (n, 3))
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 5.0, 1.5)
+    exact = GamdForce(sd, n, box, rc, nbr_flavour="torch")
+    skinned = GamdForce(sd, n, box, rc, nbr_flavour="torch", neighbor_skin=rc / 6.0)
+    for step in range(3):
+        x = torch.from_numpy(pos + step * rng.normal(0, 0.1, pos.shape)).float().cuda()
+        f0, f1 = exact.forward(x), skinned.forward(x)
+        e0, e1 = exact.debug_edges(), skinned.debug_edges()
+        assert e0.shape == e1.shape and np.array_equal(edge_set(e0), edge_set(e1))
+        assert np.array_equal(np.bincount(e0[0], minlength=n), np.bincount(e1[0], minlength=n))
+        assert (np.bincount(e0[0], minlength=n) == 0).any() or box < 50.0        # the dilute cases do have empty rows
+        assert torch.isfinite(f1).all() and rel_err(f1.cpu().numpy(), f0.cpu().numpy()) < 1e-5
+        assert exact.counts()[:2] != (0, 0) and skinned.counts()[0] == exact.counts()[0]
+    exact.close(); skinned.close()
