@@ -253,3 +253,32 @@ def test_fill_pass_with_its_own_row_scan_on_rows_of_every_kind(n, box, rc):
         assert torch.isfinite(f1).all() and rel_err(f1.cpu().numpy(), f0.cpu().numpy()) < 1e-5
         assert exact.counts()[:2] != (0, 0) and skinned.counts()[0] == exact.counts()[0]
     exact.close(); skinned.close()
+
+
+def test_host_species_are_uploaded_once_and_outlive_an_asynchronous_run():
+    """engine._dev_species: the device copy of a host-side species array belongs to the engine (kernels of an md_run(sync=False)
+    still read it after the call has returned) and is reused while the content is the same — same pointer, so the library's
+    O,H,H layout check (a device -> host copy + stream synchronisation) runs once, not once per call.  Changed content or another
+    stream gets its own copy."""
+    from gamd_amd.engine import GamdForce
+    pos, box, species, bonds = workloads.water_box(300, seed=12, jitter=0.0, wrap=False)
+    eng = GamdForce(make_state_dict(ModelConfig(kind="water", use_bond=True), 1, 2.9, 1.1), 900, box, 4.2, bond=bonds,
+                    scaler=SHIPPED_SCALERS["tip3p"], neighbor_skin=0.7)
+    x = torch.from_numpy(pos).float().cuda()
+    v = torch.zeros_like(x)
+    f = eng.forward(x, species=species, denormalize=True).clone()
+    p0 = eng._species_cache[1].data_ptr()
+    kw = dict(dt_ps=0.0005, mass_amu=workloads.MASS_O, mass_h_amu=workloads.MASS_H, temperature_k=300.0, rigid_water=True,
+              r_oh=workloads.TIP3P_R_OH, r_hh=workloads.TIP3P_R_HH, species=species, seed=1)
+    for _ in range(3):
+        eng.md_run(x, v, f, 5, sync=False, **kw)
+        assert eng._species_cache[1].data_ptr() == p0
+    assert eng.sync_status() == 0 and torch.isfinite(x).all()
+    eng.forward(x, species=species.copy())                                 # another array, same content: same copy
+    assert eng._species_cache[1].data_ptr() == p0
+    flipped = species.copy(); flipped[0], flipped[1] = flipped[1], flipped[0]
+    eng.forward(x, species=flipped)                                        # other content: a new copy
+    assert not torch.equal(eng._species_cache[1].cpu(), torch.from_numpy((species != 0).astype(np.uint8)))
+    with torch.cuda.stream(torch.cuda.Stream()):
+        eng.forward(x, species=flipped)                                    # other stream: not the copy another stream made
+    eng.close()
