@@ -25,7 +25,14 @@ def _run(*flags, env=None, steps=6, warmup=2):
 
 
 def test_default_line_has_the_contract_keys():
+    def timing_consistent(d):            # relations between clocks, which one stall from outside the process can break
+        tr, fe = d["config"]["timed_region"], d["force_eval_only"]
+        return (abs(tr["step_ms"]["mean"] - d["ms_per_step"]) / d["ms_per_step"] < 0.05
+                and 0.8 * d["ms_per_step"] < fe["ms_per_eval"] < 1.3 * d["ms_per_step"])
     d = _run("--no-cpu-baseline", "--no-secondary")
+    if not timing_consistent(d):
+        print("first attempt:", d["ms_per_step"], d["config"]["timed_region"]["step_ms"], d["force_eval_only"]["ms_per_eval"])
+        d = _run("--no-cpu-baseline", "--no-secondary")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
