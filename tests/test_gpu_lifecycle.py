@@ -282,3 +282,43 @@ def test_host_species_are_uploaded_once_and_outlive_an_asynchronous_run():
     with torch.cuda.stream(torch.cuda.Stream()):
         eng.forward(x, species=flipped)                                    # other stream: not the copy another stream made
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_skin_path_against_exact_path_on_random_boxes(seed):
+    """Seeded sweep over what the large-system skin path (k_skin_check | k_cells_sliced | k_filter_count | k_filter_fill_scan, or
+    the five-launch form above 16 384 atoms) can meet: atom counts that are not multiples of the 8 rows of a fill workgroup,
+    orthorhombic boxes, both search flavours, densities from a dilute gas to cells with > 64 atoms, skins from 2 % to 40 % of the
+    cutoff.  Four calls with growing displacements (so reuse steps and rebuild steps both occur); every call: edge set and per-row
+    degrees equal the exact path's, forces within 1e-5."""
+    from gamd_amd.engine import GamdForce
+    from helpers import edge_set, rel_err
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1025, 1031, 2048, 3001, 4099, 7777, 12345, 16384, 16391, 20011]))
+    flavour = "jaxmd" if seed % 2 == 0 else "torch"
+    rc = float(rng.uniform(4.0, 9.0))
+    per_atom = float(rng.choice([1.5, 6.0, 25.0, 60.0]))                  # neighbours within the cutoff
+    vol = n * (4.0 / 3.0) * np.pi * rc ** 3 / per_atom
+    shape = rng.uniform(0.7, 1.4, 3)
+    box = (vol / shape.prod()) ** (1.0 / 3.0) * shape
+    box = np.maximum(box, 2.05 * rc)                                       # minimum image
+    skin = float(rc * rng.choice([0.02, 1.0 / 6.0, 0.4]))
+    pos = rng.uniform(0, 1, (n, 3)) * box
+    sd = make_state_dict(ModelConfig(kind="lj"), 0, 0.6 * rc, 0.2 * rc)
+    exact = GamdForce(sd, n, box, rc, nbr_flavour=flavour)
+    skinned = GamdForce(sd, n, box, rc, nbr_flavour=flavour, neighbor_skin=skin)
+    step_sigma = [0.0, 0.1 * skin, 0.25 * skin, 0.6 * skin]
+    rebuilds = []
+    for k, sg in enumerate(step_sigma):
+        pos = pos + rng.normal(0, sg, pos.shape) if sg > 0 else pos
+        x = torch.from_numpy(pos).float().cuda()
+        f0, f1 = exact.forward(x), skinned.forward(x)
+        e0, e1 = exact.debug_edges(), skinned.debug_edges()
+        assert e0.shape == e1.shape, (k, e0.shape, e1.shape)
+        assert np.array_equal(edge_set(e0), edge_set(e1)), k
+        assert np.array_equal(np.bincount(e0[0], minlength=n), np.bincount(e1[0], minlength=n))
+        assert torch.isfinite(f1).all() and rel_err(f1.cpu().numpy(), f0.cpu().numpy()) < 1e-5
+        rebuilds.append(skinned.skin_stats()[0])
+    # (a dense first build can outgrow the initial candidate capacity: regrown and rebuilt, 2 on the first call)
+    assert rebuilds[0] >= 1 and rebuilds[-1] > rebuilds[0]                 # the last displacement is beyond half the skin
+    exact.close(); skinned.close()
