@@ -192,7 +192,7 @@ int fill_com(gamd_handle* h, int enabled, MdCom* c) {
 }
 
 int alloc_candidates(gamd_handle* h, long long cap) {
-    if (!small_path(h)) cap = std::max<long long>(cap, h->n);     // fixed-width rows: at least one slot per atom
+    cap = std::max<long long>(cap, h->n);                         // fixed-width rows: at least one slot per atom
     if (h->cand_col.ensure(sizeof(int) * ((size_t)cap + 64), true)) return fail(-12, "candidate buffer allocation failed");
     h->cand_cap = cap;
     h->cand_valid = false;
@@ -217,9 +217,9 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
     h->e_cap = e_cap;
     if (h->skin > 0.f) {
         const double grow = std::pow(((double)h->cfg.cutoff + h->skin) / (double)h->cfg.cutoff, 3.0);
-        // n > 1024: candidate rows have a fixed width (capacity / n), so what must fit is the LONGEST row, not the total:
-        // ~2.5 x the mean row (e_cap is already 1.5 x the density estimate) instead of ~1.65 x
-        const long long want = (long long)((double)e_cap * grow * (small_path(h) ? 1.1 : 1.7)) + 1024;
+        // candidate rows have a fixed width (capacity / n), so what must fit is the LONGEST row, not the total:
+        // ~2.5 x the mean row (e_cap is already 1.5 x the density estimate)
+        const long long want = (long long)((double)e_cap * grow * 1.7) + 1024;
         if (want > h->cand_cap) return alloc_candidates(h, want);
     }
     return 0;
@@ -322,11 +322,11 @@ NbrArgs nbr_args(gamd_handle* h, const float* pos_dev, const uint8_t* species_de
         a.cand_ptr = h->cand_ptr.as<int>();
         a.cand_col = h->cand_col.as<int>();
         a.cand_cap = h->cand_cap;
-        // fixed-width candidate rows above the single-workgroup size (neighbor.hip): the width follows the capacity
-        // (alloc_candidates keeps cand_cap >= n on this path, so the width is at least 1: a buffer that is too small shows up
-        // as rows longer than the stride = the overflow -> regrow protocol, not as a zero stride)
+        // fixed-width candidate rows (neighbor.hip): the width follows the capacity (alloc_candidates keeps cand_cap >= n, so
+        // the width is at least 1: a buffer that is too small shows up as rows longer than the stride = the overflow -> regrow
+        // protocol, not as a zero stride)
         a.use_small = small_path(h) ? 1 : 0;
-        a.cand_stride = small_path(h) ? 0 : (int)std::max<long long>(1, std::min<long long>(h->cand_cap / h->n, 1 << 20));
+        a.cand_stride = (int)std::max<long long>(1, std::min<long long>(h->cand_cap / h->n, 1 << 20));
     }
     return a;
 }
@@ -906,13 +906,13 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         if ((r = set_box(h, all.data()))) { gamd_destroy(h); return r; }
     }
     {
-        // Small-system path (k_step_small: skin check, integrator halves and — on the steps that need it — the whole candidate
-        // rebuild in ONE workgroup): worth it while a rebuild is cheap.  The in-kernel rebuild tests every atom against the
-        // atoms of its 27 cells on a single CU: ~n x min(n, 27 n / cells) pair tests, 0.17 ms for the 258-atom LJ box but 1.5 ms
-        // for 774 atoms in a box of 3 cells per axis (the DFT-water configuration, which rebuilds every ~5 steps).  Beyond
-        // ~3e5 pair tests the grid-wide kernels take over (three more launches per step, rebuilds spread over the chip).
+        // Small-system path (k_step_small: skin check, integrator halves and — on the steps that need it — the cell build of a
+        // candidate rebuild in ONE workgroup; the candidate rows are written by the count pass behind it).  Worth it while
+        // rebuilds are rare and cheap: a box of 3 cells per axis (the 774-atom DFT-water configuration: every atom is a
+        // candidate of every other, a rebuild every ~7 steps) is as fast on the grid-wide path (measured: 0.8825 against
+        // 0.884 ms per step), and a dilute box with thousands of cells is walked faster by 32 workgroups than by one.
         const double per_atom = std::min<double>(h->n, 27.0 * h->n / std::max(1, h->ncell));
-        h->use_small = h->n <= 1024 && n_boxes <= 1 && (double)h->n * per_atom <= 3.0e5;
+        h->use_small = h->n <= 1024 && n_boxes <= 1 && (double)h->n * per_atom <= 3.0e5 && h->ncell <= 4096;
     }
     long long ecap = cfg->edge_capacity;
     if (ecap <= 0) {

@@ -471,45 +471,48 @@ __device__ __forceinline__ void d_scan_deg(const NbrArgs& a) {
     }
 }
 
+// The fixed-stride candidate rows were rebuilt in this call (k_filter_count): publish their size.  A row longer than the stride is an
+// overflow (the list is truncated: freeze, the host regrows to 1.25 x longest row x n and resumes).  Total and longest row are
+// reduced HERE from the row lengths (one coalesced pass of this workgroup over cand_deg): as a pair of global atomics per
+// workgroup of the count pass they were 1 500 operations on two addresses at 6 000 atoms, which the L2 serialises — 13 of the
+// 36 us of that kernel on a rebuild step.  Whole workgroup of NT threads.
+template <int NT>
+__device__ __forceinline__ void d_publish_candidates(const NbrArgs& a) {
+    __shared__ int s_ctot[NT / 64], s_cmax[NT / 64];
+    int tot = 0, longest = 0;
+    for (int i = threadIdx.x; i < a.n; i += NT) {
+        const int w = a.cand_deg[i];
+        tot += w < a.cand_stride ? w : a.cand_stride;
+        longest = w > longest ? w : longest;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        tot += __shfl_xor(tot, d, 64);
+        const int o = __shfl_xor(longest, d, 64);
+        longest = o > longest ? o : longest;
+    }
+    if ((threadIdx.x & 63) == 0) { s_ctot[threadIdx.x >> 6] = tot; s_cmax[threadIdx.x >> 6] = longest; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tot = 0; longest = 0;
+        for (int w = 0; w < NT / 64; ++w) { tot += s_ctot[w]; longest = s_cmax[w] > longest ? s_cmax[w] : longest; }
+        a.counters[CNT_NCAND] = tot;
+        a.counters[CNT_CAND_MAX] = longest;
+        a.sticky[STICKY_NCAND] = tot;
+        a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
+        if (longest > a.cand_stride) {
+            const long long need = (long long)longest * a.n;
+            a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
+            a.sticky[STICKY_CAND_OVERFLOW] = 1;
+            a.devflags[DEVFLAG_FROZEN] = 1;
+        }
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
     GAMD_GATE();
-    if (!a.cand_pass && a.cand_stride > 0 && a.counters[CNT_REBUILD]) {
-        // skin path, the fixed-stride candidate rows were rebuilt in this call (k_filter_count): publish their size; a row
-        // longer than the stride is an overflow (the list is truncated: freeze, the host regrows to 1.25 x longest row x n
-        // and resumes).  Total and longest row are reduced HERE from the row lengths (one coalesced pass of this workgroup
-        // over cand_deg): as a pair of global atomics per workgroup of the count pass they were 1 500 operations on two
-        // addresses at 6 000 atoms, which the L2 serialises — 13 of the 36 us of that kernel on a rebuild step.
-        __shared__ int s_ctot[16], s_cmax[16];
-        int tot = 0, longest = 0;
-        for (int i = threadIdx.x; i < a.n; i += 1024) {
-            const int w = a.cand_deg[i];
-            tot += w < a.cand_stride ? w : a.cand_stride;
-            longest = w > longest ? w : longest;
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            tot += __shfl_xor(tot, d, 64);
-            const int o = __shfl_xor(longest, d, 64);
-            longest = o > longest ? o : longest;
-        }
-        if ((threadIdx.x & 63) == 0) { s_ctot[threadIdx.x >> 6] = tot; s_cmax[threadIdx.x >> 6] = longest; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            tot = 0; longest = 0;
-            for (int w = 0; w < 16; ++w) { tot += s_ctot[w]; longest = s_cmax[w] > longest ? s_cmax[w] : longest; }
-            a.counters[CNT_NCAND] = tot;
-            a.counters[CNT_CAND_MAX] = longest;
-            a.sticky[STICKY_NCAND] = tot;
-            a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
-            if (longest > a.cand_stride) {
-                const long long need = (long long)longest * a.n;
-                a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
-                a.sticky[STICKY_CAND_OVERFLOW] = 1;
-                a.devflags[DEVFLAG_FROZEN] = 1;
-            }
-        }
-        __syncthreads();
-    }
+    if (!a.cand_pass && a.cand_stride > 0 && a.counters[CNT_REBUILD]) d_publish_candidates<1024>(a);
     d_scan_deg(a);
 }
 
@@ -905,10 +908,9 @@ __global__ void __launch_bounds__(1024) k_cells_sliced(NbrArgs a0) {
 // not by work.  One 1024-thread workgroup (one thread per atom) therefore does, in this order:
 //   [B of the previous MD step] [B A O A of this step]     (plain BAOAB only: MdFuse; skipped when the run is frozen)
 //   wrap + displacement check, positions into the sorted order, clear of the other counter block
-//   the seven phases of the candidate rebuild, behind a workgroup-wide OR of the check (runs once in 50-100 steps),
-// with workgroup barriers where the large-system path has kernel boundaries: 1 launch instead of 11.
-constexpr int SMALL_CELLS_LDS = 2047;      // cell bounds of the small-system rebuild kept in LDS up to this many cells
-
+//   the cell build of a candidate rebuild (bin | scan | fill | sort), behind a workgroup-wide OR of the check (once in 50-100
+//   steps), with workgroup barriers where the large-system path has kernel boundaries.
+// The candidate rows are then written by the count pass of the exact filter (k_filter_count, as above 1 024 atoms): 3 launches.
 __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int do_second, int do_first) {
     const int tid = threadIdx.x;
     if (do_second | do_first) {
@@ -949,27 +951,8 @@ __global__ void __launch_bounds__(1024) k_step_small(NbrArgs a, MdArgs md, int d
     __syncthreads();
     for (int k = tid >> 6; k < c.ncell; k += 16) d_sort_gather(c, k, tid & 63);
     __syncthreads();
-    // The two sweeps below visit 27 cells per atom, 32 atoms at a time, and every visit is two dependent loads (cell bounds ->
-    // positions): ~1 350 serialized L2 round trips for 774 atoms = 1.5 ms per rebuild when they go to global memory (the
-    // DFT-water box rebuilds every ~5 steps).  From an LDS copy of the sorted positions and the cell bounds a visit costs an
-    // LDS round trip instead.  (Flat pointers into LDS: the sweep code is shared with the grid-wide kernels.)
-    __shared__ float4 s_pos[1024];
-    __shared__ int s_cell_start[SMALL_CELLS_LDS + 1];
-    const bool lds_tables = c.ncell <= SMALL_CELLS_LDS;
-    if (lds_tables) {
-        if (tid < c.n) s_pos[tid] = c.pos_s[tid];
-        for (int k = tid; k <= c.ncell; k += 1024) s_cell_start[k] = c.cell_start[k];
-        __syncthreads();
-    }
-    const LdsPos lpos = (LdsPos)(const void*)s_pos;
-    const LdsCells lcells = (LdsCells)(const void*)s_cell_start;
-    if (lds_tables) { for (int base = 0; base < c.n; base += 32) d_count(c, base + (tid >> 5), tid & 31, lpos, lcells); }
-    else { for (int base = 0; base < c.n; base += 32) d_count(c, base + (tid >> 5), tid & 31, c.pos_s, c.cell_start); }
-    __syncthreads();
-    d_scan_deg(c);       // (forced inline: as a real call its argument block would have to live in scratch memory)
-    __syncthreads();
-    if (lds_tables) { for (int base = 0; base < c.n; base += 32) d_fill(c, base + (tid >> 5), tid & 31, lpos, lcells); }
-    else { for (int base = 0; base < c.n; base += 32) d_fill(c, base + (tid >> 5), tid & 31, c.pos_s, c.cell_start); }
+    // (the candidate rows themselves are written by the count pass behind this kernel, k_filter_count, spread over the chip: as two
+    //  sweeps of this ONE workgroup they were 0.26 of the 0.27 ms a rebuild step cost at 258 atoms)
 }
 
 // exact cutoff on the candidate rows: one half-wave per centre atom, candidates keep their order
@@ -1129,39 +1112,7 @@ __global__ void __launch_bounds__(256) k_filter_fill_scan(NbrArgs a) {
     if (tid <= r_end - r0 && (tid < r_end - r0 || last)) { a.row_ptr[r0 + tid] = s_rp[tid]; a.na_excl[r0 + tid] = s_na[tid]; }
     const int E_all = carry_rp;                                  // (only the last workgroup's value is the total)
     if (last) {
-        if (a.counters[CNT_REBUILD]) {
-            // the fixed-stride candidate rows were rebuilt in this call (k_filter_count): publish their size; a row longer than
-            // the stride is an overflow (the list is truncated: freeze, the host regrows to 1.25 x longest row x n and resumes)
-            int ctot = 0, longest = 0;
-            for (int i = tid; i < a.n; i += 256) {
-                const int w = a.cand_deg[i];
-                ctot += w < a.cand_stride ? w : a.cand_stride;
-                longest = w > longest ? w : longest;
-            }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) {
-                ctot += __shfl_xor(ctot, d, 64);
-                const int o = __shfl_xor(longest, d, 64);
-                longest = o > longest ? o : longest;
-            }
-            if (lane == 0) { s_w[0][wv] = ctot; s_w[1][wv] = longest; }
-            __syncthreads();
-            if (tid == 0) {
-                ctot = (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]);
-                longest = 0;
-                for (int w = 0; w < 4; ++w) longest = s_w[1][w] > longest ? s_w[1][w] : longest;
-                a.counters[CNT_NCAND] = ctot;
-                a.counters[CNT_CAND_MAX] = longest;
-                a.sticky[STICKY_NCAND] = ctot;
-                a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
-                if (longest > a.cand_stride) {
-                    const long long need = (long long)longest * a.n;
-                    a.sticky[STICKY_NCAND] = need > 0x7fffffffll ? 0x7fffffff : (int)need;
-                    a.sticky[STICKY_CAND_OVERFLOW] = 1;
-                    a.devflags[DEVFLAG_FROZEN] = 1;
-                }
-            }
-        }
+        if (a.counters[CNT_REBUILD]) d_publish_candidates<256>(a);          // what k_scan_deg does on the five-launch path
         if (tid == 0) {
             a.counters[CNT_E] = E_all;
             a.counters[CNT_PIECES] = (E_all + GAMD_CHUNK - 1) / GAMD_CHUNK + carry_na;
@@ -1286,6 +1237,7 @@ __global__ void __launch_bounds__(256) k_filter_fill_small(NbrArgs a) {
     long long E = E_all;
     if (E > a.e_cap) E = a.e_cap;
     if (blockIdx.x == 0) {
+        if (a.cand_stride > 0 && a.counters[CNT_REBUILD]) d_publish_candidates<256>(a);
         for (int i = tid; i <= a.n; i += 256) { a.row_ptr[i] = s_rp[i]; a.na_excl[i] = s_na[i]; }
         if (tid == 0) {
             a.counters[CNT_E] = E_all;
@@ -1430,7 +1382,7 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
         GAMD_CHECK_LAUNCH();
         NbrArgs x = a;
         x.ref_pos = nullptr;
-        hipLaunchKernelGGL(k_filter<false>, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_filter_count, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_filter_fill_small, dim3(ga), dim3(256), 0, st, x); GAMD_CHECK_LAUNCH();
         return 0;
     }
