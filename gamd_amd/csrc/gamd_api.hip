@@ -47,7 +47,15 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) return (int)e;
         bytes = want;
-        if (zero) { e = hipMemset(p, 0, want); if (e != hipSuccess) return (int)e; }
+        if (zero) {
+            // hipMemset of device memory is asynchronous to the host and ordered on the NULL stream only: a kernel that the
+            // caller's non-blocking stream runs next is not ordered behind it and could have its first results zeroed under it
+            // (seen once in ~300 runs: the momentum sums of a run's first step, com_partial, wiped after k_com_partial wrote
+            // them -> centre-of-mass velocity 0 / 0).  Allocations are rare: wait for the memset.
+            e = hipMemset(p, 0, want);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) return (int)e;
+        }
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -272,6 +280,7 @@ int set_box(gamd_handle* h, const float* box, hipStream_t st = nullptr) {
             memcpy(&img[(size_t)12 * b + 8], &grid[(size_t)4 * b], 4 * sizeof(int));
         }
         HIP_TRY(hipMemcpy(h->boxes_dev.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipStreamSynchronize(nullptr));
     }
     return 0;
 }
@@ -699,6 +708,7 @@ int check_rigid_layout(gamd_handle* h, const uint8_t* species_dev, hipStream_t s
 int clear_devflags(gamd_handle* h) {
     const int init[2] = {0, -1};                             // FROZEN, FROZEN_AT; the rebuild counter behind them stays
     HIP_TRY(hipMemcpy(h->devflags.p, init, sizeof(init), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(nullptr));                  // (a copy from pageable memory may return before the DMA has landed)
     return 0;
 }
 
@@ -922,7 +932,8 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     }
     if (cfg->self_loop_mode) ecap += h->n;
     if ((r = alloc_edges(h, ecap))) { gamd_destroy(h); return r; }
-    *out = h;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) { gamd_destroy(h); return fail(-1, "device synchronisation failed"); }
+    *out = h;                                  // every initialising memset / copy has landed: any stream may use the handle
     return 0;
 }
 
@@ -1224,6 +1235,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
 
     if (h->wblob.ensure(sizeof(float) * bb.host.size(), false)) return fail(-12, "weight blob allocation failed");
     HIP_TRY(hipMemcpy(h->wblob.p, bb.host.data(), sizeof(float) * bb.host.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     const float* B = h->wblob.as<float>();
     h->layers.assign(L, LayerDev{});
     for (int l = 0; l < L; ++l) {
@@ -1278,6 +1290,7 @@ int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds) {
         }
     if (h->bond_nbr.ensure(sizeof(int) * tab.size(), false)) return fail(-12, "bond table allocation failed");
     HIP_TRY(hipMemcpy(h->bond_nbr.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     h->has_bonds = n_bonds > 0;
     return 0;
 }
