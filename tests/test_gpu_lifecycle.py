@@ -322,3 +322,70 @@ def test_skin_path_against_exact_path_on_random_boxes(seed):
     # (a dense first build can outgrow the initial candidate capacity: regrown and rebuilt, 2 on the first call)
     assert rebuilds[0] >= 1 and rebuilds[-1] > rebuilds[0]                 # the last displacement is beyond half the skin
     exact.close(); skinned.close()
+
+
+# ---- a fresh handle driven from a non-blocking side stream from its first call on ---------------------------------------
+# (what caught the hipMemset race of DESIGN.md section 7: buffers that a call allocates and zeroes on the NULL stream while the
+# caller's stream is not ordered behind it — the momentum sums of a run's first step were wiped in 1 of ~300 runs)
+def _sc_lj(stream):
+    pos, box = workloads.lj_box(3000, seed=11)
+    from gamd_amd.engine import GamdForce
+    e = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2), 3000, box, 10.2, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=1.7)
+    x = torch.from_numpy(pos).float().cuda(); v = torch.from_numpy(workloads.maxwell_boltzmann(3000, seed=1)).float().cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        f = e.forward(x, denormalize=True).clone()
+        e.md_run(x, v, f, 15, seed=2, sync=False, remove_cm_motion=True)
+        e.sync_status()
+    out = (x.cpu(), v.cpu(), f.cpu()); e.close(); return out
+
+def _sc_water_nhc(stream):
+    pos, box, species, bonds = workloads.water_box(300, seed=12, jitter=0.0, wrap=False)
+    from gamd_amd.engine import GamdForce
+    e = GamdForce(make_state_dict(ModelConfig(kind="water", use_bond=True), 1, 2.9, 1.1), 900, box, 4.2, bond=bonds,
+                  scaler=SHIPPED_SCALERS["tip3p"], neighbor_skin=0.7)
+    x = torch.from_numpy(pos).float().cuda(); v = torch.zeros_like(x)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        f = e.forward(x, species=species, denormalize=True).clone()
+        ch = e.md_run_nhc(x, v, f, 10, dt_ps=0.0005, mass_amu=workloads.MASS_O, mass_h_amu=workloads.MASS_H, temperature_k=300.0,
+                          species=species, rigid_water=True, r_oh=workloads.TIP3P_R_OH, r_hh=workloads.TIP3P_R_HH, sync=False)
+        e.sync_status()
+    out = (x.cpu(), v.cpu(), f.cpu(), ch.cpu()); e.close(); return out
+
+def _sc_batch(stream):
+    boxes = [workloads.lj_box(500, seed=100 + b) for b in range(4)]
+    from gamd_amd.engine import GamdForce
+    e = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 5.3, 1.6), 500, boxes[0][1], 7.5, n_boxes=4, scaler=SHIPPED_SCALERS["lj"],
+                  neighbor_skin=1.25)
+    x = torch.from_numpy(np.concatenate([p for p, _ in boxes])).float().cuda()
+    v = torch.from_numpy(workloads.maxwell_boltzmann(2000, seed=4)).float().cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        f = e.forward(x, denormalize=True).clone()
+        e.md_run(x, v, f, 12, seed=3, sync=False, remove_cm_motion=True)
+        e.sync_status()
+    out = (x.cpu(), v.cpu(), f.cpu()); e.close(); return out
+
+def _sc_small(stream):
+    pos, box = workloads.lj_box(258, seed=13)
+    from gamd_amd.engine import GamdForce
+    e = GamdForce(make_state_dict(ModelConfig(kind="lj"), 0, 5.3, 1.6), 258, box, 7.5, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=1.25)
+    x = torch.from_numpy(pos).float().cuda(); v = torch.from_numpy(workloads.maxwell_boltzmann(258, seed=5)).float().cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        f = e.forward(x, denormalize=True).clone()
+        e.md_run(x, v, f, 60, seed=6, sync=False, remove_cm_motion=True)
+        e.sync_status()
+    out = (x.cpu(), v.cpu(), f.cpu()); e.close(); return out
+
+
+
+@pytest.mark.parametrize("scenario", ["lj", "water_nhc", "batch", "small"])
+def test_fresh_handles_on_side_streams_match_the_default_stream(scenario):
+    fn = {"lj": _sc_lj, "water_nhc": _sc_water_nhc, "batch": _sc_batch, "small": _sc_small}[scenario]
+    ref = fn(torch.cuda.current_stream())
+    assert all(torch.isfinite(r).all() for r in ref)
+    for k in range(25):
+        got = fn(torch.cuda.Stream())
+        assert all(torch.equal(g, r) for g, r in zip(got, ref)), (scenario, k, [int(torch.isnan(g).sum()) for g in got])
