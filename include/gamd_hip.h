@@ -9,7 +9,8 @@
  * Conventions
  *   - plain C types only; all `*_dev` pointers are caller-owned DEVICE pointers,
  *     all other pointers are HOST pointers; `stream` is a hipStream_t passed as void*
- *     (NULL = default stream).  Work is stream-ordered.
+ *     (NULL = default stream).  Work is ordered on that stream only (it may be a non-blocking stream: nothing relies
+ *     on the NULL stream's implicit ordering; what a call allocates and initialises has landed before it returns).
  *   - every function returns an int32 status: 0 = ok, 1 = ok after the neighbour
  *     buffers overflowed and were regrown (the analogue of jax-md's
  *     did_buffer_overflow -> re-allocate, graph_utils.py:41-42), < 0 = error
