@@ -38,6 +38,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_32
 PEAK_HBM_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E spec peak
 CPU_SAMPLE_ATOMS = 2000
 C1_BATCH_BOXES = 38                         # 38 x 258 = 9 804 atoms: a C2-sized set of launches
+SECONDARY_COMPACT = ("c1", "c3", "c5", "c5b", "dft")    # the default line's secondary triples; --secondary full runs twelve
+LINE_LIMIT = 6000                           # characters of the ONE stdout line (the driver keeps an 8 081-character tail)
 C2_BATCH_BOXES = 8                          # config 4's eight rank boxes (seeds 1234 .. 1241) as ONE batch on one GPU
 # SURVEY.md 8d algorithmic FLOPs of one force evaluation (F = 44, L = 4, H = 128), src/dst Linears on node rows
 FLOP_PER_EDGE_STEP = 2 * (44 * 128 + 2 * 128 * 128) + 4 * (8 * 128 * 128 + 4 * 128)      # 603 136
@@ -97,7 +99,19 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short C1/C3/C5 runs and the per-kernel replays")
+    ap.add_argument("--no-secondary", action="store_true", help="same as --secondary none")
+    ap.add_argument("--secondary", default="compact", choices=["none", "compact", "full"],
+                    help="c2, N = 1 only.  compact (default): 20-step runs of the other single-GPU BASELINE configs (c1, c3, c5, "
+                         "c5b) and of the DFT-water configuration, one [ms_per_step, atom-steps/s, conv-kernel frac] triple each in the "
+                         "result line; full: all twelve secondary workloads with their per-step distributions, in the detail file only "
+                         "(the line still carries the compact triples); none: skip them and the per-kernel replays")
+    ap.add_argument("--line", default="compact", choices=["compact", "full"],
+                    help="compact (default; the driver's contract): the ONE stdout line is the compact record.  full: print the "
+                         "full record instead (tools/ only: the per-kernel list and per-step distributions on stdout)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (per-step distributions, per-kernel list, per-rank summaries, prose notes, "
+                         "secondary workloads): the ONE line on stdout is the compact contract record, <= 6 000 characters; "
+                         "'-' = do not write a detail file")
     ap.add_argument("--workload", default="c2", choices=["c1", "c1_batch", "c2", "c2_batch8", "c3", "c5", "c5b", "dft"],
                     help="c2 (default, the headline metric): 10k-atom LJ fp32; c1: the reference's own 258-atom LJ snapshot "
                          "(code/LJ/init_pos.npy); c1_batch: 38 such boxes in one set of launches (gamd_config.n_boxes); c2_batch8: the eight 10k-atom boxes the ranks of "
@@ -243,6 +257,8 @@ def build_workload(name, ctx, dev, skin, edge_dtype):
             w.dtype_name, w.kernel_name = "f16x3 (fp32 operands split into hi+lo fp16, fp32 accumulate)", "k_conv_edge_f16x3"
         elif edge_dtype == "bf16":
             w.dtype_name, w.kernel_name = "bf16", "k_conv_edge_bf16"
+        elif name == "c1":
+            w.kernel_name = "k_conv_edge_small"       # <= small_tile_limit 32-edge tiles: one tile per 4-wave workgroup
         w.dt_ps = 0.002
         w.label = ("C2: 10 000-atom LJ box, rho*=0.5, L=92.29 A, cutoff 3.0 sigma=10.2 A, fp32, 4 conv layers x 128, "
                    "random-init weights (seed 0), 1 box per GPU") if name == "c2" else \
@@ -413,6 +429,8 @@ def cpu_baseline(w, dev):
                       f"same weights, {edges.shape[1]} edges from the GPU's neighbour list), 1 warm-up + 2 evaluations "
                       f"(best) with {best_thr} torch threads on a {ncpu}-thread host (os.cpu_count()); neighbour search "
                       "and integrator excluded",
+            "sample_short": f"force eval of the timed run's own {w.n_atoms}-atom box ({edges.shape[1]} edges), 1 warm-up + 2 evals (best), "
+                            f"{best_thr} torch threads of {ncpu}",
             "seconds_per_eval": sec, "seconds_all": times, "host_threads": ncpu, "gpu_vs_cpu_rel_err": err,
             "gpu_vs_cpu_per_atom": {"median": float(np.median(rel_i)), "p99": float(np.percentile(rel_i, 99)),
                                     "max": float(rel_i.max()), "atoms": int(keep.sum()),
@@ -447,8 +465,77 @@ def roofline_block(w, n_edges, conv_ms, conv_n):
     return r
 
 
+def _sig(x, n=6):
+    """Numbers of the result line: n significant digits (the full-precision values are in the detail file)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    return float(f"{float(x):.{n}g}")
+
+
+def rocprof_record():
+    """roofline.rocprof_avg_launch_ms: the rocprofv3 --kernel-trace --stats average of the dominant kernel, taken by
+    tools/gpu_profile_round.sh with the same command and kept in profiles/pmc_conv_edge.json next to the PMC traffic; reported
+    only for the kernel sources it was measured on (hash), otherwise null."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_conv_edge.json")))
+    except Exception:
+        return None
+    return rec if rec.get("kernel_source_sha256_16") == kernel_source_hash() else None
+
+
+def compact_line(d, args):
+    """The ONE stdout line: the contract keys in the contract's order, numbers only (<= LINE_LIMIT characters).  Everything
+    explanatory — notes, per-kernel list, per-rank summaries, per-step distributions of the secondary workloads — is in the
+    detail file."""
+    cfg, rl = d["config"], d["roofline"]
+    tr = cfg["timed_region"]
+    sm = tr.get("step_ms") or {}
+    out = {k: (_sig(d[k]) if k in ("value", "ms_per_step") else d[k]) for k in
+           ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")}
+    out["config"] = {"workload": cfg["workload"], "n_atoms": cfg["n_atoms"], "edges_per_step": cfg["edges_per_step"],
+                     "boxes": cfg["boxes"], "neighbour_list": cfg["neighbour_list"], "launch": cfg["launch"],
+                     "timed_region": {"p50": _sig(sm.get("p50"), 4), "p99": _sig(sm.get("p99"), 4), "max": _sig(sm.get("max"), 4),
+                                      "mean": _sig(sm.get("mean"), 4), "intervals": sm.get("intervals"),
+                                      "rebuilds_in_timed": tr["rebuilds_in_timed"], "regrown_in_timed": tr["regrown_in_timed"],
+                                      "regrown_in_warmup": tr["regrown_in_warmup"], "rebuild_ms": _sig(tr.get("rebuild_ms"), 3)}}
+    r = {k: _sig(rl.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches")}
+    r["flop_per_launch" if "flop_per_launch" in rl else "bytes_per_launch"] = _sig(rl.get("flop_per_launch", rl.get("bytes_per_launch")))
+    for k in ("whole_step_frac", "rocprof_avg_launch_ms", "rocprof_frac"):
+        if k in rl:
+            r[k] = _sig(rl[k])
+    if "neighbour_gather" in rl:
+        r["neighbour_gather"] = {k: _sig(rl["neighbour_gather"][k], 4) for k in ("bytes_per_step", "GB_per_s", "frac_of_hbm_peak")}
+    if "kernels" in rl:                                     # [avg launch ms, frac of the fp32 matrix peak] of the other kernels
+        r["other_kernels"] = {k["kernel"].split(" ")[0]: [_sig(k.get("avg_launch_ms", k.get("avg_stage_ms")), 4), _sig(k.get("frac"), 3)]
+                              for k in rl["kernels"]}
+    out["roofline"] = r
+    if "cpu_baseline" in d:
+        cb = d["cpu_baseline"]
+        out["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                               "sample": cb.get("sample_short") or cb["sample"][:160], "host_threads": cb["host_threads"],
+                               "seconds_per_eval": _sig(cb["seconds_per_eval"], 4), "gpu_vs_cpu_rel_err": _sig(cb["gpu_vs_cpu_rel_err"], 3),
+                               "gpu_vs_cpu_per_atom_p99": _sig(cb["gpu_vs_cpu_per_atom"]["p99"], 3)}
+    if "force_eval_only" in d:
+        fe = d["force_eval_only"]
+        out["force_eval_only"] = {"ms_per_eval": _sig(fe["ms_per_eval"], 4), "value": _sig(fe["value"]), "unit": fe["unit"]}
+    en = d["ensemble"]
+    out["ensemble"] = {"boxes": en["boxes"], "distinct_devices": en["distinct_devices"],
+                       "collective_on_step_path": en["collective_on_step_path"],
+                       "rank_seconds": [_sig(x["seconds"], 4) for x in en["per_rank"]]}
+    if "secondary" in d:                                    # name -> [ms per step, atom-steps/s, conv-kernel roofline frac]
+        out["secondary"] = {k: [_sig(v["ms_per_step"], 4), _sig(v["value"], 4), _sig(v["conv_kernel"]["frac"], 3)]
+                            for k, v in d["secondary"].items() if k in SECONDARY_COMPACT}
+        out["secondary_unit"] = "[ms_per_step, atom-steps/s, conv-kernel roofline frac], 20 steps each"
+    if args.detail != "-":
+        out["detail_file"] = os.path.basename(args.detail)
+    return out
+
+
 def main():
     args = parse_args()
+    if args.no_secondary:
+        args.secondary = "none"
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -535,6 +622,14 @@ def main():
                                       f"({rec.get('kernel_source_sha256_16')} != {kernel_source_hash()}): not reported")
         except Exception as exc:                                        # missing / unreadable file: say so, report null
             rl["traffic_note"] = f"no PMC record: {exc}"
+        # the rocprofv3 --kernel-trace --stats average of the same kernel sources (profiles/), beside the live HIP-event figure
+        rp = rocprof_record()
+        if rp is not None and rp.get("rocprof_avg_launch_us"):
+            rl["rocprof_avg_launch_ms"] = rp["rocprof_avg_launch_us"] * 1e-3
+            rl["rocprof_frac"] = rl["flop_per_launch"] / (rp["rocprof_avg_launch_us"] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+            rl["rocprof_source"] = rp.get("rocprof_source")
+        else:
+            rl["rocprof_avg_launch_ms"] = None
         rl["ceiling_note"] = ("gfx950 issues fp32 MFMA and VALU on the same lanes (simple VALU 4 cycles, v_exp_f32 / v_rcp_f32 8, next to "
                               "64 per v_mfma_f32_32x32x2_f32). Timing ablations of this kernel at this size (profiles/"
                               "r03_conv_edge_experiments.md): the GEMM chain alone (LDS-fed MFMAs, barriers, piece stores) 0.90 of the "
@@ -557,7 +652,7 @@ def main():
                                            "gather is reachable only by the bf16 kernel (see secondary c5)"}
         rl["neighbour_gather_hbm"] = gather_hbm_block()
     single = ctx.world == 1
-    if single and not args.no_secondary:
+    if single and args.secondary != "none":
         # the other MFMA kernels, from the same live HIP events of the timed region as the conv kernel: the edge encoder has
         # its own event pair; the node kernel between two conv layers is the interval between their event pairs (both
         # kernel boundaries included).  The neighbour stage comes from event-timed replays afterwards.
@@ -603,16 +698,17 @@ def main():
                                            "positions resident on the device, no integrator"}
     if single and not args.no_cpu_baseline and args.workload == "c2":
         line["cpu_baseline"] = cpu_baseline(w, dev)
-    if single and not args.no_secondary and args.workload == "c2":
+    if single and args.secondary != "none" and args.workload == "c2":
         sec = {}
         w.eng.close()
         # (entry, workload, edge dtype): the other single-GPU BASELINE configs, the batched C1, the opt-in split-fp16 and bf16
         # runs of C2 (c2_bf16: the north star's neighbour-gather figure on the 10k-atom LJ box itself, tolerance restated as
         # for config 5) and the DFT-water configuration, 20 timed steps each
-        for name, wname, dt_name in (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c1_batch_f16x3", "c1_batch", "f16x3"),
-                                     ("c2_batch8", "c2_batch8", "f32"), ("c3", "c3", "f32"), ("c5", "c5", "f32"),
-                                     ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("c2_bf16", "c2", "bf16"), ("dft", "dft", "f32"),
-                                     ("dft_f16x3", "dft", "f16x3"), ("dft_bf16", "dft", "bf16")):
+        full = (("c1", "c1", "f32"), ("c1_batch", "c1_batch", "f32"), ("c1_batch_f16x3", "c1_batch", "f16x3"),
+                ("c2_batch8", "c2_batch8", "f32"), ("c3", "c3", "f32"), ("c5", "c5", "f32"),
+                ("c5b", "c5b", "f32"), ("c2_f16x3", "c2", "f16x3"), ("c2_bf16", "c2", "bf16"), ("dft", "dft", "f32"),
+                ("dft_f16x3", "dft", "f16x3"), ("dft_bf16", "dft", "bf16"))
+        for name, wname, dt_name in (full if args.secondary == "full" else [t for t in full if t[0] in SECONDARY_COMPACT]):
             s = build_workload(wname, ctx, dev, args.skin, dt_name)
             sdt, _, sconv_ms, sconv_n = timed_run(s, 20, 5, ctx, dev, ddev)
             first_attempt = None
@@ -633,7 +729,19 @@ def main():
                 sec[name]["stall_detected_in_first_attempt"] = first_attempt
             s.eng.close()
         line["secondary"] = sec
-    print(json.dumps(line))
+    out = compact_line(line, args)
+    text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:
+        raise SystemExit(f"bench.py: the result line has {len(text)} characters (limit {LINE_LIMIT}): move fields to the detail file")
+    if args.detail != "-":
+        try:
+            with open(args.detail, "w") as f:
+                json.dump({"line": out, "detail": line}, f)
+            print(f"bench.py: full record (per-step distributions, per-kernel list, per-rank summaries, notes, secondary "
+                  f"workloads) written to {args.detail}", file=sys.stderr)
+        except OSError as exc:
+            print(f"bench.py: detail file not written: {exc}", file=sys.stderr)
+    print(text if args.line == "compact" else json.dumps(line))
     ens.shutdown(ctx)
 
 

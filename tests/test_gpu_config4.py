@@ -228,12 +228,16 @@ def test_bench_gpus_2_on_real_rccl():
     def run(*flags):
         e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
                                                                "TORCHELASTIC_RUN_ID", "GAMD_BENCH_SHARE_GPU", "GAMD_BENCH_BACKEND")}
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "20", "--no-cpu-baseline",
-                            "--no-secondary", *flags], capture_output=True, text=True, timeout=900, cwd=ROOT, env=e)
-        assert p.returncode == 0, p.stderr[-2000:]
-        lines = [l for l in p.stdout.splitlines() if l.strip()]
-        assert len(lines) == 1, p.stdout
-        return json.loads(lines[0])
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            det = os.path.join(td, "detail.json")
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "20", "--no-cpu-baseline",
+                                "--no-secondary", "--detail", det, *flags], capture_output=True, text=True, timeout=900, cwd=ROOT, env=e)
+            assert p.returncode == 0, p.stderr[-2000:]
+            lines = [l for l in p.stdout.splitlines() if l.strip()]
+            assert len(lines) == 1 and len(lines[0]) < 6000, p.stdout
+            assert json.loads(lines[0])["ensemble"]["boxes"] == len(json.load(open(det))["detail"]["ensemble"]["per_rank"])
+            return json.load(open(det))["detail"]                  # the full record: per-rank summaries
     one, two = run("--gpus", "1"), run("--gpus", "2")
     ens = two["ensemble"]
     assert two["n_gpus"] == 2 and ens["distinct_devices"] == 2 and ens["collective_on_step_path"] is False

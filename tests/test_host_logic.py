@@ -241,6 +241,34 @@ def test_pmc_record_is_tied_to_kernel_sources():
     assert "kernel_source_sha256_16" in rec and len(rec["kernel_source_sha256_16"]) == 16
 
 
+def test_bench_result_line_stays_under_the_drivers_capture():
+    """Round 5's bench line was 21 KB; the driver keeps an 8 081-character tail of stdout and parsed nothing.  bench.compact_line
+    turns the full record into the contract line: fed with that very record (profiles/r05_final_bench_default.json), once as it
+    is and once blown up to eight ranks, the line stays under bench.LINE_LIMIT and keeps the contract's key order."""
+    import json, importlib.util, types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(root, "profiles", "r05_final_bench_default.json")))
+    assert len(json.dumps(full)) > 20000
+    args = types.SimpleNamespace(detail=os.path.join(root, "bench_detail.json"))
+    for ranks in (1, 8):
+        rec = json.loads(json.dumps(full))
+        rec["ensemble"]["per_rank"] = [dict(rec["ensemble"]["per_rank"][0], rank=r) for r in range(ranks)]
+        rec["ensemble"]["boxes"] = rec["n_gpus"] = rec["config"]["boxes"] = ranks
+        line = bench.compact_line(rec, args)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+        assert len(text) < bench.LINE_LIMIT <= 6000, len(text)
+        assert list(line)[:14] == ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data", "config", "roofline"]
+        assert list(line["roofline"])[:7] == ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"]
+        assert list(line["cpu_baseline"])[:5] == ["value", "unit", "cores", "kind", "sample"]
+        assert abs(line["value"] / full["value"] - 1) < 1e-5 and abs(line["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-5
+        assert set(line["secondary"]) == set(bench.SECONDARY_COMPACT) and len(line["ensemble"]["rank_seconds"]) == ranks
+        print(ranks, len(text))
+
+
 def test_self_loop_mode_names_agree_between_oracle_and_engine():
     import gamd_oracle as orc
     from gamd_amd.engine import SELF_LOOP

@@ -12,7 +12,7 @@ NAMES = {0: "production", 1: "SiLU -> x/2", 2: "gathers from one hot row", 4: "n
          16: "no MFMAs", 32: "S / D gathers from one hot row", 3: "1+2", 7: "1+2+4", 23: "1+2+4+16", 31: "all"}
 for v in [int(x) for x in sys.argv[1:]] or [0]:
     env = dict(os.environ, GAMD_LIB=os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so"), GAMD_BF16_VARIANT=str(v))
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--no-secondary", "--no-cpu-baseline",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--no-secondary", "--no-cpu-baseline", "--line", "full",
                         "--steps", "100", "--warmup", "10"], env=env, capture_output=True, text=True)
     try:
         d = json.loads(p.stdout.strip().splitlines()[-1])

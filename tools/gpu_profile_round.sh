@@ -29,7 +29,7 @@ for w in c2 c5; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_write_$w -- $B --steps 5 --warmup 2 --workload $w > $out/pmc_write_$w.log 2>&1
   python3 tools/profile_summary.py pmc $out/pmc_sq_$w $out/pmc_fetch_$w $out/pmc_write_$w > $out/pmc_$w.md
 done
-python3 tools/profile_summary.py pmcjson $out/pmc_fetch_c2 $out/pmc_write_c2 k_conv_edge $out/pmc_conv_edge.json > /dev/null
+python3 tools/profile_summary.py pmcjson $out/pmc_fetch_c2 $out/pmc_write_c2 'k_conv_edge<' $out/pmc_conv_edge.json $out/trace_c2 > /dev/null
 # the neighbour gather where it reaches HBM (10^5 / 10^6 atoms): live run + trace + three separate --pmc passes each
 for cfg in "100000 bf16" "1000000 bf16" "1000000 f32"; do set -- $cfg; bash tools/gpu_pmc_gather.sh $tag/gather $1 $2 > /dev/null 2>&1; done
 python3 tools/profile_summary.py gatherjson $out/gather_hbm.json $out/gather/100000_bf16 $out/gather/1000000_bf16 $out/gather/1000000_f32 > /dev/null

@@ -12,7 +12,7 @@ NAMES = {0: "production", 1: "no piece loads (agg = 0)", 2: "all weights from on
 for wl in sys.argv[1:] or ["c2", "c5", "c1"]:
     for v in (0, 1, 2, 3, 4, 7):
         env = dict(os.environ, GAMD_LIB=os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so"), GAMD_NODE_VARIANT=str(v))
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--steps", "100", "--warmup", "10"],
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--line", "full", "--steps", "100", "--warmup", "10"],
                            env=env, capture_output=True, text=True)
         try:
             d = json.loads(p.stdout.strip().splitlines()[-1])

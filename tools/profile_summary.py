@@ -9,7 +9,9 @@
     python tools/profile_summary.py gatherjson <out.json> <dir> [<dir> ...]
         merge the gather.json records of several `gather` directories into the record bench.py reports as
         roofline.neighbour_gather_hbm (profiles/gather_hbm.json), stamped with the hash of the kernel sources
-    python tools/profile_summary.py pmcjson <fetch_dir> <write_dir> <kernel substring> <out.json>
+    python tools/profile_summary.py pmcjson <fetch_dir> <write_dir> <kernel substring> <out.json> [<trace_dir>]
+        (with <trace_dir>, a --kernel-trace --stats run of the same build: the kernel's average launch duration goes into the
+        record too, which bench.py reports as roofline.rocprof_avg_launch_ms)
         HBM bytes per launch of one kernel (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), stamped with
         the hash of the kernel sources (bench.kernel_source_hash) so that bench.py only reports it for the build it was taken on
 """
@@ -70,7 +72,7 @@ def pmc(dirs):
             print(f"| {c} | {len(v)} | {sum(v) / len(v):.6g} |")
 
 
-def pmcjson(fetch_dir, write_dir, kernel, out):
+def pmcjson(fetch_dir, write_dir, kernel, out, trace_dir=None):
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
@@ -92,6 +94,14 @@ def pmcjson(fetch_dir, write_dir, kernel, out):
            "hbm_bytes_per_launch": (2.0 * fs + ws) * 1024.0,
            "kernel_source_sha256_16": bench.kernel_source_hash(),
            "algorithmic_bytes_per_launch_note": "e_frag 512 B/edge + pieces ~40 B/edge = ~3.5e8 B at E=6.34e5; S/D/hn gathers are L2-resident"}
+    if trace_dir:
+        for f in find(trace_dir, "*kernel_stats.csv"):
+            for r in csv.DictReader(open(f)):
+                if kernel in short(r["Name"]) and "rocprof_avg_launch_us" not in rec:
+                    rec["rocprof_avg_launch_us"] = float(r["AverageNs"]) / 1e3
+                    rec["rocprof_calls"] = int(r["Calls"])
+                    rec["rocprof_source"] = ("rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-secondary "
+                                             "--steps 50 --warmup 5 --workload c2 (tools/gpu_profile_round.sh, same kernel sources)")
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
@@ -181,4 +191,4 @@ if __name__ == "__main__":
     elif cmd == "gatherjson":
         gatherjson(sys.argv[2], sys.argv[3:])
     elif cmd == "pmcjson":
-        pmcjson(*sys.argv[2:6])
+        pmcjson(*sys.argv[2:7])
