@@ -609,6 +609,8 @@ def main():
         "roofline": roofline_block(w, n_edges, conv_ms, conv_n),
     }
     rl = line["roofline"]
+    # live HIP events of the timed region per stage: average ms per launch and launches (detail record; tools/ab_libs.sh)
+    line["stages_ms"] = {k: [v[0] / max(v[1], 1), v[1]] for k, v in w.stages.items()}
     if args.workload == "c2" and w.dtype_name == "f32":
         # HBM bytes per launch from the PMC passes (profiles/), valid only for the kernel sources they were taken on
         pmc = os.path.join(ROOT, "profiles", "pmc_conv_edge.json")

@@ -104,7 +104,8 @@ class _ModelLevel:
                 while j < len(sizes) and sizes[j] == sizes[i]:
                     j += 1
                 cnt = sizes[i] * (j - i)
-                sub_rest = (lst[i:j],) if len(rest) == 1 else (rest[0][off:off + cnt], lst[i:j])
+                # (the LJ call pnet_model(pos_lst, None, edge_lst) carries feat = None: forwarded as it is)
+                sub_rest = (lst[i:j],) if len(rest) == 1 else (None if rest[0] is None else rest[0][off:off + cnt], lst[i:j])
                 outs.append(self.__call__(pos_lst[i:j], *sub_rest))
                 off += cnt
                 i = j
@@ -190,12 +191,13 @@ class _ForceFieldBase:
         ``ParticleNetLightning(args).load_from_checkpoint(PATH, args=args)`` (LJ/test_script/test_langevin.py:74): a
         classmethod (callable on the class or on an instance) that builds a NEW wrapper from ``args`` (+ ``kw``), loads the
         checkpoint's ``state_dict`` ('pnet_model.' prefix) into it and returns it; the instance it was called on is left
-        alone.  Called on an instance, the new wrapper inherits its system size / box / cutoff / bond / device.
+        alone.  Called on an instance, the new wrapper inherits its system size / box / cutoff / bond / device — NOT its
+        scaler: like the module Lightning's classmethod returns, it starts from the constructor's training_mean = 0,
+        training_var = 1, and the drivers call load_training_stats on it next (LJ/test_script/test_langevin.py:75-76).
         ``allow_pickle``: see weights.load_checkpoint (restricted unpickler unless opted out)."""
         sd = load_checkpoint(path, allow_pickle=allow_pickle)
         if self is not None:
             new = self._respawn(args if args is not None else self.args, **kw)
-            new.training_mean, new.training_var = self.training_mean, self.training_var
         else:
             new = cls(args, **kw)
         new.load_state_dict(sd)

@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
     int src = 0, dst = 0;
     {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
-        if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
+        if (active && x < E) { src = GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_CONV_SRC); dst = GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_CONV_DST); }
         else if (V & CV_ZROW) { src = a.zero_row; dst = a.zero_row; }
         if (V & CV_ROW0) { src = 0; dst = 0; }
         if (active) {
@@ -427,11 +427,11 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
         // small index loads for phase 4 / the next tile go first: done long before the barrier needs vmcnt(0)
         if (active) {
             mask = a.chunk_mask[tile * 2 + half];
-            p0 = a.chunk_piece[tile * 2 + half];
+            p0 = GAMD_CHK_RANGE(a.sticky, a.chunk_piece[tile * 2 + half], 0, a.piece_cap - 17, GAMD_CHK_PIECE);
         }
         if (active_n) {
             const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
-            if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
+            if (xn < E) { src_n = GAMD_CHK_RANGE(a.sticky, a.col[xn], 0, a.zero_row, GAMD_CHK_CONV_SRC); dst_n = GAMD_CHK_RANGE(a.sticky, a.erow[xn], 0, a.zero_row, GAMD_CHK_CONV_DST); }
             if (V & CV_ROW0) { src_n = 0; dst_n = 0; }
         }
         if (active) {

@@ -5,24 +5,41 @@
 // add, SiLU, message, segment sum) in fp32.  At 1/16 of the fp32 matrix time the kernel is no longer
 // MFMA-bound: all four bf16 weight matrices (4 x 32 KiB) stay resident in LDS, so there is no weight
 // streaming and no barrier in the main loop; waves run free and hide each other's gather latency.
-// Bound: L2 / HBM gather traffic (8 KiB of e + 3 x 16 KiB of S/D/hn rows per 32-edge tile).
+//
+// Round 6: the node tables of this mode are fp16 (NodeArgs::tab16, written by k_node: hn in natural order, S and D in the group
+// order of gamd_tab16_pos and pre-multiplied by log2 e), and the pre-activations of the three SiLUs arrive multiplied by log2 e
+// (W1, b1, b3 scaled at packing time, W4 by ln 2 to take it out again): y' = x' / (1 + 2^-x') needs no multiply in front of the
+// exponential.  Half the gather instructions and cache lines, 96 vector registers less between GEMM 1 and GEMM 2 (which is what
+// lets the next tile's e stream be fetched a whole tile ahead), S + D and the message as one v_fma_mix_f32 per element.
+// Bound: the vector ALU (3 x 128 transcendental pairs per tile and wave) next to 8 KiB of e + 3 x 8 KiB of S/D/hn rows per tile.
 #include "gamd_bf16.h"
 #include "gamd_internal.h"
 #include <cstdlib>
 
 namespace {
 
-// row `row` of a [.][128] fp32 table -> chain layout, addressed as (scalar base) + (32-bit per-lane byte offset) + (immediate):
-// one offset register per gather instead of a 64-bit per-lane pointer (the round-3 kernel spilled those)
-__device__ __forceinline__ void load_row_chain_off(const float* __restrict__ base, unsigned row_off, f32x16 (&X)[4]) {
+// fp16 tables: the 64 features of row `row_off / 256` that lane (slot, half) owns = eight 16-byte groups, 32 bytes apart
+__device__ __forceinline__ void load_row_tab16(const float* __restrict__ base, unsigned row_off, gamd_u32x4 (&X)[8]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + (size_t)row_off + (32 * t + 8 * q) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) X[t][q * 4 + j] = v[j];
-        }
+    for (int c = 0; c < 8; ++c)
+        X[c] = *reinterpret_cast<const gamd_u32x4*>(reinterpret_cast<const char*>(base) + (size_t)row_off + 32 * c);
+}
+// d = (float)a.h[HI_A] * 1.0 + (float)c.h[HI_C]  /  (float)a.h[HI_A] * b + c : one v_fma_mix_f32 each (fp16 sources converted
+// inside the instruction, fp32 arithmetic, one rounding)
+// (hi_a / hi_c / hi: which half of the dword; constants after unrolling)
+__device__ __forceinline__ float add_h_h(unsigned a, unsigned c, bool HI_A, bool HI_C) {
+    float d;
+    if (HI_A && HI_C) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
+    else if (HI_A)    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
+    else if (HI_C)    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
+    else              asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_h_f_f(unsigned a, float b, float c, bool HI_A) {
+    float d;
+    if (HI_A) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    else      asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
 
 #ifndef BF16_NW
@@ -38,24 +55,44 @@ __device__ __forceinline__ void load_row_chain_off(const float* __restrict__ bas
 #define BF16_FETCH_AFTER_GEMM4 1
 #endif
 #ifndef BF16_PREFETCH_E
-#define BF16_PREFETCH_E 0
+#define BF16_PREFETCH_E 1
 #endif
 constexpr int CONVB_LDS_BYTES = 4 * GAMD_WFRAG_BF16_BYTES + 3 * 128 * 4;
 
 // ABL (profiling build only, wrong results by construction): timing ablations selected with GAMD_BF16_VARIANT
 //   1 SiLU -> x / 2   2 every gather from the zero row   4 no piece stores   8 no LDS weight fill   16 no MFMAs
 //   32 the S / D (chain-layout) gathers alone from the zero row
+//   128 GEMMs without their LDS weight reads (one fragment quad, read once)   256 GEMMs without MFMAs (operands and weight
+//   reads stay live: an empty asm statement per MFMA consumes them and "writes" the accumulator)
+template <int ABL, bool F2>
+__device__ __forceinline__ void gemm_abl(const bf16x8* W, int lane, const bf16x8 (&P)[4][2], f32x16 (&acc)[4]) {
+    if (ABL & 16) return;
+    if (!(ABL & (128 | 256))) { gemm128_bf16_pf<F2, BF16_RING>(W, lane, P, acc); return; }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 w0 = W[lane];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int tp = i & 3, t = i >> 3, u = (i >> 2) & 1;
+        const bf16x8 cur = (ABL & 128) ? w0 : W[((tp * 4 + t) * 2 + u) * 64 + lane];
+        if (ABL & 256) asm volatile("" : "+v"(acc[tp]) : "v"(cur), "v"(P[t][u]));
+        else acc[tp] = F2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(P[t][u], cur, acc[tp], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, P[t][u], acc[tp], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
 template <int ABL>
 __device__ __forceinline__ float silu_abl(float x) { return (ABL & 1) ? 0.5f * x : gamd_silu_hw(x); }
 
-// SiLU of a 32 x 128 block + rounding to the bf16 operands of the next GEMM, two elements at a time: the three simple
-// operations of x * rcp(1 + exp2(-x log2 e)) as packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 on register pairs; the
-// constants live in registers because packed instructions take no literals), the two transcendentals per element as they
-// are.  Same IEEE operations per element as gamd_silu_hw, so the bits do not change.
-struct SiluK { gamd_f32x2 nl2e, one; };
+// SiLU of a 32 x 128 block + rounding to the bf16 operands of the next GEMM, two elements at a time.  The block arrives
+// multiplied by log2 e (x' = x log2 e: the scale sits in the weights and tables that feed it), so
+//     y' = x' * rcp(1 + exp2(-x')) = log2 e * SiLU(x)
+// costs two transcendentals (the negation is a source modifier), one packed add, one packed multiply and the packed conversion
+// per pair; the next GEMM's weights carry what takes the log2 e out again (W2 and W3 unchanged: their outputs are wanted
+// times log2 e; W4 times ln 2).  The constant lives in a register pair because packed instructions take no literals.
+struct SiluK { gamd_f32x2 one; };
 __device__ __forceinline__ SiluK silu_consts() {
-    SiluK k{{-1.4426950408889634f, -1.4426950408889634f}, {1.0f, 1.0f}};
-    asm volatile("" : "+v"(k.nl2e), "+v"(k.one));
+    SiluK k{{1.0f, 1.0f}};
+    asm volatile("" : "+v"(k.one));
     return k;
 }
 template <int ABL>
@@ -72,8 +109,7 @@ __device__ __forceinline__ void silu_pack_bf16(const f32x16 (&X)[4], bf16x8 (&P)
                 if (ABL & 1) {
                     y = x * gamd_f32x2{0.5f, 0.5f};
                 } else {
-                    const gamd_f32x2 a = x * k.nl2e;
-                    const gamd_f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                    const gamd_f32x2 e = {__builtin_amdgcn_exp2f(-x[0]), __builtin_amdgcn_exp2f(-x[1])};
                     const gamd_f32x2 d = e + k.one;
                     const gamd_f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
                     y = x * r;
@@ -103,20 +139,6 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
 
     const int tid = threadIdx.x, lane = tid & 63, slot = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {
-        f32x4* dst = reinterpret_cast<f32x4*>(ldsb);
-        const f32x4* s1 = reinterpret_cast<const f32x4*>(a.w1p);
-        const f32x4* s2 = reinterpret_cast<const f32x4*>(a.w2p);
-        const f32x4* s3 = reinterpret_cast<const f32x4*>(a.w3p);
-        const f32x4* s4 = reinterpret_cast<const f32x4*>(a.w4p);
-        if (!(ABL & 8))
-            for (int i = tid; i < 2048; i += 64 * BF16_NW) {
-                dst[i] = s1[i]; dst[2048 + i] = s2[i]; dst[4096 + i] = s3[i]; dst[6144 + i] = s4[i];
-            }
-        if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
-    }
-    __syncthreads();
-
     int E = a.counters[CNT_E];
     if ((long long)E > a.e_cap) E = (int)a.e_cap;
     const int n_tiles = (E + GAMD_TILE - 1) / GAMD_TILE;
@@ -135,14 +157,14 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
         const bool valid = tile < n_tiles && x < E;
         // padding slots of the last tile gather the all-zero row n of hn / S / D: their messages are exact zeros
         const int xc = valid ? x : 0;
-        const int s0 = a.col[xc], d0 = a.erow[xc];
+        const int s0 = GAMD_CHK_RANGE(a.sticky, a.col[xc], 0, a.zero_row, GAMD_CHK_CONV_SRC), d0 = GAMD_CHK_RANGE(a.sticky, a.erow[xc], 0, a.zero_row, GAMD_CHK_CONV_DST);
         src = valid ? s0 : a.zero_row; dst = valid ? d0 : a.zero_row;
         if (ABL & 2) { src = a.zero_row; dst = a.zero_row; }
     };
     const unsigned lane16 = 16u * (unsigned)lane, half16 = 16u * (unsigned)half;
     auto fetch_e = [&](int tile, bf16x8 (&P)[4][2]) {
         // (wave-uniform tile base in scalar registers) + (lane * 16) + (immediate)
-        const char* tb = reinterpret_cast<const char*>(efrag) + (size_t)(tile < n_tiles ? tile : 0) * 8192;
+        const char* tb = reinterpret_cast<const char*>(efrag) + (size_t)((tile < n_tiles && !(ABL & 512)) ? tile : 0) * 8192;   // ABL 512: every tile reads e tile 0 (no HBM stream)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -164,8 +186,26 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
     int tile = tile_of(first);
     int src, dst;
     bf16x8 P[4][2], Pn[4][2];
+    // Prologue: the first tile's indices and e fragments (HBM) are requested FIRST, then the four weight matrices go L2 -> LDS as
+    // 128 one-KiB LDS-DMA copies (16 per wave, all in flight at once, no register round trip), then ONE wait and ONE barrier.
+    // (Rounds 3-5 copied through registers in four dependent round trips of 4 loads + 4 ds_write_b128 per thread and only then
+    // asked for the first indices: three more serial round trips before the first MFMA of every workgroup.)
     fetch_idx(tile, src, dst);
     fetch_e(tile, P);
+    if (!(ABL & 8)) {
+        unsigned l16 = lane16;
+        asm volatile("" : "+v"(l16));
+#pragma unroll
+        for (int k = 0; k < 128 / BF16_NW; ++k) {
+            const int chunk = k * BF16_NW + wave;               // 128 chunks of 1 KiB: matrix chunk >> 5, KiB chunk & 31 of it
+            const float* gw = (chunk >> 5) == 0 ? a.w1p : (chunk >> 5) == 1 ? a.w2p : (chunk >> 5) == 2 ? a.w3p : a.w4p;
+            const char* base = reinterpret_cast<const char*>(gw) + (chunk & 31) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + l16),
+                                             (__attribute__((address_space(3))) void*)(ldsb + chunk * 1024), 16, 0, 0);
+        }
+    }
+    if (tid < 128) { vb1[tid] = a.b1[tid]; vb3[tid] = a.b3[tid]; vb4[tid] = a.b4[tid]; }
+    __syncthreads();                                             // (its release fence waits for the DMA copies: vmcnt(0))
 
     for (int wt = first; wt < end; wt += step) {
         if (tile >= n_tiles) break;                  // this wave's tiles are exhausted (tile numbers grow with wt)
@@ -175,38 +215,44 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
         fetch_idx(tile_n, src_n, dst_n);
 
         if (TIME) tprev = (long long)__builtin_readcyclecounter();
-        f32x16 RA[4], RB[4], RC[4];
+        f32x16 RB[4], RC[4];
+        gamd_u32x4 S16[8], D16[8];                     // fp16 S[src] / D[dst] rows: the 64 features this lane owns, 8 groups of 8
+        gamd_u32x2 H16[4][4];                          // fp16 hn[src] of the 16 edges of this half: features 4 slot .. 4 slot + 3
         // phase 1: T1 = SiLU(W1 e + b1).  The S[src] / D[dst] rows of phase 2 are gathered behind the GEMM (their round trip
-        // rides under the SiLU block): issued at the top of the tile they hold 128 registers through the GEMM, which leaves no
-        // room for the weight-fragment ring
+        // rides under the SiLU block)
         load_bias_chain(vb1, half, RC);
         BT(0);                                         // bias init (+ wait for e)
-        if (!(ABL & 16)) gemm128_bf16_pf<false, BF16_RING>(W1, lane, P, RC);
+        gemm_abl<ABL, false>(W1, lane, P, RC);
         BT(1);                                         // GEMM 1
         // (ABL 32: only the S / D gathers from the zero row, the hn gather as it is: what the chain-layout gather alone costs)
-        load_row_chain_off(a.S, ((unsigned)((ABL & 32) ? a.zero_row : src) << 9) + half16, RA);
-        load_row_chain_off(a.D, ((unsigned)((ABL & 32) ? a.zero_row : dst) << 9) + half16, RB);
+        load_row_tab16(a.S, ((unsigned)((ABL & 32) ? a.zero_row : src) << 8) + half16, S16);
+        load_row_tab16(a.D, ((unsigned)((ABL & 32) ? a.zero_row : dst) << 8) + half16, D16);
         BT(2);                                         // S / D gather issue
         silu_pack_bf16<ABL>(RC, P, sk);
         BT(3);                                         // SiLU 1 + pack
         if (BF16_PREFETCH_E) fetch_e(tile_n, Pn);     // next tile's e: three phases to land
-        // phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst])
+        // phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]); group c = 2 t + k holds X[t][8 k .. 8 k + 7], two fp16 per dword
 #pragma unroll
-        for (int t = 0; t < 4; ++t) RB[t] += RA[t];
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                RB[c >> 1][8 * (c & 1) + 2 * i] = add_h_h(S16[c][i], D16[c][i], false, false);
+                RB[c >> 1][8 * (c & 1) + 2 * i + 1] = add_h_h(S16[c][i], D16[c][i], true, true);
+            }
         BT(4);                                         // S + D (waits for both gathers)
-        if (!(ABL & 16)) gemm128_bf16_pf<false, BF16_RING>(W2, lane, P, RB);
+        gemm_abl<ABL, false>(W2, lane, P, RB);
         BT(5);                                         // GEMM 2
         silu_pack_bf16<ABL>(RB, P, sk);
         BT(6);                                         // SiLU 2 + pack
-        // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge): RA is free now
+        // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge)
         const int x0 = tile * GAMD_TILE + 16 * half;
         int nvalid = E - x0;
         nvalid = nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid);
-        // (W4's output rows are packed permuted, gamd_finalize_weights: lane = features 4 slot .. 4 slot + 3, one 16-byte load
-        // per edge, landing in RA[r >> 2][4 (r & 3) + tp]; one bpermute index register + immediate lane offsets, scalar base +
-        // 32-bit offset addressing: conv_edge.hip's gather_hn2)
+        // (W4's output rows are packed permuted, gamd_finalize_weights: lane = features 4 slot .. 4 slot + 3, one 8-byte load
+        // per edge, H16[r >> 2][r & 3]; one bpermute index register + immediate lane offsets, scalar base + 32-bit offset
+        // addressing: conv_edge.hip's gather_hn2)
         {
-            const unsigned soff = (unsigned)src << 9, idx0 = 16u * (unsigned)half, slot16 = 16u * (unsigned)slot;
+            const unsigned soff = (unsigned)src << 8, idx0 = 16u * (unsigned)half, slot8 = 8u * (unsigned)slot;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 unsigned o0, o1, o2, o3;
@@ -216,23 +262,20 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
                              : "v"(idx0), "v"(soff), "n"(4 * (0 + 8 * r4)), "n"(4 * (1 + 8 * r4)), "n"(4 * (2 + 8 * r4)), "n"(4 * (3 + 8 * r4)));
                 const unsigned o[4] = {o0, o1, o2, o3};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x4 hv = *(const f32x4*)((const char*)a.hn + (o[k] + slot16));
-#pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) RA[r4][k * 4 + tp] = hv[tp];
-                }
+                for (int k = 0; k < 4; ++k)
+                    H16[r4][k] = *(const gamd_u32x2*)((const char*)a.hn + (o[k] + slot8));
             }
         }
         BT(7);                                         // hn gather issue (bpermutes + 16 loads)
         // phase 3: T4 = SiLU(W3 T3 + b3)
         load_bias_chain(vb3, half, RC);
-        if (!(ABL & 16)) gemm128_bf16_pf<false, BF16_RING>(W3, lane, P, RC);
+        gemm_abl<ABL, false>(W3, lane, P, RC);
         BT(8);                                         // GEMM 3
         silu_pack_bf16<ABL>(RC, P, sk);
         BT(9);                                         // SiLU 3 + pack
         // phase 4: e_emb = T4 W4^T + b4 (F2), message, segment sum (fp32)
         const unsigned mask = a.chunk_mask[tile * 2 + half];
-        int p = a.chunk_piece[tile * 2 + half];
+        int p = GAMD_CHK_RANGE(a.sticky, a.chunk_piece[tile * 2 + half], 0, a.piece_cap - 17, GAMD_CHK_PIECE);
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
             const float b = vb4[32 * tp + slot];
@@ -240,7 +283,7 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
             for (int r = 0; r < 16; ++r) RB[tp][r] = b;
         }
         BT(10);                                        // chunk metadata loads + b4 init
-        if (!(ABL & 16)) gemm128_bf16_pf<true, BF16_RING>(W4, lane, P, RB);
+        gemm_abl<ABL, true>(W4, lane, P, RB);
         BT(11);                                        // GEMM 4
         if (!BF16_PREFETCH_E && BF16_FETCH_AFTER_GEMM4) fetch_e(tile_n, P);      // P is free: the next tile's e rides under the message / store block
         const unsigned keep_bits = ~(mask << 1);
@@ -248,7 +291,7 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
         for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                RB[tp][r] = gamd_msg_acc(RA[r >> 2][(r & 3) * 4 + tp], RB[tp][r], (r > 0 && ((keep_bits >> r) & 1u)) ? RB[tp][r - 1] : 0.f);
+                RB[tp][r] = fma_h_f_f(H16[r >> 2][r & 3][tp >> 1], RB[tp][r], (r > 0 && ((keep_bits >> r) & 1u)) ? RB[tp][r - 1] : 0.f, (tp & 1) != 0);
         BT(12);                                        // message + segment sum (waits for hn)
         unsigned ends = mask;
         if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends |= 1u << (nvalid - 1);
@@ -326,6 +369,16 @@ int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
         case 31: return launch_bf16_abl<31>(a, n_blocks, st);
         case 32: return launch_bf16_abl<32>(a, n_blocks, st);
         case 64: return launch_bf16_abl<64>(a, n_blocks, st);
+        case 128: return launch_bf16_abl<128>(a, n_blocks, st);
+        case 256: return launch_bf16_abl<256>(a, n_blocks, st);
+        case 257: return launch_bf16_abl<257>(a, n_blocks, st);
+        case 263: return launch_bf16_abl<263>(a, n_blocks, st);
+        case 9: return launch_bf16_abl<9>(a, n_blocks, st);
+        case 512: return launch_bf16_abl<512>(a, n_blocks, st);
+        case 391: return launch_bf16_abl<391>(a, n_blocks, st);
+        case 775: return launch_bf16_abl<775>(a, n_blocks, st);
+        case 903: return launch_bf16_abl<903>(a, n_blocks, st);
+        case 384: return launch_bf16_abl<384>(a, n_blocks, st);
         default: break;
     }
 #endif

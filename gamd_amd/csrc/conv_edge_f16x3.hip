@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_f16x3(ConvEdgeArgs a) {
     int src = a.zero_row, dst = a.zero_row;
     {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
-        if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
+        if (active && x < E) { src = GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_CONV_SRC); dst = GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_CONV_DST); }
         if (active) load_e_tile_s(a.e_frag, tile, lane16, PA);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the W1 copy is not tracked by hipcc
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_f16x3(ConvEdgeArgs a) {
             // gathers: scalar base + 32-bit lane offset + immediate (no 64-bit per-lane pointers)
             const unsigned soff = ((unsigned)src << 9) + 16u * (unsigned)half, doff = ((unsigned)dst << 9) + 16u * (unsigned)half;
             const unsigned mask = a.chunk_mask[tile * 2 + half];
-            const int p0 = a.chunk_piece[tile * 2 + half];
+            const int p0 = GAMD_CHK_RANGE(a.sticky, a.chunk_piece[tile * 2 + half], 0, a.piece_cap - 17, GAMD_CHK_PIECE);
             // ===== phase 1: T1 = SiLU(W1 e + b1) =====
             gemm128_f16x3_lazy<false>((const f16x8*)buf0, lane, PA, ACC, [&](int tp) { ACC[tp] = bias_block(vb1, tp, half); },
                 [&](int tp, int r0) { silu_split_pair(PB, tp, r0, ACC[tp][r0], ACC[tp][r0 + 1], sk); },
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_f16x3(ConvEdgeArgs a) {
             // ===== phase 3: T4 = SiLU(W3 T3 + b3); hn[src] rows for phase 4 =====
             if (active_n) {
                 const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
-                if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
+                if (xn < E) { src_n = GAMD_CHK_RANGE(a.sticky, a.col[xn], 0, a.zero_row, GAMD_CHK_CONV_SRC); dst_n = GAMD_CHK_RANGE(a.sticky, a.erow[xn], 0, a.zero_row, GAMD_CHK_CONV_DST); }
             }
             // hn[src] rows of edges 4 r4 .. 4 r4 + 3 of this half (row layout: lane = feature, register = edge; rows are stored
             // permuted, node.hip hn_perm: one 16-byte load per edge): the row offset of edge r lives in lane rho(r, half) -- one

@@ -36,8 +36,8 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
-        const int src = valid ? a.col[x] : 0;
-        const int dst = valid ? a.erow[x] : 0;
+        const int src = valid ? GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_CONV_SRC) : 0;
+        const int dst = valid ? GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_CONV_DST) : 0;
         f32x16 X[4], XE[EHT][4], acc;
         WQuarter wa, wb;
         const float* wblk = a.w1p;                       // block k at wblk + k * GAMD_WFRAG_FLOATS
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_conv_edge_small(ConvEdgeArgs a) {
             for (int ob = 0; ob < HT; ++ob) hn_q[ob][r] = a.hn[(size_t)s * H + feat4(ob)];
         }
         const unsigned mask = a.chunk_mask[tile * 2 + half];
-        const int p0 = a.chunk_piece[tile * 2 + half];
+        const int p0 = GAMD_CHK_RANGE(a.sticky, a.chunk_piece[tile * 2 + half], 0, a.piece_cap - 17, GAMD_CHK_PIECE);
         const int x0 = tile * GAMD_TILE + 16 * half;
         int nvalid = E - x0;
         nvalid = nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid);

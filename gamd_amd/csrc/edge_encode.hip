@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode(EncArgs a) {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool ok = tile < n_tiles && x < E32;
         const int xc = ok ? x : 0;
-        src = a.col[xc]; dst = a.erow[xc];
+        src = GAMD_CHK_RANGE(a.sticky, a.col[xc], 0, a.zero_row, GAMD_CHK_ENC_SRC); dst = GAMD_CHK_RANGE(a.sticky, a.erow[xc], 0, a.zero_row, GAMD_CHK_ENC_DST);
         return ok;
     };
     int src_c, dst_c;
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) k_edge_encode_small(EncArgs a) {
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
-        const int src = valid ? a.col[x] : 0, dst = valid ? a.erow[x] : 0;
+        const int src = valid ? GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_ENC_SRC) : 0, dst = valid ? GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_ENC_DST) : 0;
         const float4 ps = a.pos_s[src], pd = a.pos_s[dst];
         f32x4 w1[6];
 #pragma unroll

@@ -29,12 +29,22 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
 
     const int tid = threadIdx.x;
     {
-        f32x4* d = reinterpret_cast<f32x4*>(ldsb);
-        const f32x4* s1 = reinterpret_cast<const f32x4*>(a.w1p);
-        const f32x4* s2 = reinterpret_cast<const f32x4*>(a.w2p);
-        const f32x4* s3 = reinterpret_cast<const f32x4*>(a.w3p);
-        for (int i = tid; i < ENCB_W1_BYTES / 16; i += 512) d[i] = s1[i];
-        for (int i = tid; i < 2048; i += 512) { d[ENCB_W1_BYTES / 16 + i] = s2[i]; d[ENCB_W1_BYTES / 16 + 2048 + i] = s3[i]; }
+        // weights L2 -> LDS as 76 one-KiB LDS-DMA copies (W1 12 KiB | W2 32 KiB | W3 32 KiB: the LDS image is contiguous), all in
+        // flight at once, one wait + one barrier (conv_edge_bf16.hip's prologue)
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        unsigned l16 = 16u * (unsigned)(tid & 63);
+        asm volatile("" : "+v"(l16));
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const int chunk = k * 8 + wv;
+            if (chunk < 76) {
+                const char* base = chunk < 12 ? reinterpret_cast<const char*>(a.w1p) + chunk * 1024
+                                 : chunk < 44 ? reinterpret_cast<const char*>(a.w2p) + (chunk - 12) * 1024
+                                              : reinterpret_cast<const char*>(a.w3p) + (chunk - 44) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + l16),
+                                                 (__attribute__((address_space(3))) void*)(ldsb + chunk * 1024), 16, 0, 0);
+            }
+        }
         if (tid < 128) { vb1[tid] = a.b1[tid]; vb2[tid] = a.b2[tid]; vb3[tid] = a.b3[tid]; vg[tid] = a.ln_g[tid]; vbeta[tid] = a.ln_b[tid]; }
         if (tid < 40) cen[tid] = a.centers[tid];
     }
@@ -55,8 +65,8 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
         if (tile >= n_tiles) continue;
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
-        const int src = valid ? a.col[x] : 0;
-        const int dst = valid ? a.erow[x] : 0;
+        const int src = valid ? GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_ENC_SRC) : 0;
+        const int dst = valid ? GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_ENC_DST) : 0;
         const float4 ps = a.pos_s[src], pd = a.pos_s[dst];
         const BoxDims B = gamd_edge_box(a, dst);
         const float rx = gamd_min_image_wrapped(ps.x - pd.x, B.bx, B.hx);
@@ -107,7 +117,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
         pack_chain_bf16(acc, P);
         // GEMM 2
         load_bias_chain(vb2, half, acc);
-        gemm128_bf16<false>(W2, lane, P, acc);
+        gemm128_bf16_pf<false, 8>(W2, lane, P, acc);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -115,7 +125,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
         pack_chain_bf16(acc, P);
         // GEMM 3 + LayerNorm (fp32)
         load_bias_chain(vb3, half, acc);
-        gemm128_bf16<false>(W3, lane, P, acc);
+        gemm128_bf16_pf<false, 8>(W3, lane, P, acc);
         layernorm_chain(acc, vg, vbeta, half, 1e-5f);
         pack_chain_bf16(acc, P);
 #pragma unroll

@@ -59,8 +59,8 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_f16x3(EncArgs a) {
         asm volatile("" ::: "memory");                       // keep loop-invariant LDS reads inside the loop
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = x < E;
-        const int src = valid ? a.col[x] : 0;
-        const int dst = valid ? a.erow[x] : 0;
+        const int src = valid ? GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_ENC_SRC) : 0;
+        const int dst = valid ? GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_ENC_DST) : 0;
         const float4 ps = a.pos_s[src], pd = a.pos_s[dst];
         const BoxDims B = gamd_edge_box(a, dst);
         const float rx = gamd_min_image_wrapped(ps.x - pd.x, B.bx, B.hx);

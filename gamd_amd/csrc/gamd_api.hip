@@ -38,6 +38,28 @@ struct HostTensor {
     std::vector<float> data;
 };
 
+// Initialising work — zeroing a fresh buffer, uploading a small table — goes to ONE stream and is waited for on THAT stream
+// before the call returns: the caller's stream inside the entry points that take one, the handle's private non-blocking
+// stream everywhere else (gamd_create, gamd_finalize_weights, gamd_set_bonds).  Nothing is ordered on, or waits for, the NULL
+// stream: a hipMemset / hipMemcpy there is asynchronous to the host for device memory and not ordered with a non-blocking
+// stream at all (round 5: the momentum sums of a run's first step, com_partial, were wiped after k_com_partial on the caller's
+// non-blocking stream had written them, once in ~300 runs), and a NULL-stream synchronise inside a library stalls every
+// blocking stream of the process.  InitStream is set by every entry point (RAII, per thread: different handles may be driven
+// from different threads).
+thread_local hipStream_t tl_init_stream = nullptr;
+struct InitStream {
+    hipStream_t prev;
+    explicit InitStream(hipStream_t st) : prev(tl_init_stream) { tl_init_stream = st; }
+    ~InitStream() { tl_init_stream = prev; }
+    InitStream(const InitStream&) = delete;
+    InitStream& operator=(const InitStream&) = delete;
+};
+// host -> device upload of a small table from pageable memory, landed before it returns
+hipError_t init_upload(void* dst, const void* src, size_t bytes) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, tl_init_stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(tl_init_stream);
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -48,12 +70,10 @@ struct DevBuf {
         if (e != hipSuccess) return (int)e;
         bytes = want;
         if (zero) {
-            // hipMemset of device memory is asynchronous to the host and ordered on the NULL stream only: a kernel that the
-            // caller's non-blocking stream runs next is not ordered behind it and could have its first results zeroed under it
-            // (seen once in ~300 runs: the momentum sums of a run's first step, com_partial, wiped after k_com_partial wrote
-            // them -> centre-of-mass velocity 0 / 0).  Allocations are rare: wait for the memset.
-            e = hipMemset(p, 0, want);
-            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+            // on the call's stream (InitStream) and waited for there: allocations are rare, and what a call allocates and
+            // initialises has landed before it returns whatever stream the next call comes on
+            e = hipMemsetAsync(p, 0, want, tl_init_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(tl_init_stream);
             if (e != hipSuccess) return (int)e;
         }
         return 0;
@@ -138,6 +158,7 @@ struct gamd_handle {
     int ncell_cap = 0;
     // edges
     long long e_cap = 0;
+    long long piece_cap = 0;        // rows of `partial`
     DevBuf col, erow, chunk_piece, chunk_mask, e_frag, partial, feat_dbg, e_emb, e_frag2;
     DevBuf counters, tdbg, tmp_eid, ke_partial, com_partial;
     DevBuf cnt2;                    // small systems in skin mode: two counter blocks used alternately (no per-call memset)
@@ -147,6 +168,7 @@ struct gamd_handle {
     int* counters_host = nullptr;   // pinned
     int* sticky_host = nullptr;     // pinned + mapped: overflow flags and rebuild count, written by kernels directly
     int* sticky_dev = nullptr;
+    hipStream_t init_stream = nullptr;   // private non-blocking stream: initialising memsets / uploads of the entry points without a stream argument
     DevBuf devflags;                // [DEVFLAG_COUNT] device-resident freeze flag + where an MD run stopped
     const float* feat_dev = nullptr;   // gamd_set_node_features
     const uint8_t* rigid_checked = nullptr;   // species pointer whose O,H,H layout has been validated
@@ -170,8 +192,10 @@ struct gamd_handle {
     size_t tev_used = 0;
     // one event at the top of every MD step of an enqueued run (and one behind the last): gamd_timing_read_steps
     std::vector<hipEvent_t> sev;
+    std::vector<uint8_t> sev_closes; // per event: 1 = recorded BEHIND the last step of an enqueue (the interval to the next event
+                                     // is the host's gap between two runs, not a step)
     size_t sev_used = 0;
-    size_t sev_run_begin = 0;        // first event of the gamd_md_run / gamd_md_run_nhc call being enqueued
+    static constexpr size_t EVENT_POOL_CAP = 1u << 16;   // timing left on across a long run: recording stops here (never unbounded)
 };
 
 namespace {
@@ -216,6 +240,7 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
     r |= h->chunk_mask.ensure(sizeof(unsigned) * (ec / GAMD_CHUNK + 2), true);
     r |= h->e_frag.ensure(sizeof(float) * 4096 * (size_t)h->EHT * (ec / GAMD_TILE + 1), false);
     r |= h->partial.ensure(sizeof(float) * (size_t)h->H * (ec / GAMD_CHUNK + (size_t)h->n + 2), false);
+    h->piece_cap = (long long)(ec / GAMD_CHUNK + (size_t)h->n + 2);
     if (h->update_edge) {                        // e_emb rows of one layer and the updated embedding tiles (H == Eh)
         r |= h->e_emb.ensure(sizeof(float) * (size_t)h->H * ec, false);
         r |= h->e_frag2.ensure(sizeof(float) * 4096 * (size_t)h->EHT * (ec / GAMD_TILE + 1), false);
@@ -279,8 +304,7 @@ int set_box(gamd_handle* h, const float* box, hipStream_t st = nullptr) {
             for (int d = 0; d < 3; ++d) { img[(size_t)12 * b + d] = box[3 * b + d]; img[(size_t)12 * b + 4 + d] = 0.5f * box[3 * b + d]; }
             memcpy(&img[(size_t)12 * b + 8], &grid[(size_t)4 * b], 4 * sizeof(int));
         }
-        HIP_TRY(hipMemcpy(h->boxes_dev.p, img.data(), sizeof(float) * img.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipStreamSynchronize(nullptr));
+        HIP_TRY(init_upload(h->boxes_dev.p, img.data(), sizeof(float) * img.size()));
     }
     return 0;
 }
@@ -550,6 +574,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     ea.e_format = !h->wide_enc ? 0 : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? 2 : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? 1 : 0;
     ea.e_frag = h->e_frag.as<float>();
     ea.e_cap = h->e_cap;
+    ea.sticky = h->sticky_dev;
     ea.feat_dbg = h->cfg.keep_stages ? h->feat_dbg.as<float>() : nullptr;
     // fp32 path, few tiles (measured crossover ~500 tiles, half a tile per SIMD): the latency-oriented kernels, one tile
     // per 4-wave workgroup (conv_edge_small.hip, k_edge_encode_small).  They are bit-identical to the throughput kernels, so
@@ -561,16 +586,19 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
         if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
     }
+    bool tev_full = false;
     auto tev_begin = [&](int kind) -> int {
         if (!h->timing) return 0;
-        if (h->tev_used + 2 > h->tev.size())
+        if (h->tev_used + 2 > h->tev.size()) {
+            if (h->tev.size() >= 8 * gamd_handle::EVENT_POOL_CAP) { tev_full = true; return 0; }   // pool full: not timed any more
             for (int k = 0; k < 256; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->tev.push_back(e); h->tev_kind.push_back(0); }
+        }
         h->tev_kind[h->tev_used] = kind;
         HIP_TRY(hipEventRecord(h->tev[h->tev_used], st));
         return 0;
     };
     auto tev_end = [&]() -> int {
-        if (!h->timing) return 0;
+        if (!h->timing || tev_full) return 0;
         HIP_TRY(hipEventRecord(h->tev[h->tev_used + 1], st));
         h->tev_used += 2;
         return 0;
@@ -596,13 +624,14 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     no.devflags = h->devflags.as<int>();
     no.sticky = h->sticky_dev;
     no.n = h->n;
-    no.n_cu = h->n_cu;
     no.pos_s = h->pos_s.as<float4>();
     no.node_emb = h->node_emb; no.enc_w = h->nenc_w; no.enc_b = h->nenc_b;
     no.row_ptr = h->row_ptr.as<int>(); no.na_excl = h->na_excl.as<int>(); no.deg = h->deg.as<int>();
     no.partial = h->partial.as<float>();
+    no.piece_cap = h->piece_cap;
     no.P_in = h->P.as<float>();
     no.hn_perm = (!h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F16X3) ? 1 : 0;
+    no.tab16 = (!h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_BF16) ? 1 : 0;       // conv_edge_bf16.hip gathers fp16 rows
     no.hn_out = h->hn.as<float>(); no.S_out = h->S.as<float>(); no.D_out = h->D.as<float>(); no.P_out = h->P.as<float>();
     no.dec_w1p = h->dec_w1p; no.dec_b1 = h->dec_b1; no.dec_w2 = h->dec_w2; no.dec_b2 = h->dec_b2;
     no.ln_inv_width = 1.0f / (float)h->H_true;
@@ -636,8 +665,15 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.w1p = ld.w1p; ca.w2p = ld.w2p; ca.w3p = ld.w3p; ca.w4p = ld.w4p;
         ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
         ca.partial = h->partial.as<float>();
+        ca.piece_cap = h->piece_cap;
+        ca.sticky = h->sticky_dev;
         ca.e_cap = h->e_cap;
         ca.zero_row = h->n;
+#ifdef GAMD_CHECKED
+        // fault injection for tests/test_gpu_checked.py: the conv kernels are told that the node tables end at row 0, so the
+        // first source index above it must be reported (GAMD_CHK_CONV_SRC) and clamped
+        { static const bool inject = getenv("GAMD_CHK_INJECT") != nullptr; if (inject) ca.zero_row = 0; }
+#endif
         ca.tdbg = h->tdbg.as<long long>();
         if ((r = tev_begin(l))) return r;                        // kind l: conv-layer edge kernel of layer l
         r = h->wide_conv ? (h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3_wide(ca, h->EHT, h->HT, h->n_cu, st)
@@ -677,6 +713,15 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     return 0;
 }
 
+// checked build: a device-side range check (GAMD_CHK_RANGE) failed in some kernel since the last report
+int check_traps(gamd_handle* h) {
+    const int code = h->sticky_host[STICKY_CHECK_CODE];
+    if (!code) return 0;
+    const int value = h->sticky_host[STICKY_CHECK_VALUE], line = h->sticky_host[STICKY_CHECK_LINE];
+    h->sticky_host[STICKY_CHECK_CODE] = 0;
+    return fail(-35, "checked build: device-side range check %d failed (value %d, source line %d)", code, value, line);
+}
+
 int check_ready(gamd_handle* h) {
     if (!h) return fail(-22, "null handle");
     if (!h->finalized) return fail(-22, "weights not finalized (call gamd_finalize_weights)");
@@ -707,17 +752,19 @@ int check_rigid_layout(gamd_handle* h, const uint8_t* species_dev, hipStream_t s
 
 int clear_devflags(gamd_handle* h) {
     const int init[2] = {0, -1};                             // FROZEN, FROZEN_AT; the rebuild counter behind them stays
-    HIP_TRY(hipMemcpy(h->devflags.p, init, sizeof(init), hipMemcpyHostToDevice));
-    HIP_TRY(hipStreamSynchronize(nullptr));                  // (a copy from pageable memory may return before the DMA has landed)
+    HIP_TRY(init_upload(h->devflags.p, init, sizeof(init)));
     return 0;
 }
 
 // live timing: a HIP event on the launch stream in front of the first kernel of an MD step (and behind the last kernel of
 // the run); consecutive events bracket one step.  Events are created outside the timed region (gamd_timing_enable).
-int step_event(gamd_handle* h, hipStream_t st) {
+int step_event(gamd_handle* h, hipStream_t st, bool closes = false) {
     if (!h->timing) return 0;
-    if (h->sev_used == h->sev.size())
-        for (int k = 0; k < 256; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->sev.push_back(e); }
+    if (h->sev_used == h->sev.size()) {
+        if (h->sev.size() >= gamd_handle::EVENT_POOL_CAP) return 0;          // pool full: the rest of the run is not timed
+        for (int k = 0; k < 256; ++k) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->sev.push_back(e); h->sev_closes.push_back(0); }
+    }
+    h->sev_closes[h->sev_used] = closes ? 1 : 0;
     HIP_TRY(hipEventRecord(h->sev[h->sev_used++], st));
     return 0;
 }
@@ -764,7 +811,7 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
             p.m.step_index = (int)(p.n_steps - 1);
             if ((r = launch_baoab_second(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
         }
-        return step_event(h, p.st);
+        return step_event(h, p.st, true);
     }
     for (long long s = s_begin; s < p.n_steps; ++s) {
         if ((r = step_event(h, p.st))) return r;
@@ -783,14 +830,18 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
             if ((r = launch_nhc_second(p.a, p.st))) return fail(-1, "integrator launch failed (%d)", r);
         }
     }
-    return step_event(h, p.st);
+    return step_event(h, p.st, true);
 }
 
 }  // namespace
 
 extern "C" {
 
+#ifdef GAMD_CHECKED
+const char* gamd_version(void) { return "gamd_hip 0.1 (gfx950) checked"; }       // libgamd_hip_chk.so: device-side range checks
+#else
 const char* gamd_version(void) { return "gamd_hip 0.1 (gfx950)"; }
+#endif
 const char* gamd_last_error(void) { return g_err; }
 
 int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
@@ -838,6 +889,12 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     gamd_handle* h = new gamd_handle();
     h->cfg = *cfg;
     h->dev = cfg->device;
+    if (hipStreamCreateWithFlags(&h->init_stream, hipStreamNonBlocking) != hipSuccess) {
+        h->init_stream = nullptr;
+        gamd_destroy(h);
+        return fail(-12, "stream creation failed");
+    }
+    InitStream init(h->init_stream);
     h->n_boxes = n_boxes;
     h->n_per_box = cfg->n_atoms;
     h->n = cfg->n_atoms * n_boxes;
@@ -885,7 +942,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     if (r) { gamd_destroy(h); return fail(-12, "device allocation failed"); }
     {
         const int no_atom = -2;
-        if (hipMemcpy(h->perm.as<int>() + n, &no_atom, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        if (init_upload(h->perm.as<int>() + n, &no_atom, sizeof(int)) != hipSuccess) {
             gamd_destroy(h);
             return fail(-1, "device copy failed");
         }
@@ -932,7 +989,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     }
     if (cfg->self_loop_mode) ecap += h->n;
     if ((r = alloc_edges(h, ecap))) { gamd_destroy(h); return r; }
-    if (hipStreamSynchronize(nullptr) != hipSuccess) { gamd_destroy(h); return fail(-1, "device synchronisation failed"); }
+    if (hipStreamSynchronize(h->init_stream) != hipSuccess) { gamd_destroy(h); return fail(-1, "device synchronisation failed"); }
     *out = h;                                  // every initialising memset / copy has landed: any stream may use the handle
     return 0;
 }
@@ -940,6 +997,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
 int32_t gamd_destroy(gamd_handle* h) {
     if (!h) return 0;
     DeviceGuard guard(h->dev);
+    InitStream init(h->init_stream);
     h->devflags.release();
     h->cnt2.release();
     DevBuf* bufs[] = {&h->boxes_dev, &h->box_shift, &h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
@@ -952,6 +1010,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     if (h->sticky_host) (void)hipHostFree(h->sticky_host);
     for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->sev) (void)hipEventDestroy(e);
+    if (h->init_stream) (void)hipStreamDestroy(h->init_stream);
     delete h;
     return 0;
 }
@@ -970,6 +1029,7 @@ int32_t gamd_load_weight(gamd_handle* h, const char* name, const float* data, co
 int32_t gamd_finalize_weights(gamd_handle* h) {
     if (!h) return fail(-22, "null handle");
     DeviceGuard guard(h->dev);
+    InitStream init(h->init_stream);
     const int F = h->n_feat, L = h->L;
     const int64_t H = h->H, Eh = h->Eh, HT = h->HT, EHT = h->EHT;         // padded widths the kernels work in
     const int64_t Ht = h->H_true, Et = h->Eh_true, Dt = h->D_true;        // the state_dict's widths
@@ -1095,6 +1155,21 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             }
             padded.push_back(std::move(al)); ng = &padded.back();
             padded.push_back(std::move(be)); nb = &padded.back();
+        }
+        // bf16 edge MLP (conv_edge_bf16.hip): the pre-activations of the layer's three SiLUs are computed times log2 e, so that
+        // SiLU(x) log2 e = x' / (1 + 2^-x') needs no multiply in front of its exponential: W1, b1 (first SiLU), the S / D tables
+        // (second: W2 sees the first SiLU's output times log2 e and needs no factor itself), b3 (third) carry log2 e, W4 ln 2
+        if (bf16_edges) {
+            auto scaled = [&](const HostTensor* t, double f) -> const HostTensor* {
+                HostTensor o = *t;
+                for (float& v : o.data) v = (float)((double)v * f);
+                padded.push_back(std::move(o));
+                return &padded.back();
+            };
+            const double LOG2E = 1.4426950408889634, LN2 = 0.6931471805599453;
+            ea0w = scaled(ea0w, LOG2E); ea0b = scaled(ea0b, LOG2E); t1b = scaled(t1b, LOG2E); t3w = scaled(t3w, LN2);
+            sw = scaled(sw, LOG2E); dw = scaled(dw, LOG2E);
+            sb = scaled(sb, LOG2E); db = scaled(db, LOG2E); ea2b = scaled(ea2b, LOG2E);      // bS = (b_src + b_dst) + b_edge_affine.2
         }
         Off& o = lo[l];
         HostTensor b4_perm;
@@ -1234,8 +1309,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     }
 
     if (h->wblob.ensure(sizeof(float) * bb.host.size(), false)) return fail(-12, "weight blob allocation failed");
-    HIP_TRY(hipMemcpy(h->wblob.p, bb.host.data(), sizeof(float) * bb.host.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(init_upload(h->wblob.p, bb.host.data(), sizeof(float) * bb.host.size()));
     const float* B = h->wblob.as<float>();
     h->layers.assign(L, LayerDev{});
     for (int l = 0; l < L; ++l) {
@@ -1271,6 +1345,7 @@ int32_t gamd_set_scaler(gamd_handle* h, double mean, double var) {
 int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds) {
     if (!h || (!bonds && n_bonds > 0)) return fail(-22, "bad argument to gamd_set_bonds");
     DeviceGuard guard(h->dev);
+    InitStream init(h->init_stream);
     std::vector<int> tab((size_t)h->n * 4, -1);
     auto add = [&](int i, int j) -> int {
         for (int k = 0; k < 4; ++k) {
@@ -1289,8 +1364,7 @@ int32_t gamd_set_bonds(gamd_handle* h, const int32_t* bonds, int64_t n_bonds) {
             if (add(i, j) || add(j, i)) return fail(-22, "more than 4 bonded partners for one atom is not supported");
         }
     if (h->bond_nbr.ensure(sizeof(int) * tab.size(), false)) return fail(-12, "bond table allocation failed");
-    HIP_TRY(hipMemcpy(h->bond_nbr.p, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(init_upload(h->bond_nbr.p, tab.data(), sizeof(int) * tab.size()));
     h->has_bonds = n_bonds > 0;
     return 0;
 }
@@ -1315,6 +1389,7 @@ int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t
     if ((r = check_ready(h))) return r;
     if (!pos_dev || !box) return fail(-22, "null argument");
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     for (int attempt = 0; attempt < 4; ++attempt) {
         if ((r = set_box(h, box, st))) return r;
@@ -1325,6 +1400,7 @@ int32_t gamd_build_neighbors(gamd_handle* h, const float* pos_dev, const uint8_t
         HIP_TRY(hipMemcpyAsync(h->counters_host, h->counters.p, sizeof(int) * CNT_COUNT, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
+        if (int t = check_traps(h)) return t;
         if (!h->counters_host[CNT_OVERFLOW]) return attempt ? 1 : 0;
         const long long need = (long long)(1.25 * (double)h->counters_host[CNT_E]) + 1024;
         if ((r = alloc_edges(h, need))) return r;
@@ -1340,6 +1416,7 @@ int32_t gamd_forces_async(gamd_handle* h, const float* pos_dev, const uint8_t* s
     if (!pos_dev || !box) return fail(-22, "null argument");
     if ((r = check_model_inputs(h, species_dev))) return r;
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     h->pending.active = false;
     return enqueue_forward(h, pos_dev, species_dev, out_norm_dev, out_denorm_dev, (hipStream_t)stream, nullptr, nullptr, nullptr);
@@ -1348,12 +1425,14 @@ int32_t gamd_forces_async(gamd_handle* h, const float* pos_dev, const uint8_t* s
 int32_t gamd_sync_status(gamd_handle* h, void* stream) {
     if (!h) return fail(-22, "null handle");
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     bool resumed = false;
     for (int attempt = 0; attempt < 5; ++attempt) {
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         // the sticky flags catch an overflow in ANY step enqueued since the last check (gamd_md_run), not only the last
         const bool cand_ovf = h->sticky_host[STICKY_CAND_OVERFLOW] != 0;
         const bool edge_ovf = h->counters_host[CNT_OVERFLOW] || h->sticky_host[STICKY_EDGE_OVERFLOW];
+        if (int t = check_traps(h)) { h->pending.active = false; return t; }
         if (!cand_ovf && !edge_ovf) {
             h->pending.active = false;
             if (h->cfg.edge_dtype != GAMD_EDGE_F32 && h->sticky_host[STICKY_NONFINITE])
@@ -1378,7 +1457,8 @@ int32_t gamd_sync_status(gamd_handle* h, void* stream) {
         h->sticky_host[STICKY_EDGE_OVERFLOW] = 0;
         h->counters_host[CNT_OVERFLOW] = 0;
         int flags[DEVFLAG_COUNT] = {0, -1, 0, 0};
-        HIP_TRY(hipMemcpy(flags, h->devflags.p, sizeof(flags), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(flags, h->devflags.p, sizeof(flags), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
         if ((r = clear_devflags(h))) return r;
         if (!h->pending.active)
             return fail(-34, "%s neighbour buffers overflowed; regrown to %lld, re-issue the call", cand_ovf ? "candidate" : "edge", need);
@@ -1416,6 +1496,7 @@ int32_t gamd_forces_edges(gamd_handle* h, const float* pos_dev, const uint8_t* s
     if ((r = check_model_inputs(h, species_dev))) return r;
     if (n_edges > 0x7fff0000ll) return fail(-22, "edge list too long");
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     h->pending.active = false;
     int status = 0;
@@ -1462,6 +1543,7 @@ int32_t gamd_get_skin_stats(gamd_handle* h, int64_t* n_rebuilds, int64_t* n_cand
 int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t bytes) {
     if (!h || !host_out) return fail(-22, "null argument");
     DeviceGuard guard(h->dev);
+    InitStream init(h->init_stream);
     HIP_TRY(hipDeviceSynchronize());
     const size_t n = (size_t)h->n;
     const size_t E = (size_t)std::min<long long>(h->counters_host[CNT_E], h->e_cap);
@@ -1492,6 +1574,7 @@ int32_t gamd_md_run(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev, co
     if (n_steps < 0 || n_steps > 0x3fffffff) return fail(-22, "n_steps out of range");
     if ((r = check_model_inputs(h, species_dev))) return r;
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     hipStream_t st = (hipStream_t)stream;
     MdArgs m{};
@@ -1535,6 +1618,7 @@ int32_t gamd_md_run_nhc(gamd_handle* h, float* x_dev, float* v_dev, float* f_dev
     const double* ys = p->num_yoshidasuzuki == 1 ? YS1 : p->num_yoshidasuzuki == 3 ? YS3 : p->num_yoshidasuzuki == 5 ? YS5 : nullptr;
     if (!ys) return fail(-22, "Invalid Yoshida-Suzuki value. Allowed values are: 1,3,5");
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     hipStream_t st = (hipStream_t)stream;
     NhcArgs a{};
@@ -1582,6 +1666,7 @@ int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* specie
     if (!pos_dev || !box || !names || !ms || !n_out) return fail(-22, "null argument");
     if ((r = check_model_inputs(h, species_dev))) return r;
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     if ((r = set_box(h, box, (hipStream_t)stream))) return r;
     h->pending.active = false;
     hipStream_t st = (hipStream_t)stream;
@@ -1612,6 +1697,7 @@ int32_t gamd_profile(gamd_handle* h, const float* pos_dev, const uint8_t* specie
 int32_t gamd_timing_enable(gamd_handle* h, int32_t enable) {
     if (!h) return fail(-22, "null handle");
     DeviceGuard guard(h->dev);
+    InitStream init(h->init_stream);
     h->timing = enable != 0;
     h->tev_used = 0;
     h->sev_used = 0;
@@ -1619,7 +1705,7 @@ int32_t gamd_timing_enable(gamd_handle* h, int32_t enable) {
         // a first pool of events HERE, not inside the region that is about to be timed (round-4 review: nothing but the
         // step's own launches belongs between the two synchronisation points); the pools still grow on demand
         while (h->tev.size() < 4096) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->tev.push_back(e); h->tev_kind.push_back(0); }
-        while (h->sev.size() < 1024) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->sev.push_back(e); }
+        while (h->sev.size() < 1024) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->sev.push_back(e); h->sev_closes.push_back(0); }
     }
     return 0;
 }
@@ -1627,12 +1713,15 @@ int32_t gamd_timing_enable(gamd_handle* h, int32_t enable) {
 int32_t gamd_timing_read_steps(gamd_handle* h, void* stream, float* step_ms, int64_t max_steps, int64_t* n_steps) {
     if (!h || !n_steps || (max_steps > 0 && !step_ms)) return fail(-22, "null argument");
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    // events: one in front of every step, one behind the last step of each enqueue_md_steps call.  A run that froze on a
-    // neighbour-buffer overflow and was resumed contributes the frozen steps (cheap: their kernels return at once) and the
-    // resumed ones as separate intervals; the interval that spans the host's regrow is reported like any other step.
+    // events: one in front of every step, one behind the last step of each enqueue_md_steps call.  The interval that starts
+    // at such a closing event ends at the first event of the NEXT run: the host's gap between two gamd_md_run calls (or the
+    // regrow of a run that froze on a neighbour-buffer overflow), not a step, and is skipped.  A frozen-and-resumed run
+    // contributes its frozen steps (cheap: their kernels return at once) and the resumed ones.
     int64_t n = 0;
     for (size_t i = 0; i + 1 < h->sev_used; ++i) {
+        if (h->sev_closes[i]) continue;
         if (n < max_steps) {
             float t = 0.f;
             HIP_TRY(hipEventElapsedTime(&t, h->sev[i], h->sev[i + 1]));
@@ -1658,6 +1747,7 @@ int32_t gamd_timing_read(gamd_handle* h, void* stream, double* total_ms, int64_t
 int32_t gamd_timing_read_stages(gamd_handle* h, void* stream, double total_ms[3], int64_t n[3]) {
     if (!h || !total_ms || !n) return fail(-22, "null argument");
     DeviceGuard guard(h->dev);
+    InitStream init((hipStream_t)stream);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     for (int k = 0; k < 3; ++k) { total_ms[k] = 0.0; n[k] = 0; }
     for (size_t i = 0; i + 1 < h->tev_used; i += 2) {

@@ -16,6 +16,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 gamd_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float gamd_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned gamd_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned gamd_u32x2 __attribute__((ext_vector_type(2)));
 
 #define GAMD_WFRAG_BF16_BYTES (GAMD_H * GAMD_H * 2)      // 32 KiB
 

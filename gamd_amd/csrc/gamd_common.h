@@ -171,6 +171,14 @@ __device__ __forceinline__ f32x4 gamd_load_stream(const f32x4* p) {
 // bit-identical to one another.
 __device__ __forceinline__ float gamd_msg_acc(float hn, float e_emb, float prev) { return __builtin_fmaf(hn, e_emb, prev); }
 
+// fp16 node tables of the bf16 edge MLP (NodeArgs::tab16): position, in fp16 elements, of feature f inside an S / D row.  A
+// lane (slot, half) of the chain layout owns the 64 features with bit 2 == half; they are stored as eight 16-byte groups
+// c = 2 t + k (t = f >> 5, k = bit 4 of f) holding X[t][8 k .. 8 k + 7], the two halves of a group side by side: one
+// global_load_dwordx4 per group touches 32 bytes per row (half a fp32 row's worth of cache lines and instructions).
+__host__ __device__ __forceinline__ int gamd_tab16_pos(int f) {
+    return 16 * (2 * (f >> 5) + ((f >> 4) & 1)) + 8 * ((f >> 2) & 1) + 4 * ((f >> 3) & 1) + (f & 3);
+}
+
 // bias fragment in chain layout: 16 float4 (one per (t,q)), from a plain [128] vector
 template <typename BPtr>
 __device__ __forceinline__ void load_bias_chain(BPtr b, int half, f32x16 (&acc)[4]) {

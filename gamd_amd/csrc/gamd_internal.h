@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "gamd_common.h"
 
 enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD = 4, CNT_NCAND = 5,
@@ -12,7 +13,35 @@ enum { CNT_E = 0, CNT_PIECES = 1, CNT_OVERFLOW = 2, CNT_TILES = 3, CNT_REBUILD =
 enum { STICKY_EDGE_OVERFLOW = 0, STICKY_CAND_OVERFLOW = 1, STICKY_REBUILDS = 2, STICKY_NCAND = 3,
        STICKY_NONFINITE = 4,   // the decoder produced a non-finite force component (NaN / inf positions, or an operand
                                // beyond the fp16 range in the split-fp16 edge MLP, which turns into inf / NaN downstream)
+       // checked build (-DGAMD_CHECKED, libgamd_hip_chk.so): the first device-side range check that failed — its code (the
+       // GAMD_CHK_* ids below), the offending value and the source line.  Never written by the release build.
+       STICKY_CHECK_CODE = 5, STICKY_CHECK_VALUE = 6, STICKY_CHECK_LINE = 7,
        STICKY_COUNT = 8 };
+// ---- checked build ----------------------------------------------------------------------------------------------------
+// SURVEY.md section 5 ("add a debug build with bounds checks"; the reference's only failure handling is the overflow test of
+// graph_utils.py:41-42).  `make checked` compiles every kernel with -DGAMD_CHECKED: each index that a kernel READS FROM MEMORY and
+// then uses as an address (CSR source / destination atoms, candidate rows, cell numbers, permutations, piece numbers, CSR write
+// positions) passes through GAMD_CHK_RANGE, which records the first violation in the host-mapped sticky block and returns a safe
+// value instead (no wild access, no trap: the process survives and gamd_sync_status / the synchronous entry points return -35
+// with code, value and line).  In the release build the macro is the identity: same instructions as without it.
+enum { GAMD_CHK_CELL = 101, GAMD_CHK_CAND = 102, GAMD_CHK_EDGE_POS = 103, GAMD_CHK_PERM = 104, GAMD_CHK_ENC_SRC = 111, GAMD_CHK_ENC_DST = 112,
+       GAMD_CHK_CONV_SRC = 121, GAMD_CHK_CONV_DST = 122, GAMD_CHK_PIECE = 123, GAMD_CHK_NODE_PIECES = 131, GAMD_CHK_INJECTED = 199 };
+#ifdef GAMD_CHECKED
+template <typename T>
+__device__ __forceinline__ T gamd_chk_range(int* sticky, T v, long long lo, long long hi, int code, int line) {
+    if ((long long)v >= lo && (long long)v <= hi) return v;
+    if (sticky && sticky[STICKY_CHECK_CODE] == 0) {          // first failure wins (a benign race between failing lanes)
+        sticky[STICKY_CHECK_VALUE] = (int)v;
+        sticky[STICKY_CHECK_LINE] = line;
+        __threadfence_system();
+        sticky[STICKY_CHECK_CODE] = code;
+    }
+    return (T)lo;
+}
+#define GAMD_CHK_RANGE(sticky, v, lo, hi, code) gamd_chk_range((sticky), (v), (long long)(lo), (long long)(hi), (code), __LINE__)
+#else
+#define GAMD_CHK_RANGE(sticky, v, lo, hi, code) (v)
+#endif
 // device-resident flags, cleared by the host only (gamd_create, after a regrow):
 //   DEVFLAG_FROZEN     a neighbour buffer (edges or candidates) overflowed: the CSR of that call is truncated.  Node kernels
 //                      and every integrator kernel return without touching their outputs while it is set, so an enqueued MD
@@ -28,20 +57,23 @@ enum { DEVFLAG_FROZEN = 0, DEVFLAG_FROZEN_AT = 1, DEVFLAG_REBUILDS = 2, DEVFLAG_
 // devices (gamd_config.device; SURVEY.md 8e "one stream per device from one process") must raise the limit on each of them, or
 // the second device launches > 64 KiB of dynamic LDS without it.  One flag per device and kernel instantiation; launchers run
 // under the handle's DeviceGuard, so the current device is the one the launch goes to.
+// Different handles may be driven from different threads (include/gamd_hip.h): two threads can make their first launch of a
+// kernel on one device at the same time, so the flags are atomics (relaxed: hipFuncSetAttribute is idempotent, a lost race
+// only repeats it).
 constexpr int GAMD_MAX_DEVICES = 64;
-struct PerDeviceOnce { bool done[GAMD_MAX_DEVICES] = {}; };
+struct PerDeviceOnce { std::atomic<bool> done[GAMD_MAX_DEVICES] = {}; };
 template <typename... Fn>
 inline int gamd_allow_dynamic_lds(PerDeviceOnce& once, int bytes, Fn... fns) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
-    if (dev >= 0 && dev < GAMD_MAX_DEVICES && once.done[dev]) return 0;
+    if (dev >= 0 && dev < GAMD_MAX_DEVICES && once.done[dev].load(std::memory_order_relaxed)) return 0;
     const void* list[] = {(const void*)fns...};
     for (const void* fn : list) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return (int)e;
     }
-    if (dev >= 0 && dev < GAMD_MAX_DEVICES) once.done[dev] = true;
+    if (dev >= 0 && dev < GAMD_MAX_DEVICES) once.done[dev].store(true, std::memory_order_relaxed);
     return 0;
 }
 
@@ -168,6 +200,7 @@ struct EncArgs {
     float* e_frag;             // [tiles][4][4][64][4]
     long long e_cap;
     float* feat_dbg;           // optional [e_cap][48] raw features (debug/parity), or null
+    int* sticky;               // host-mapped flags (checked build: GAMD_CHK_RANGE reports here)
     int e_format;              // generic-width encoder (wide.hip): 0 = fp32 fragments, 1 = bf16 fragments (wide_lp.hip), 2 = (hi, lo)
                                // fp16 operand images for the split-fp16 conv kernels (the layout edge_encode_f16x3.hip writes)
 };
@@ -205,12 +238,16 @@ struct ConvEdgeArgs {
     const float* hn;           // [n][128] LayerNorm'd node features
     const float* S;            // [n][128] src_affine(hn) + b_src + b_dst + b_edge_affine2
     const float* D;            // [n][128] dst_affine(hn) (no bias)
+                               // (bf16 edge MLP: the three tables are fp16 rows of 256 B, NodeArgs::tab16, S and D pre-multiplied
+                               //  by log2 e)
     const float* w1p; const float* w2p; const float* w3p; const float* w4p;   // packed 128x128
     const float* b1; const float* b3; const float* b4;                           // [128]
     float* partial;            // [pieces][128]
     long long e_cap;
     int zero_row;              // = n: hn / S / D have one extra all-zero row for the padding slots of the last tile
     long long* tdbg;           // profiling builds only: [blocks][8 waves][16] cycle sums, or null
+    int* sticky;               // host-mapped flags (checked build: GAMD_CHK_RANGE reports here)
+    long long piece_cap;       // rows of `partial` (checked build: every piece index is tested against it)
     float* emb_out;            // update_edge_emb (generic-width kernels only): e_emb = theta_edge(...) of every edge, [E][H] rows
                                // in CSR order, for launch_edge_update; null otherwise
 };
@@ -259,7 +296,6 @@ struct NodeArgs {
     const int* devflags;       // DEVFLAG_FROZEN set: same
     int* sticky;               // host-mapped; STICKY_NONFINITE is raised by the decoder
     int n;
-    int n_cu;                  // compute units of the device (launch_node: which prefetch depth keeps every tile resident)
     int mode;                  // 0: first (embed + pre(0)); 1: post(l-1) + pre(l); 2: post(L-1) + decoder
     // inputs
     const float4* pos_s;       // .w = species feature
@@ -267,6 +303,7 @@ struct NodeArgs {
     const float* enc_w; const float* enc_b;   // node_encoder Linear(1->128): weight[:,0], bias (water)
     const int* row_ptr; const int* na_excl; const int* deg;
     const float* partial;
+    long long piece_cap;       // rows of `partial` (checked build)
     const float* h_in;         // [n][128] residual stream before this layer's conv (mode 1,2)
     const float* P_in;         // [n][128] phi_dst(hn)+biases from pre()
     NodeLayerW post;           // layer being finished (mode 1,2)
@@ -283,6 +320,9 @@ struct NodeArgs {
     float* hn_out; float* S_out; float* D_out; float* P_out;
     int hn_perm;               // 1: hn rows are stored feature-permuted, position (f & 31) * 4 + (f >> 5), so that the
                                // conv kernel's row-layout gather is one 16-byte load per edge (conv_edge_f16x3.hip)
+    int tab16;                 // 1 (bf16 edge MLP, conv_edge_bf16.hip): hn, S, D are written as fp16 rows of 256 B instead of fp32
+                               // rows — hn in natural feature order, S and D in the order gamd_tab16_pos() gives (the 64 features a
+                               // lane of the chain layout owns come as 8 x 16 B, lanes slot and slot + 32 side by side)
     float* forces_norm;        // [n][3] normalised network output, ORIGINAL atom order (mode 2)
     float* forces;             // [n][3] denormalised fp32 (device MD loop), original order, or null
     long long* tdbg;           // profiling builds only (GAMD_NODE_TIME=1): [workgroup][wave][16] s_memtime marks of the mode-1 launches

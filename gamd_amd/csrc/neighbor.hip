@@ -70,6 +70,7 @@ __device__ __forceinline__ void d_bin(const NbrArgs& a, int i) {
     // cells are numbered box-major: atoms of different boxes never share a cell, so they are never neighbours
     const BoxCells G = box_cells(a, bi);
     const int c = G.base + (cell_coord(p.x, B.bx, G.nx) * G.ny + cell_coord(p.y, B.by, G.ny)) * G.nz + cell_coord(p.z, B.bz, G.nz);
+    (void)GAMD_CHK_RANGE(a.sticky, c, 0, a.ncell - 1, GAMD_CHK_CELL);
     a.cell_of[i] = c;
     atomicAdd(&a.cell_cnt[c], 1);
 }
@@ -126,9 +127,9 @@ __global__ void __launch_bounds__(1024) k_scan_cells(NbrArgs a) {
 }
 
 __device__ __forceinline__ void d_fill_cells(const NbrArgs& a, int i) {
-    const int c = a.cell_of[i];
+    const int c = GAMD_CHK_RANGE(a.sticky, a.cell_of[i], 0, a.ncell - 1, GAMD_CHK_CELL);
     const int s = atomicAdd(&a.cell_fill[c], 1);
-    a.perm[a.cell_start[c] + s] = i;
+    a.perm[GAMD_CHK_RANGE(a.sticky, a.cell_start[c] + s, 0, a.n - 1, GAMD_CHK_PERM)] = i;
 }
 
 __global__ void k_fill_cells(NbrArgs a) {
@@ -978,7 +979,7 @@ __device__ __forceinline__ void d_filter(const NbrArgs& a, int ctr, int l, RowPt
         bool ok = false;
         int b = 0;
         if (b0 + l < e) {
-            b = a.cand_col[b0 + l];
+            b = GAMD_CHK_RANGE(a.sticky, a.cand_col[b0 + l], 0, a.n, GAMD_CHK_CAND);
             const float4 pb = a.pos_s[b];
             const float d2 = gamd_mask_d2(pc, pb, B);
             if (a.flavour == 0) ok = d2 < a.rc2;

@@ -152,6 +152,22 @@ __device__ __forceinline__ void exchange16(float* xbuf, int w, int a, int g, con
     for (int blk = 0; blk < 8; ++blk) XB[blk] = *reinterpret_cast<const f32x4*>(xbuf + a * XLD + 16 * blk + 4 * g);
 }
 
+// the same 2 x 4 features as fp16 (NodeArgs::tab16: 256-byte rows), natural order (hn) ...
+typedef _Float16 nf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ nf16x4 cvt16x4(const f32x4& v) {
+    const nf16x2 lo = __builtin_convertvector(nf32x2{v[0], v[1]}, nf16x2), hi = __builtin_convertvector(nf32x2{v[2], v[3]}, nf16x2);
+    return nf16x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ void store16_h(_Float16* __restrict__ row, int w, int g, const f32x4 (&v)[2]) {
+    *reinterpret_cast<nf16x4*>(row + 32 * w + 4 * g) = cvt16x4(v[0]);
+    *reinterpret_cast<nf16x4*>(row + 32 * w + 16 + 4 * g) = cvt16x4(v[1]);
+}
+// ... and in the group order of gamd_tab16_pos (S, D): features 32 w + 16 o + 4 g + r  ->  16 (2 w + o) + 8 (g & 1) + 4 (g >> 1) + r
+__device__ __forceinline__ void store16_tab(_Float16* __restrict__ row, int w, int g, const f32x4 (&v)[2]) {
+    *reinterpret_cast<nf16x4*>(row + 32 * w + 8 * (g & 1) + 4 * (g >> 1)) = cvt16x4(v[0]);
+    *reinterpret_cast<nf16x4*>(row + 32 * w + 16 + 8 * (g & 1) + 4 * (g >> 1)) = cvt16x4(v[1]);
+}
+
 // sum over the four lane groups g of an atom (lanes a, a + 16, a + 32, a + 48)
 __device__ __forceinline__ float group_sum(float v) {
     v += __shfl_xor(v, 16, 64);
@@ -217,6 +233,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         const int na_incl = a.na_excl[atom] + ((dg > 0 && (rp0 % GAMD_CHUNK) != 0) ? 1 : 0);
         const int p0 = rp0 / GAMD_CHUNK + na_incl;
         const int np = dg > 0 ? ((rp0 + dg - 1) / GAMD_CHUNK - rp0 / GAMD_CHUNK + 1) : 0;
+        (void)GAMD_CHK_RANGE(a.sticky, (long long)p0 + np, 0, a.piece_cap, GAMD_CHK_NODE_PIECES);
         mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         mine[1] = mine[0];
         f32x4 p_in[2], h_res[2];
@@ -293,7 +310,8 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[o][r] = (mine[o][r] - mean) * rstd * gg[o][r] + bb[o][r];
         }
-        if (valid && !a.hn_perm) store16(a.hn_out + row, w, g, mine);
+        if (valid && a.tab16) store16_h(reinterpret_cast<_Float16*>(a.hn_out) + row, w, g, mine);
+        else if (valid && !a.hn_perm) store16(a.hn_out + row, w, g, mine);
         exchange16(xbuf, w, la, g, mine, XB);                     // XB = hn
         SPLIT16();
         NMARK(6);                                                  // 6: LayerNorm + exchange 3
@@ -311,12 +329,14 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
         }
         load16(a.pre.bS, w, g, mine);
         GEMM16(true, a.pre.wsp, a.pre.wdp);
-        if (valid) store16(a.S_out + row, w, g, mine);
+        if (valid && a.tab16) store16_tab(reinterpret_cast<_Float16*>(a.S_out) + row, w, g, mine);
+        else if (valid) store16(a.S_out + row, w, g, mine);
         NMARK(7);                                                  // 7: GEMM S
         mine[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         mine[1] = mine[0];
         GEMM16(true, a.pre.wdp, a.pre.wpdp);
-        if (valid) store16(a.D_out + row, w, g, mine);
+        if (valid && a.tab16) store16_tab(reinterpret_cast<_Float16*>(a.D_out) + row, w, g, mine);
+        else if (valid) store16(a.D_out + row, w, g, mine);
         NMARK(8);                                                  // 8: GEMM D
         load16(a.pre.bP, w, g, mine);
         GEMM16(false, a.pre.wpdp, nullptr);

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64 * EncWaves<EHT>::value) k_edge_encode_wide(
         const bool active = tile < n_tiles;
         const long long x = (long long)tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = active && x < E;
-        const int src = valid ? a.col[x] : 0, dst = valid ? a.erow[x] : 0;
+        const int src = valid ? GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_ENC_SRC) : 0, dst = valid ? GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_ENC_DST) : 0;
         const float4 ps = a.pos_s[src], pd = a.pos_s[dst];
         const BoxDims B = gamd_edge_box(a, dst);
         const float rx = gamd_min_image_wrapped(ps.x - pd.x, B.bx, B.hx);
@@ -285,14 +285,14 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge_wide(ConvEdgeArgs a) {
         const bool active = tile < n_tiles;
         const int x = tile * GAMD_TILE + gamd_pi(slot);
         const bool valid = active && x < E;
-        const int src = valid ? a.col[x] : 0;
-        const int dst = valid ? a.erow[x] : 0;
+        const int src = valid ? GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_CONV_SRC) : 0;
+        const int dst = valid ? GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_CONV_DST) : 0;
         const int x0 = tile * GAMD_TILE + 16 * half;
         int nvalid = E - x0;
         nvalid = !active ? 0 : (nvalid >= 16 ? 16 : (nvalid <= 0 ? 0 : nvalid));
         unsigned mask = 0;
         int p0 = 0;
-        if (active) { mask = a.chunk_mask[tile * 2 + half]; p0 = a.chunk_piece[tile * 2 + half]; }
+        if (active) { mask = a.chunk_mask[tile * 2 + half]; p0 = GAMD_CHK_RANGE(a.sticky, a.chunk_piece[tile * 2 + half], 0, a.piece_cap - 17, GAMD_CHK_PIECE); }
 
         f32x16 T[4], U[4], X[4];
         // ---- T = SiLU(W1 e + b1), K = Eh --------------------------------------------------------
@@ -557,6 +557,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
         const int na_incl = a.na_excl[atom] + ((dg > 0 && (rp0 % GAMD_CHUNK) != 0) ? 1 : 0);
         const int p0 = rp0 / GAMD_CHUNK + na_incl;
         const int np = dg > 0 ? ((rp0 + dg - 1) / GAMD_CHUNK - rp0 / GAMD_CHUNK + 1) : 0;
+        (void)GAMD_CHK_RANGE(a.sticky, (long long)p0 + np, 0, a.piece_cap, GAMD_CHK_NODE_PIECES);
 #pragma unroll
         for (int b = 0; b < HT; ++b)
 #pragma unroll

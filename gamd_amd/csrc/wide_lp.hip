@@ -133,7 +133,7 @@ __device__ __forceinline__ void conv_lp_wide(const ConvEdgeArgs& a) {
     int src = a.zero_row, dst = a.zero_row;       // padding slots gather the all-zero row n of hn / S / D
     {
         const int x = tile * GAMD_TILE + gamd_pi(slot);
-        if (active && x < E) { src = a.col[x]; dst = a.erow[x]; }
+        if (active && x < E) { src = GAMD_CHK_RANGE(a.sticky, a.col[x], 0, a.zero_row, GAMD_CHK_CONV_SRC); dst = GAMD_CHK_RANGE(a.sticky, a.erow[x], 0, a.zero_row, GAMD_CHK_CONV_DST); }
         if (active) load_e_block<M>(a.e_frag, tile * EHT, lane16, PA);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first block's copy is not tracked by hipcc
@@ -159,7 +159,7 @@ __device__ __forceinline__ void conv_lp_wide(const ConvEdgeArgs& a) {
             f32x16 ACC[4], RC[4];
             const unsigned soff = ((unsigned)src << 9) + 16u * (unsigned)half, doff = ((unsigned)dst << 9) + 16u * (unsigned)half;
             const unsigned mask = a.chunk_mask[tile * 2 + half];
-            const int p0 = a.chunk_piece[tile * 2 + half];
+            const int p0 = GAMD_CHK_RANGE(a.sticky, a.chunk_piece[tile * 2 + half], 0, a.piece_cap - 17, GAMD_CHK_PIECE);
             // ===== phase 1: T1 = SiLU(W1 e + b1), K = Eh: one GEMM per 128-wide block of e =====
             {
                 const Frag* W = cur_w();
@@ -229,7 +229,7 @@ __device__ __forceinline__ void conv_lp_wide(const ConvEdgeArgs& a) {
             // ===== phase 3: T4 = SiLU(W3 T3 + b3) =====
             if (active_n) {
                 const int xn = tile_n * GAMD_TILE + gamd_pi(slot);
-                if (xn < E) { src_n = a.col[xn]; dst_n = a.erow[xn]; }
+                if (xn < E) { src_n = GAMD_CHK_RANGE(a.sticky, a.col[xn], 0, a.zero_row, GAMD_CHK_CONV_SRC); dst_n = GAMD_CHK_RANGE(a.sticky, a.erow[xn], 0, a.zero_row, GAMD_CHK_CONV_DST); }
             }
             {
                 const Frag* W = cur_w();

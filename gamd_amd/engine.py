@@ -185,8 +185,9 @@ class GamdForce:
         # and a stream synchronisation) on every call after the first.
         key = None
         if not species.is_cuda:
-            c = species.reshape(-1).contiguous()
-            key = (str(c.dtype), c.numel(), hash(c.numpy().tobytes()), torch.cuda.current_stream(self.device).cuda_stream)
+            c = species.detach().reshape(-1).contiguous()
+            # (bytes through a uint8 view: dtypes numpy does not know, bfloat16, hash like any other)
+            key = (str(c.dtype), c.numel(), hash(c.view(torch.uint8).numpy().tobytes()), torch.cuda.current_stream(self.device).cuda_stream)
             hit = getattr(self, "_species_cache", None)
             if hit is not None and hit[0] == key:
                 self._set_features(hit[2])
@@ -200,6 +201,10 @@ class GamdForce:
         self._set_features(feat)
         flags = (s != 0).to(torch.uint8).contiguous()
         # (a device tensor of the caller's is the caller's to keep alive; the flags derived from it are held until the next call)
+        # The library skips its O,H,H layout check while the species POINTER is the one it validated last: new content must never
+        # arrive at an address it has validated for other content.  The flags above were allocated while the previous buffer was
+        # still alive, and the previous generation stays alive one change longer, so three consecutive generations are distinct.
+        self._species_prev = getattr(self, "_species_cache", None)
         self._species_cache = (key, flags, feat)
         return flags
 

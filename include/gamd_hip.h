@@ -281,8 +281,11 @@ int32_t gamd_timing_read_stages(gamd_handle* h, void* stream, double total_ms[3]
 /* While timing is enabled, gamd_md_run / gamd_md_run_nhc also record one HIP event in front of the first kernel of every MD
  * step (the iteration of the drivers' loop, LJ/test_script/test_langevin.py:95-113) and one behind the last: step_ms[i] =
  * device time between consecutive events, in enqueue order, since the last gamd_timing_enable.  Writes at most max_steps
- * values; *n_steps = intervals available.  A step that takes far longer than the median is a candidate rebuild, a regrow
- * (the interval that spans the host's re-allocation) or a stall: bench.py reports min / p50 / p99 / max. */
+ * values; *n_steps = intervals available.  K runs of n steps give K * n intervals: the interval between the event behind a run's
+ * last step and the first event of the next run (the host's gap between two calls, or the re-allocation of a run that froze
+ * on a neighbour-buffer overflow) is not a step and is skipped.  A step that takes far longer than the median is a candidate
+ * rebuild or a stall: bench.py reports min / p50 / p99 / max.  The event pools are bounded (65 536 step events): with timing
+ * left on across a longer run the remaining steps are not timed. */
 int32_t gamd_timing_read_steps(gamd_handle* h, void* stream, float* step_ms, int64_t max_steps, int64_t* n_steps);
 
 #ifdef __cplusplus

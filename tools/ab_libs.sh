@@ -14,7 +14,8 @@ for lib in ${LIBS:-old} new; do
     python3 bench.py --workload $wl $extra --steps 300 --warmup 30 --no-secondary --no-cpu-baseline --line full 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); t=d['config']['timed_region']; n=t.get('neighbour_stage_ms') or {}
-print('$rep $lib $w ms/step %.4f  p50 %.4f  rebuilds %d  nbr reuse %.1f us rebuild %.1f us' % (d['ms_per_step'], t['step_ms']['p50'], t['rebuilds_in_timed'], 1e3*n.get('reuse_step', float('nan')), 1e3*n.get('rebuild_step', float('nan'))))" | tee -a $out/ab.txt
+st=d.get('stages_ms') or {}
+print('$rep $lib $w ms/step %.4f  p50 %.4f  rebuilds %d  nbr reuse %.1f us rebuild %.1f us | conv %.1f us  encoder %.1f us  node interval %.1f us' % (d['ms_per_step'], t['step_ms']['p50'], t['rebuilds_in_timed'], 1e3*n.get('reuse_step', float('nan')), 1e3*n.get('rebuild_step', float('nan')), 1e3*st.get('conv_edge',[float('nan')])[0], 1e3*st.get('edge_encode',[float('nan')])[0], 1e3*st.get('node_mid',[float('nan')])[0]))" | tee -a $out/ab.txt
   done
 done
 done

@@ -32,8 +32,8 @@ sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
 rc = 3.0 * workloads.LJ_SIGMA
 rows = []
 print(f"edge dtype {args.edge_dtype}\n")
-print("| atoms | edges | ms / step | atom-steps/s | conv kernel ms / launch | GB device memory |")
-print("|---|---|---|---|---|---|")
+print("| atoms | edges | ms / step | atom-steps/s | conv kernel ms / launch | GB device memory | encoder ms | node interval ms | 32-edge tiles per wave slot (2 048) |")
+print("|---|---|---|---|---|---|---|---|---|")
 for n in sizes:
     pos, box = workloads.lj_box(n)
     eng = GamdForce(sd, n, box, rc, scaler=SHIPPED_SCALERS["lj"], neighbor_skin=rc / 6, edge_dtype=args.edge_dtype)
@@ -50,10 +50,12 @@ for n in sizes:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     conv_ms, conv_n = eng.timing_read()
+    stages = eng.timing_read_stages()
     eng.timing_enable(False)
     free, total = torch.cuda.mem_get_info()
     e = eng.counts()[0]
-    print(f"| {n} | {e} | {dt * 1e3:.3f} | {n / dt:.3e} | {conv_ms / max(conv_n, 1):.4f} | {(total - free) / 2**30:.2f} |")
+    enc_ms, node_ms = (stages[k][0] / max(stages[k][1], 1) for k in ("edge_encode", "node_mid"))
+    print(f"| {n} | {e} | {dt * 1e3:.3f} | {n / dt:.3e} | {conv_ms / max(conv_n, 1):.4f} | {(total - free) / 2**30:.2f} | {enc_ms:.4f} | {node_ms:.4f} | {e / 32 / 2048:.2f} |")
     rows.append({"atoms": n, "edges": e, "ms_per_step": dt * 1e3, "atom_steps_per_s": n / dt,
                  "conv_ms_per_launch": conv_ms / max(conv_n, 1), "conv_launches": conv_n, "edge_dtype": args.edge_dtype,
                  "device_GB": (total - free) / 2 ** 30})
