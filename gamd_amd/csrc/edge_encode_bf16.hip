@@ -29,22 +29,12 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
 
     const int tid = threadIdx.x;
     {
-        // weights L2 -> LDS as 76 one-KiB LDS-DMA copies (W1 12 KiB | W2 32 KiB | W3 32 KiB: the LDS image is contiguous), all in
-        // flight at once, one wait + one barrier (conv_edge_bf16.hip's prologue)
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        unsigned l16 = 16u * (unsigned)(tid & 63);
-        asm volatile("" : "+v"(l16));
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            const int chunk = k * 8 + wv;
-            if (chunk < 76) {
-                const char* base = chunk < 12 ? reinterpret_cast<const char*>(a.w1p) + chunk * 1024
-                                 : chunk < 44 ? reinterpret_cast<const char*>(a.w2p) + (chunk - 12) * 1024
-                                              : reinterpret_cast<const char*>(a.w3p) + (chunk - 44) * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + l16),
-                                                 (__attribute__((address_space(3))) void*)(ldsb + chunk * 1024), 16, 0, 0);
-            }
-        }
+        f32x4* d = reinterpret_cast<f32x4*>(ldsb);
+        const f32x4* s1 = reinterpret_cast<const f32x4*>(a.w1p);
+        const f32x4* s2 = reinterpret_cast<const f32x4*>(a.w2p);
+        const f32x4* s3 = reinterpret_cast<const f32x4*>(a.w3p);
+        for (int i = tid; i < ENCB_W1_BYTES / 16; i += 512) d[i] = s1[i];
+        for (int i = tid; i < 2048; i += 512) { d[ENCB_W1_BYTES / 16 + i] = s2[i]; d[ENCB_W1_BYTES / 16 + 2048 + i] = s3[i]; }
         if (tid < 128) { vb1[tid] = a.b1[tid]; vb2[tid] = a.b2[tid]; vb3[tid] = a.b3[tid]; vg[tid] = a.ln_g[tid]; vbeta[tid] = a.ln_b[tid]; }
         if (tid < 40) cen[tid] = a.centers[tid];
     }
@@ -117,7 +107,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
         pack_chain_bf16(acc, P);
         // GEMM 2
         load_bias_chain(vb2, half, acc);
-        gemm128_bf16_pf<false, 8>(W2, lane, P, acc);
+        gemm128_bf16<false>(W2, lane, P, acc);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -125,7 +115,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
         pack_chain_bf16(acc, P);
         // GEMM 3 + LayerNorm (fp32)
         load_bias_chain(vb3, half, acc);
-        gemm128_bf16_pf<false, 8>(W3, lane, P, acc);
+        gemm128_bf16<false>(W3, lane, P, acc);
         layernorm_chain(acc, vg, vbeta, half, 1e-5f);
         pack_chain_bf16(acc, P);
 #pragma unroll

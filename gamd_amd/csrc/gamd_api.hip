@@ -153,6 +153,11 @@ struct gamd_handle {
     // per-atom buffers
     DevBuf pos_w, pos_s, cell_of, perm, inv_perm, deg, row_ptr, na_excl, bond_nbr;
     DevBuf hbuf, hn, S, D, P, f_norm, f_den;
+    // Layer-0 node tables of their own (skin mode): h0 and pre(0)'s hn / S / D / P depend on the species and the weights only,
+    // not on the positions — in sorted atom order they change when the candidate list is rebuilt (the atoms are renumbered), not
+    // otherwise.  Inside an enqueued MD run the first node launch of a step therefore returns at once unless that step rebuilt
+    // (NodeArgs::l0_gate): the other layers' tables are overwritten layer by layer, these are not.
+    DevBuf l0_h, l0_hn, l0_S, l0_D, l0_P;
     // cells
     DevBuf cell_cnt, cell_fill, cell_start;
     int ncell_cap = 0;
@@ -510,7 +515,7 @@ int fill_rigid(const gamd_handle* h, int rigid_water, float mass_o, float mass_h
 
 int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, float* out_norm_dev,
                     float* out_denorm_dev, hipStream_t st, hipEvent_t* evs, int* n_ev, std::vector<std::string>* labels,
-                    const EdgeList* el = nullptr, const MdFuse* fuse = nullptr, bool copy_counters = true) {
+                    const EdgeList* el = nullptr, const MdFuse* fuse = nullptr, bool copy_counters = true, bool l0_reuse = false) {
     auto mark = [&](const char* label) {
         if (evs) { (void)hipEventRecord(evs[*n_ev], st); ++*n_ev; labels->push_back(label); }
     };
@@ -644,10 +649,18 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     no.forces_norm = out_norm_dev ? out_norm_dev : h->f_norm.as<float>();
     no.forces = out_denorm_dev;
 
+    // layer 0 owns its tables in skin mode (see gamd_handle::l0_*); l0_reuse (steps of an enqueued MD run behind its first: same
+    // species buffer, same weights): the launch returns at once unless this step rebuilt the candidate list
+    const bool l0 = h->skin > 0.f && !el;
+    float* const h0 = (l0 && !h->cfg.keep_stages) ? h->l0_h.as<float>() : hptr(0);
     no.mode = 0;
     no.pre = h->layers[0].node;
-    no.h_out = hptr(0);
+    no.h_out = h0;
+    if (l0) { no.hn_out = h->l0_hn.as<float>(); no.S_out = h->l0_S.as<float>(); no.D_out = h->l0_D.as<float>(); no.P_out = h->l0_P.as<float>(); }
+    no.l0_gate = (l0 && l0_reuse) ? 1 : 0;
     if ((r = node(no))) return fail(-1, "node(0) launch failed (%d)", r);
+    no.l0_gate = 0;
+    no.hn_out = h->hn.as<float>(); no.S_out = h->S.as<float>(); no.D_out = h->D.as<float>(); no.P_out = h->P.as<float>();
     mark("node_first");
 
 
@@ -661,6 +674,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.e_frag = (h->update_edge && l > 0) ? h->e_frag2.as<float>() : h->e_frag.as<float>();
         ca.emb_out = (h->update_edge && l + 1 < h->L) ? h->e_emb.as<float>() : nullptr;
         ca.hn = h->hn.as<float>(); ca.S = h->S.as<float>(); ca.D = h->D.as<float>();
+        if (l0 && l == 0) { ca.hn = h->l0_hn.as<float>(); ca.S = h->l0_S.as<float>(); ca.D = h->l0_D.as<float>(); }
         const LayerDev& ld = h->layers[l];
         ca.w1p = ld.w1p; ca.w2p = ld.w2p; ca.w3p = ld.w3p; ca.w4p = ld.w4p;
         ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
@@ -701,7 +715,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         no.mode = (l == h->L - 1) ? 2 : 1;
         no.post = ld.node;
         if (l + 1 < h->L) no.pre = h->layers[l + 1].node;
-        no.h_in = hptr(l);
+        no.h_in = l == 0 ? h0 : hptr(l);
+        no.P_in = (l0 && l == 0) ? h->l0_P.as<float>() : h->P.as<float>();
         no.h_out = hptr(l + 1);
         if ((r = node(no))) return fail(-1, "node launch failed (%d)", r);
         mark(no.mode == 2 ? "node_last_decode" : "node_mid");
@@ -804,7 +819,7 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
             }
             const MdFuse fuse{&p.m, do_second, do_first};
             if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, &fuse,
-                                     s + 1 == p.n_steps)))
+                                     s + 1 == p.n_steps, s > s_begin)))
                 return r;
         }
         if (p.n_steps > s_begin) {
@@ -821,12 +836,12 @@ int enqueue_md_steps(gamd_handle* h, long long s_begin, bool skip_first) {
             p.m.step = p.first_step + (unsigned long long)s;
             p.m.step_index = (int)s;
             if (first && (r = launch_baoab_first(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
-            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, nullptr, last))) return r;
+            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, nullptr, last, s > s_begin))) return r;
             if ((r = launch_baoab_second(p.m, p.st))) return fail(-1, "integrator launch failed (%d)", r);
         } else {
             p.a.step_index = (int)s;
             if (first && (r = launch_nhc_first(p.a, p.st))) return fail(-1, "integrator launch failed (%d)", r);
-            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, nullptr, last))) return r;
+            if ((r = enqueue_forward(h, p.x, p.species, nullptr, p.f, p.st, nullptr, nullptr, nullptr, nullptr, nullptr, last, s > s_begin))) return r;
             if ((r = launch_nhc_second(p.a, p.st))) return fail(-1, "integrator launch failed (%d)", r);
         }
     }
@@ -934,6 +949,13 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->S.ensure(nd + 128 * sizeof(float), true);
     r |= h->D.ensure(nd + 128 * sizeof(float), true);
     r |= h->P.ensure(nd, true);
+    if (cfg->neighbor_skin > 0.f) {
+        r |= h->l0_hn.ensure(nh + (size_t)H * sizeof(float), true);
+        r |= h->l0_S.ensure(nd + 128 * sizeof(float), true);
+        r |= h->l0_D.ensure(nd + 128 * sizeof(float), true);
+        r |= h->l0_P.ensure(nd, true);
+        if (!cfg->keep_stages) r |= h->l0_h.ensure(nh, true);
+    }
     r |= h->f_norm.ensure(sizeof(float) * 3 * n, true);
     r |= h->f_den.ensure(sizeof(float) * 3 * n, true);
     r |= h->tdbg.ensure(sizeof(long long) * 16 * 8 * 1024, true);
@@ -1001,7 +1023,7 @@ int32_t gamd_destroy(gamd_handle* h) {
     h->devflags.release();
     h->cnt2.release();
     DevBuf* bufs[] = {&h->boxes_dev, &h->box_shift, &h->wblob, &h->pos_w, &h->pos_s, &h->cell_of, &h->perm, &h->inv_perm, &h->deg, &h->row_ptr,
-                      &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->f_norm, &h->f_den,
+                      &h->na_excl, &h->bond_nbr, &h->hbuf, &h->hn, &h->S, &h->D, &h->P, &h->l0_h, &h->l0_hn, &h->l0_S, &h->l0_D, &h->l0_P, &h->f_norm, &h->f_den,
                       &h->cell_cnt, &h->cell_fill, &h->cell_start, &h->col, &h->erow, &h->chunk_piece,
                       &h->chunk_mask, &h->e_frag, &h->e_emb, &h->e_frag2, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial, &h->com_partial,
                       &h->ref_pos, &h->cand_deg, &h->cand_ptr, &h->cand_col};

@@ -297,6 +297,8 @@ struct NodeArgs {
     int* sticky;               // host-mapped; STICKY_NONFINITE is raised by the decoder
     int n;
     int mode;                  // 0: first (embed + pre(0)); 1: post(l-1) + pre(l); 2: post(L-1) + decoder
+    int l0_gate;               // mode 0 inside an enqueued MD run: return at once unless this step rebuilt the candidate list
+                               // (counters[CNT_REBUILD]) — layer 0's tables depend on species + weights only and are still valid
     // inputs
     const float4* pos_s;       // .w = species feature
     const float* node_emb;     // [128] (lj) or null

@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256, 3) k_node(NodeArgs a) {
     __shared__ float red[2][4][NT];
 
     if (a.counters[CNT_OVERFLOW] || a.devflags[DEVFLAG_FROZEN]) return;
+    if (a.mode == 0 && a.l0_gate && a.counters[CNT_REBUILD] == 0) return;      // layer-0 tables of the last rebuild still stand
 
     const int lane = threadIdx.x & 63, la = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

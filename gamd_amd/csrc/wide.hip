@@ -496,6 +496,7 @@ __global__ void __launch_bounds__(256) k_node_wide(NodeArgs a) {
     __shared__ float red[2][4][32];
 
     if (a.counters[CNT_OVERFLOW] || a.devflags[DEVFLAG_FROZEN]) return;
+    if (a.mode == 0 && a.l0_gate && a.counters[CNT_REBUILD] == 0) return;      // layer-0 tables of the last rebuild still stand (node.hip)
 
     const int lane = threadIdx.x & 63, slot = lane & 31, half = lane >> 5;
     const int quarter = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
