@@ -64,10 +64,20 @@ constexpr int CONVB_LDS_BYTES = 4 * GAMD_WFRAG_BF16_BYTES + 3 * 128 * 4;
 //   32 the S / D (chain-layout) gathers alone from the zero row
 //   128 GEMMs without their LDS weight reads (one fragment quad, read once)   256 GEMMs without MFMAs (operands and weight
 //   reads stay live: an empty asm statement per MFMA consumes them and "writes" the accumulator)
+//   1024 s_setprio 1 around every GEMM (its MFMAs win the issue arbitration against the partner wave's vector instructions)
+//   2048 WITHOUT the s_setprio 1 around every SiLU block   4096 static s_setprio 1 for waves 4-7   8192 priority 1 everywhere
+//   but in the GEMMs (results unchanged by all of them)
 template <int ABL, bool F2>
 __device__ __forceinline__ void gemm_abl(const bf16x8* W, int lane, const bf16x8 (&P)[4][2], f32x16 (&acc)[4]) {
     if (ABL & 16) return;
-    if (!(ABL & (128 | 256))) { gemm128_bf16_pf<F2, BF16_RING>(W, lane, P, acc); return; }
+    if (!(ABL & (128 | 256))) {
+        if (ABL & 1024) __builtin_amdgcn_s_setprio(1);
+        if (ABL & 8192) __builtin_amdgcn_s_setprio(0);            // 8192: priority 1 everywhere BUT in the GEMMs
+        gemm128_bf16_pf<F2, BF16_RING>(W, lane, P, acc);
+        if (ABL & 1024) __builtin_amdgcn_s_setprio(0);
+        if (ABL & 8192) __builtin_amdgcn_s_setprio(1);
+        return;
+    }
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 w0 = W[lane];
 #pragma unroll
@@ -83,6 +93,10 @@ __device__ __forceinline__ void gemm_abl(const bf16x8* W, int lane, const bf16x8
 template <int ABL>
 __device__ __forceinline__ float silu_abl(float x) { return (ABL & 1) ? 0.5f * x : gamd_silu_hw(x); }
 
+// (Round 6: the block runs at s_setprio 1.  The two waves of a SIMD share its vector issue; a wave inside a SiLU block — 128
+// transcendental pairs, the densest vector stretch of a tile — that keeps losing issue slots to its partner's scattered
+// vector instructions finishes later AND delays the partner's next block.  Measured same-box: 42.3 -> 39.8 us per launch at
+// C5, 113.1 -> 108.6 at 10 000 LJ atoms; priority around the GEMMs, for the younger half, or everywhere but the GEMMs: +-0.)
 // SiLU of a 32 x 128 block + rounding to the bf16 operands of the next GEMM, two elements at a time.  The block arrives
 // multiplied by log2 e (x' = x log2 e: the scale sits in the weights and tables that feed it), so
 //     y' = x' * rcp(1 + exp2(-x')) = log2 e * SiLU(x)
@@ -97,6 +111,7 @@ __device__ __forceinline__ SiluK silu_consts() {
 }
 template <int ABL>
 __device__ __forceinline__ void silu_pack_bf16(const f32x16 (&X)[4], bf16x8 (&P)[4][2], const SiluK& k) {
+    if (!(ABL & 2048)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -118,6 +133,7 @@ __device__ __forceinline__ void silu_pack_bf16(const f32x16 (&X)[4], bf16x8 (&P)
             }
             P[t][u] = __builtin_bit_cast(bf16x8, w);
         }
+    if (!(ABL & 2048)) __builtin_amdgcn_s_setprio(0);
 }
 
 template <int ABL>
@@ -171,6 +187,8 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
             for (int u = 0; u < 2; ++u)
                 P[t][u] = __builtin_bit_cast(bf16x8, gamd_load_stream(reinterpret_cast<const f32x4*>(tb + (size_t)lane16 + (t * 2 + u) * 1024)));
     };
+    if ((ABL & 4096) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (ABL & 8192) __builtin_amdgcn_s_setprio(1);
 #if BF16_STAGGER > 0
     // de-phase the two waves of a SIMD (waves w and w + 4): their MFMA phases and their VALU phases then interleave instead
     // of colliding on the matrix pipe / the vector ALU
@@ -379,6 +397,12 @@ int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
         case 775: return launch_bf16_abl<775>(a, n_blocks, st);
         case 903: return launch_bf16_abl<903>(a, n_blocks, st);
         case 384: return launch_bf16_abl<384>(a, n_blocks, st);
+        case 1024: return launch_bf16_abl<1024>(a, n_blocks, st);
+        case 2048: return launch_bf16_abl<2048>(a, n_blocks, st);
+        case 4096: return launch_bf16_abl<4096>(a, n_blocks, st);
+        case 5120: return launch_bf16_abl<5120>(a, n_blocks, st);
+        case 8192: return launch_bf16_abl<8192>(a, n_blocks, st);
+        case 10240: return launch_bf16_abl<10240>(a, n_blocks, st);
         default: break;
     }
 #endif
