@@ -85,6 +85,7 @@ struct DevBuf {
 struct LayerDev {
     // edge side
     const float *w1p, *w2p, *w3p, *w4p, *b1, *b3, *b4;
+    const float *w16p = nullptr;                        // generic-width fp32: the blocks again, packed for wide16.hip
     const float *e_ln_g = nullptr, *e_ln_b = nullptr;   // update_edge_emb: this layer's edge_layer_norm
     NodeLayerW node;
 };
@@ -414,6 +415,23 @@ void pack_enc1(const float* W, int n_feat, float* out) {
                 }
 }
 
+// ---- packing for the 16-edge generic-width conv kernel (wide16.hip) --------------------------------------------------------
+// K position p = 4 m + g of the 32-edge kernels' accumulation order <-> input feature kfeat(m, g); image [ob 8][m4 8][lane 64][c 4]
+// = W[row(ob, lane & 15)][kfeat(4 m4 + c, lane >> 4)].  chained = true (W1, W2, W3): packed output row 16 ob + 4 g' + r' is feature
+// kfeat(4 ob + r', g'), so the C/D registers of one GEMM are the B operands of the next; chained = false (W4): packed column n of
+// block ob is feature 64 (ob >> 2) + 4 n + (ob & 3) (a lane of the F2 output owns four consecutive features).
+int kfeat16x(int m, int g) { return 32 * (m >> 3) + 8 * ((m >> 1) & 3) + 4 * (g & 1) + (g >> 1) + 2 * (m & 1); }
+void pack16x(const float* W, float* out, int ld, bool chained) {
+    for (int ob = 0; ob < 8; ++ob)
+        for (int m4 = 0; m4 < 8; ++m4)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 15, g = lane >> 4;
+                const int row = chained ? kfeat16x(4 * ob + (i & 3), i >> 2) : 64 * (ob >> 2) + 4 * i + (ob & 3);
+                for (int c = 0; c < 4; ++c)
+                    out[(((size_t)ob * 8 + m4) * 64 + lane) * 4 + c] = W[(size_t)row * ld + kfeat16x(4 * m4 + c, g)];
+            }
+}
+
 // ---- bf16 packing (config 5), layout of gamd_bf16.h --------------------------------------------
 uint16_t f2bf(float x) {                       // round to nearest even
     uint32_t u; memcpy(&u, &x, 4);
@@ -591,6 +609,12 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         const long long tiles = (e_est + GAMD_TILE - 1) / GAMD_TILE;
         if (tiles <= h->small_tile_limit) small_tiles = (int)std::max<long long>(1, std::min<long long>(tiles + tiles / 8 + 1, 4096));
     }
+    // Generic-width fp32 conv kernel on 16-edge work units (k_conv_edge_wide16, bit-identical to k_conv_edge_wide): opt-in through
+    // GAMD_KSEL_FORCE_HALF_QUANTUM.  The idea — with t tiles per SIMD the launch takes ceil(2 t) / 2 tile quanta instead of ceil(t):
+    // 1.5 instead of 2 at the DFT-water size — holds for the matrix time (61 against 82 us) but not for the launch: one wave per
+    // SIMD pays the barrier, the 64 KiB weight copy and its vector work per 8 192-cycle phase instead of per 32 768-cycle phase
+    // pair, ~2.7 us x 18 phases (110 us against 107, profiles/r06_experiments.md).  Not chosen automatically.
+    const bool half_quantum = h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F32 && (h->cfg.kernel_select & GAMD_KSEL_FORCE_HALF_QUANTUM) != 0;
     bool tev_full = false;
     auto tev_begin = [&](int kind) -> int {
         if (!h->timing) return 0;
@@ -676,7 +700,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         ca.hn = h->hn.as<float>(); ca.S = h->S.as<float>(); ca.D = h->D.as<float>();
         if (l0 && l == 0) { ca.hn = h->l0_hn.as<float>(); ca.S = h->l0_S.as<float>(); ca.D = h->l0_D.as<float>(); }
         const LayerDev& ld = h->layers[l];
-        ca.w1p = ld.w1p; ca.w2p = ld.w2p; ca.w3p = ld.w3p; ca.w4p = ld.w4p;
+        ca.w1p = ld.w1p; ca.w2p = ld.w2p; ca.w3p = ld.w3p; ca.w4p = ld.w4p; ca.w16p = ld.w16p;
         ca.b1 = ld.b1; ca.b3 = ld.b3; ca.b4 = ld.b4;
         ca.partial = h->partial.as<float>();
         ca.piece_cap = h->piece_cap;
@@ -692,6 +716,7 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         if ((r = tev_begin(l))) return r;                        // kind l: conv-layer edge kernel of layer l
         r = h->wide_conv ? (h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3_wide(ca, h->EHT, h->HT, h->n_cu, st)
                             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16_wide(ca, h->EHT, h->HT, h->n_cu, st)
+                            : (half_quantum && ca.w16p && !ca.emb_out) ? launch_conv_edge_wide16(ca, h->EHT, h->HT, h->n_cu, st)
                             : small_tiles > 0 ? launch_conv_edge_small_wide(ca, h->EHT, h->HT, small_tiles, st)
                                               : launch_conv_edge_wide(ca, h->EHT, h->HT, h->n_cu, st))
             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16(ca, h->n_cu, st)
@@ -877,7 +902,7 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
         return fail(-22, "unknown self_loop_mode %d", cfg->self_loop_mode);
     if (cfg->self_loop_mode != GAMD_SELF_LOOP_DGL07_NOOP && cfg->edge_dtype != GAMD_EDGE_F32)
         return fail(-22, "self_loop_mode 1 is built for the fp32 edge dtype only");
-    if (cfg->kernel_select & ~GAMD_KSEL_FORCE_GENERIC_WIDTH)
+    if (cfg->kernel_select & ~(GAMD_KSEL_FORCE_GENERIC_WIDTH | GAMD_KSEL_FORCE_HALF_QUANTUM))
         return fail(-22, "unknown kernel_select bits 0x%x", cfg->kernel_select);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1057,7 +1082,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     const int64_t Ht = h->H_true, Et = h->Eh_true, Dt = h->D_true;        // the state_dict's widths
     const bool expand = !h->cfg.no_expand_edge;
     BlobBuilder bb;
-    struct Off { size_t w1p, w2p, w3p, w4p, b1, b3, b4, elng = 0, elnb = 0, lng, lnb, wsp, wdp, wpdp, bS, bP, wpep, wphip, bphi; };
+    struct Off { size_t w1p, w2p, w3p, w4p, w16p = 0, b1, b3, b4, elng = 0, elnb = 0, lng, lnb, wsp, wdp, wpdp, bS, bP, wpep, wphip, bphi; };
     std::vector<Off> lo(L);
     // get(name, true shape, padded shape): the tensor as the reference stores it, zero-padded to the kernels' block widths.
     // Padded output rows / input columns are zeros, so padded features are exact zeros through every layer.
@@ -1242,6 +1267,13 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             o.w3p = put_blocks(t1w, 1, 1);
             if (h->wide_conv) {
                 o.w4p = put_blocks(t3w, (int)HT, 1);
+                // the same run of blocks for the opt-in 16-edge kernel (wide16.hip): W1[:, kb] | W2 | W3 chained, W4[ob, :] not
+                o.w16p = bb.add((size_t)(EHT + 2 + HT) * GAMD_WFRAG_FLOATS);
+                size_t at = o.w16p;
+                for (int kb = 0; kb < (int)EHT; ++kb, at += GAMD_WFRAG_FLOATS) pack16x(ea0w->data.data() + 128 * kb, bb.host.data() + at, 128 * (int)EHT, true);
+                pack16x(ea2w->data.data(), bb.host.data() + at, 128, true); at += GAMD_WFRAG_FLOATS;
+                pack16x(t1w->data.data(), bb.host.data() + at, 128, true); at += GAMD_WFRAG_FLOATS;
+                for (int ob = 0; ob < (int)HT; ++ob, at += GAMD_WFRAG_FLOATS) pack16x(t3w->data.data() + (size_t)128 * ob * 128, bb.host.data() + at, 128, false);
             } else {
                 permute_w4();
                 o.w4p = put_blocks(&w4_perm, 1, 1);
@@ -1338,6 +1370,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         const Off& o = lo[l];
         LayerDev& d = h->layers[l];
         d.w1p = B + o.w1p; d.w2p = B + o.w2p; d.w3p = B + o.w3p; d.w4p = B + o.w4p;
+        d.w16p = (h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F32) ? B + o.w16p : nullptr;
         d.b1 = B + o.b1; d.b3 = B + o.b3; d.b4 = B + o.b4;
         d.node.ln_g = B + o.lng; d.node.ln_b = B + o.lnb;
         if (update_edge) { d.e_ln_g = B + o.elng; d.e_ln_b = B + o.elnb; }
@@ -1581,6 +1614,8 @@ int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t byte
     } else if (what >= GAMD_DBG_H0 && what <= GAMD_DBG_H0 + h->L) {
         if (!h->cfg.keep_stages) return fail(-22, "H_l needs keep_stages=1");
         src = h->hbuf.as<float>() + (size_t)(what - GAMD_DBG_H0) * n * (size_t)h->H; avail = sizeof(float) * n * (size_t)h->H;
+    } else if (what == GAMD_DBG_PARTIAL) {
+        src = h->partial.p; avail = sizeof(float) * (size_t)h->H * (size_t)std::max(0, h->counters_host[CNT_PIECES]);
     } else if (what == GAMD_DBG_CYCLES) { src = h->tdbg.p; avail = sizeof(long long) * 16 * 8 * (size_t)h->n_cu;
     } else return fail(-22, "unknown debug tensor %d", what);
     if (bytes < avail) return fail(-22, "host buffer too small: %zu < %zu", bytes, avail);

@@ -241,6 +241,7 @@ struct ConvEdgeArgs {
                                // (bf16 edge MLP: the three tables are fp16 rows of 256 B, NodeArgs::tab16, S and D pre-multiplied
                                //  by log2 e)
     const float* w1p; const float* w2p; const float* w3p; const float* w4p;   // packed 128x128
+    const float* w16p;         // generic-width fp32 path: the same EHT + 2 + HT blocks packed for the 16-edge kernel (wide16.hip), or null
     const float* b1; const float* b3; const float* b4;                           // [128]
     float* partial;            // [pieces][128]
     long long e_cap;
@@ -260,6 +261,9 @@ int launch_conv_edge_f16x3(const ConvEdgeArgs& a, int n_blocks, hipStream_t st);
 // generic widths (wide.hip): Eh = 128 eht, H = 128 ht.  w1p points at eht + 2 + ht contiguous packed blocks
 // W1[:, kb] | W2 | W3 | W4[ob, :]; b4 is [H]; hn and partial rows are H wide, S and D stay 128 wide
 int launch_conv_edge_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
+// the same on 16-edge work units (wide16.hip: v_mfma_f32_16x16x4_f32, one wave per SIMD, a.w16p), bit-identical to
+// launch_conv_edge_wide; for launches whose 32-edge tiles leave the SIMDs between 1 and 1.5 (2 and 2.5, ...) quanta of work
+int launch_conv_edge_wide16(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
 // the same on the fp16 matrix pipe by operand splitting (wide_lp.hip): w1p = eht + 2 + ht contiguous [hi | lo] fp16 images,
 // e_frag in the encoder's e_format 2, hn rows in their natural [n][H] layout
 int launch_conv_edge_f16x3_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);

@@ -285,6 +285,11 @@ class GamdForce:
         check(self._lib.gamd_debug_get(self._h, what, out.ctypes.data_as(C.c_void_p), out.nbytes), "gamd_debug_get")
         return out
 
+    def debug_partial(self) -> np.ndarray:
+        """[pieces, H] partial-sum pieces of the LAST conv layer (one row per run of edges with the same destination inside a
+        16-edge chunk), CSR order."""
+        return self._dbg(6, (self.counts()[1], 128 * ((self.cfg.encoding_size + 127) // 128)), np.float32)
+
     def debug_perm(self) -> np.ndarray:
         return self._dbg(0, (self.n_total,), np.int32)
 

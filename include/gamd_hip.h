@@ -91,7 +91,9 @@ typedef struct gamd_config {
                                 container (DGL absent), hence the switch.  fp32 edge dtype only. */
     int32_t kernel_select;   /* 0 = automatic.  Bit flags for tests (never change results beyond fp32 rounding):
                                 GAMD_KSEL_FORCE_GENERIC_WIDTH (1): run a 128/128 configuration on the generic-width kernels
-                                of wide.hip */
+                                of wide.hip; GAMD_KSEL_FORCE_HALF_QUANTUM (2): run the generic-width fp32 conv layer on 16-edge
+                                work units (wide16.hip, v_mfma_f32_16x16x4_f32; bit-identical results, measured slower at every
+                                size tried: never chosen automatically) */
     int32_t small_tile_limit;/* fp32 path: edge counts of at most this many 32-edge tiles run the latency-oriented conv kernel
                                 (one tile per 4-wave workgroup, bit-identical results).  0 = default (512), -1 = never */
     int32_t n_boxes;         /* 0 or 1: one box (default).  B > 1: B INDEPENDENT boxes of n_atoms atoms each, evaluated and
@@ -108,7 +110,7 @@ typedef struct gamd_config {
                                 index B*n).  A neighbour-buffer overflow in any box regrows the shared buffers. */
 } gamd_config;
 enum { GAMD_SELF_LOOP_DGL07_NOOP = 0, GAMD_SELF_LOOP_APPEND_ZERO_FEATURE = 1 };
-enum { GAMD_KSEL_FORCE_GENERIC_WIDTH = 1 };
+enum { GAMD_KSEL_FORCE_GENERIC_WIDTH = 1, GAMD_KSEL_FORCE_HALF_QUANTUM = 2 };
 
 const char* gamd_version(void);
 const char* gamd_last_error(void);
@@ -196,6 +198,8 @@ enum {
     GAMD_DBG_EFRAG = 3,     /* fp32  [ceil(E/32)][Eh/128][4][4][64][4]  e in fragment order */
     GAMD_DBG_FEAT = 4,      /* fp32  [E][48]  raw edge features (first 44|45, or 4|5 unexpanded, columns valid) */
     GAMD_DBG_CYCLES = 5,    /* int64 [n_cu][8][16]  per-wave cycle sums of the instrumented conv-edge kernel (profiling build) */
+    GAMD_DBG_PARTIAL = 6,   /* fp32  [pieces][H]  the LAST conv layer's partial-sum pieces (one row per run of edges with the same
+                               destination inside a 16-edge chunk), in CSR order */
     GAMD_DBG_H0 = 16        /* fp32  [n][H] residual stream h_l, sorted order: GAMD_DBG_H0 + l */
 };
 int32_t gamd_debug_get(gamd_handle* h, int32_t what, void* host_out, size_t bytes);
