@@ -73,7 +73,10 @@ __device__ __forceinline__ void silu_block16(f32x16& v, const f32x16* add, float
 // pipe idle after every barrier (CV_INGEMM).
 // BUNCH (variant): the 16 post-op elements of output tile tp - 1 run as ONE fenced block behind the first MFMA group of tile
 // tp (post(tp - 1, -1)) instead of one element per MFMA group.
-template <bool F2, bool BUNCH = false, typename WPtr, typename Post, typename Mid>
+// PRIO (variants CV_PRIO_TAIL / CV_PRIO_BUNCH, round 6: conv_edge_bf16.hip's SiLU blocks gained 10 % from it): bit 0 = the
+// trailing post-ops of output tile 3 (a pure vector stretch behind the last MFMA) at s_setprio 1, bit 1 = the fenced blocks of
+// BUNCH at s_setprio 1.
+template <bool F2, bool BUNCH = false, int PRIO = 0, typename WPtr, typename Post, typename Mid>
 __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)[4], f32x16 (&acc)[4], Post post, Mid mid) {
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
@@ -91,15 +94,21 @@ __device__ __forceinline__ void gemm128_post(WPtr W, int lane, const f32x16 (&X)
                 if (!BUNCH) { if (tp > 0) post(tp - 1, t * 4 + q); }
                 else if (tp > 0 && t == 0 && q == 0) {
                     __builtin_amdgcn_sched_barrier(0);
+                    if (PRIO & 2) __builtin_amdgcn_s_setprio(1);
                     post(tp - 1, -1);                                   // g = -1: the whole block
+                    if (PRIO & 2) __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
     }
-    if (BUNCH) { __builtin_amdgcn_sched_barrier(0); post(3, -1); return; }
+    if (PRIO) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
+    if (BUNCH) { __builtin_amdgcn_sched_barrier(0); post(3, -1); }
+    else {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) post(3, g);
+        for (int g = 0; g < 16; ++g) post(3, g);
+    }
+    if (PRIO) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
 }
 
 // The same GEMM with an explicit ring of D fragment buffers (4 registers each): the read of fragment g + D is issued as soon
@@ -171,6 +180,8 @@ enum {
     CV_SYM_GATHER = 2,   // every wave issues its gathers BEFORE the phase barrier (round-1 schedule; see below)
     CV_TRACKED_DMA = 4,  // the weight copy through __builtin_amdgcn_global_load_lds (compiler-tracked: see gamd_stage_weight_raw)
     CV_INGEMM = 8,       // weight copy / piece stores / D gather issued 64 MFMAs into the GEMM instead of at the phase boundary
+    CV_PRIO_TAIL = 16,   // the trailing post-ops of a GEMM (output tile 3's, behind the last MFMA) at s_setprio 1
+    CV_PRIO_BUNCH = 64,  // with CV_BUNCH: the fenced post-op blocks at s_setprio 1
     CV_NOBARRIER = 32,   // TIMING ONLY (results invalid): the phase barriers are skipped, waves run free
     CV_ROW0 = 128,       // TIMING ONLY: every S / D / hn gather reads row 0 (cache-hot)
     CV_BUNCH = 256,      // post-ops of an output tile as one fenced block (gemm128_post<.., BUNCH>)
@@ -360,7 +371,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
 #define GEMM(F2, BUF, IN, OUT, ...)                                                              \
     do {                                                                                         \
         if (V & CV_PF3) gemm128_post_pf<F2, 3>(BUF, lane, IN, OUT, __VA_ARGS__);                 \
-        else gemm128_post<F2, (V & CV_BUNCH) != 0>((const f32x4*)BUF, lane, IN, OUT, __VA_ARGS__); \
+        else gemm128_post<F2, (V & CV_BUNCH) != 0, ((V & CV_PRIO_TAIL) ? 1 : 0) | ((V & CV_PRIO_BUNCH) ? 2 : 0)>((const f32x4*)BUF, lane, IN, OUT, __VA_ARGS__); \
     } while (0)
 
     if (V & CV_NODMA) dma_on = false;
@@ -526,7 +537,7 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
 #define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
         // (CONV_PRODUCTION = 3592; | 1 = cycle marks)
         CASE(0); CASE(1); CASE(2); CASE(4); CASE(6); CASE(8); CASE(520); CASE(1544); CASE(3592); CASE(3593); CASE(3624); CASE(3720);
-        CASE(3848); CASE(11784); CASE(19976); CASE(28168); CASE(36360); CASE(60936); CASE(126472); CASE(192008); CASE(257544);
+        CASE(3848); CASE(3608); CASE(3864); CASE(3912); CASE(3928); CASE(11784); CASE(19976); CASE(28168); CASE(36360); CASE(60936); CASE(126472); CASE(192008); CASE(257544);
 #undef CASE
         default: break;
     }
