@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
         BT(3);                                         // SiLU 1 + pack
         if (BF16_PREFETCH_E) fetch_e(tile_n, Pn);     // next tile's e: three phases to land
         // phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]); group c = 2 t + k holds X[t][8 k .. 8 k + 7], two fp16 per dword
+        if (ABL & 16384) __builtin_amdgcn_s_setprio(1);           // ABL 16384: the S + D block at priority too
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
@@ -257,6 +258,7 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
                 RB[c >> 1][8 * (c & 1) + 2 * i] = add_h_h(S16[c][i], D16[c][i], false, false);
                 RB[c >> 1][8 * (c & 1) + 2 * i + 1] = add_h_h(S16[c][i], D16[c][i], true, true);
             }
+        if (ABL & 16384) { asm volatile("" : "+v"(RB[0]), "+v"(RB[3])); __builtin_amdgcn_s_setprio(0); }
         BT(4);                                         // S + D (waits for both gathers)
         gemm_abl<ABL, false>(W2, lane, P, RB);
         BT(5);                                         // GEMM 2
@@ -305,11 +307,13 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
         BT(11);                                        // GEMM 4
         if (!BF16_PREFETCH_E && BF16_FETCH_AFTER_GEMM4) fetch_e(tile_n, P);      // P is free: the next tile's e rides under the message / store block
         const unsigned keep_bits = ~(mask << 1);
+        if (ABL & 65536) __builtin_amdgcn_s_setprio(1);           // ABL 65536: message + segment sum at priority too
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 RB[tp][r] = fma_h_f_f(H16[r >> 2][r & 3][tp >> 1], RB[tp][r], (r > 0 && ((keep_bits >> r) & 1u)) ? RB[tp][r - 1] : 0.f, (tp & 1) != 0);
+        if (ABL & 65536) { asm volatile("" : "+v"(RB[0]), "+v"(RB[3])); __builtin_amdgcn_s_setprio(0); }
         BT(12);                                        // message + segment sum (waits for hn)
         unsigned ends = mask;
         if (nvalid > 0 && !((mask >> (nvalid - 1)) & 1u)) ends |= 1u << (nvalid - 1);
@@ -403,6 +407,9 @@ int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
         case 5120: return launch_bf16_abl<5120>(a, n_blocks, st);
         case 8192: return launch_bf16_abl<8192>(a, n_blocks, st);
         case 10240: return launch_bf16_abl<10240>(a, n_blocks, st);
+        case 16384: return launch_bf16_abl<16384>(a, n_blocks, st);
+        case 65536: return launch_bf16_abl<65536>(a, n_blocks, st);
+        case 81920: return launch_bf16_abl<81920>(a, n_blocks, st);
         default: break;
     }
 #endif

@@ -60,42 +60,6 @@ __device__ __forceinline__ void edge_features(const EncArgs& a, CPtr cen, int sr
     }
 }
 
-// The seven coefficients of gamd_gelu_hw's exponent polynomial as register PAIRS (c, c): v_pk_fma_f32 cannot take a literal,
-// and left to itself hipcc keeps the Horner chain scalar (6 x v_fmaak_f32 per element).
-typedef float gelu_f2 __attribute__((ext_vector_type(2)));
-struct GeluCoef { gelu_f2 q[7]; };
-__device__ __forceinline__ GeluCoef gelu_coef() {
-    GeluCoef k;
-    const float c[7] = {GAMD_GELU_Q0, GAMD_GELU_Q1, GAMD_GELU_Q2, GAMD_GELU_Q3, GAMD_GELU_Q4, GAMD_GELU_Q5, GAMD_GELU_Q6};
-#pragma unroll
-    for (int i = 0; i < 7; ++i) { k.q[i] = gelu_f2{c[i], c[i]}; asm volatile("" : "+v"(k.q[i])); }
-    return k;
-}
-__device__ __forceinline__ gelu_f2 pk_fma(gelu_f2 a, gelu_f2 b, gelu_f2 c) {
-    gelu_f2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-// GELU of two elements: per element exactly the operations of gamd_gelu_hw (same IEEE fused multiply-adds in the same
-// order, so the bits are the same), the six Horner steps as packed instructions: 77 lane cycles per pair instead of 96.
-__device__ __forceinline__ gelu_f2 gelu_pair(gelu_f2 x, const GeluCoef& k) {
-    const gelu_f2 a = {__builtin_amdgcn_fmed3f(fabsf(x[0]), 0.0f, 6.0f), __builtin_amdgcn_fmed3f(fabsf(x[1]), 0.0f, 6.0f)};
-    gelu_f2 q = pk_fma(k.q[6], a, k.q[5]);
-    q = pk_fma(q, a, k.q[4]);
-    q = pk_fma(q, a, k.q[3]);
-    q = pk_fma(q, a, k.q[2]);
-    q = pk_fma(q, a, k.q[1]);
-    q = pk_fma(q, a, k.q[0]);
-    const gelu_f2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
-    const gelu_f2 relu = {x[0] - __builtin_amdgcn_fmed3f(x[0], -3.0e38f, 0.0f), x[1] - __builtin_amdgcn_fmed3f(x[1], -3.0e38f, 0.0f)};
-    // The last step stays a compiler-visible instruction per element: its result is the next GEMM's MFMA operand, and gfx940+
-    // needs two wait states between a VALU write and an MFMA read of the same register (and one behind a transcendental) —
-    // hipcc's hazard recogniser inserts them for its own instructions but cannot see the operands of inline assembly.  The
-    // packed Horner steps above only ever feed v_exp_f32.
-    gelu_f2 r = {__builtin_fmaf(-a[0], e[0], relu[0]), __builtin_fmaf(-a[1], e[1], relu[1])};
-    return r;
-}
-
 // X = GELU(acc) on a 32 x 128 block.  ABL bit 1 (profiling build): x/2 instead (timing ablation, wrong results); bit 16:
 // the scalar form
 template <int ABL>

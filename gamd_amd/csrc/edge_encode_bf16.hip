@@ -13,6 +13,23 @@ namespace {
 constexpr int ENCB_W1_BYTES = 4 * 3 * 64 * 16;                       // 12 KiB
 constexpr int ENCB_LDS_BYTES = ENCB_W1_BYTES + 2 * GAMD_WFRAG_BF16_BYTES + (5 * 128 + 64) * 4;
 
+// GELU of a 32 x 128 block + rounding to the bf16 operands of the next GEMM, two elements at a time (gelu_pair: the Horner chain
+// of the exponent polynomial as packed instructions, per element the operations of gamd_gelu_hw: same bits as the scalar form)
+__device__ __forceinline__ void gelu_pack_bf16(const f32x16 (&X)[4], bf16x8 (&P)[4][2], const GeluCoef& k) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            gamd_u32x4 w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const gelu_f2 y = gelu_pair(gelu_f2{X[t][8 * u + 2 * q], X[t][8 * u + 2 * q + 1]}, k);
+                w[q] = gamd_pk_bf16(y[0], y[1]);
+            }
+            P[t][u] = __builtin_bit_cast(bf16x8, w);
+        }
+}
+
 template <int NFEAT>
 __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
     if (a.devflags[DEVFLAG_FROZEN]) return;          // frozen run: nothing to compute until the host has regrown and resumed
@@ -49,6 +66,7 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
     gamd_xcd_range(n_wg_tiles, blockIdx.x, gridDim.x, first, end, step);
     bf16x8* efrag = reinterpret_cast<bf16x8*>(a.e_frag);
     const float gexp = a.gamma * -1.4426950408889634f;
+    const GeluCoef gk = gelu_coef();
 
     for (int wt = first; wt < end; wt += step) {
         const int tile = wt * 8 + wave;
@@ -100,19 +118,11 @@ __global__ void __launch_bounds__(512, 2) k_edge_encode_bf16(EncArgs a) {
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp)
                 acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1[(tp * 3 + s) * 64 + lane], F[s], acc[tp], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = gamd_gelu_hw(acc[t][r]);
-        pack_chain_bf16(acc, P);
+        gelu_pack_bf16(acc, P, gk);
         // GEMM 2
         load_bias_chain(vb2, half, acc);
         gemm128_bf16<false>(W2, lane, P, acc);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = gamd_gelu_hw(acc[t][r]);
-        pack_chain_bf16(acc, P);
+        gelu_pack_bf16(acc, P, gk);
         // GEMM 3 + LayerNorm (fp32)
         load_bias_chain(vb3, half, acc);
         gemm128_bf16<false>(W3, lane, P, acc);
