@@ -11,6 +11,8 @@ for w in c2 dft; do { echo "# $name — $hdr2"; echo; cat $src/trace_${w}_f16x3.
 for w in c2 c5 c2_f16x3; do cp $src/pmc_$w.md $dst/${name}_pmc_$w.md; done
 tail -1 $src/bench_default.json > $dst/${name}_bench_default.json
 tail -1 $src/bench_f16x3.json > $dst/${name}_bench_f16x3.json
+[ -f $src/bench_default_detail.json ] && cp $src/bench_default_detail.json $dst/${name}_bench_default_detail.json
+[ -f $src/bench_driver_cmd.json ] && tail -1 $src/bench_driver_cmd.json > $dst/${name}_bench_driver_cmd.json
 cp $src/pmc_conv_edge.json $dst/pmc_conv_edge.json
 if [ -f $src/gather_hbm.json ]; then cp $src/gather_hbm.json $dst/gather_hbm.json; cp $src/gather_summary.md $dst/${name}_gather_summary.md; fi
 raw=$dst/${name%%_*}_raw
@@ -18,4 +20,5 @@ mkdir -p $raw
 cp $src/conv_variants_sched.log $raw/${name}_conv_variants_sched.log
 cp $src/conv_variants_cycles.log $raw/${name}_conv_variants_cycles.log
 cp $src/f16x3_marks.log $raw/${name}_f16x3_marks.log
-for f in node_variants.log node_marks_c5.log node_marks_c1.log node_marks_10000.log; do [ -f $src/$f ] && cp $src/$f $raw/${name}_$f; done
+for f in node_variants.log node_marks_c5.log node_marks_c1.log node_marks_10000.log bf16_variants_c5.log bf16_marks.log enc_variants.log bf16_overlap_probe.log mfma_korder_probe.log c5_error.log; do [ -f $src/$f ] && cp $src/$f $raw/${name}_$f; done
+true

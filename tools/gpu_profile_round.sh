@@ -34,17 +34,24 @@ python3 tools/profile_summary.py pmcjson $out/pmc_fetch_c2 $out/pmc_write_c2 'k_
 for cfg in "100000 bf16" "1000000 bf16" "1000000 f32"; do set -- $cfg; bash tools/gpu_pmc_gather.sh $tag/gather $1 $2 > /dev/null 2>&1; done
 python3 tools/profile_summary.py gatherjson $out/gather_hbm.json $out/gather/100000_bf16 $out/gather/1000000_bf16 $out/gather/1000000_f32 > /dev/null
 cat $out/gather/*/summary.md > $out/gather_summary.md
-# k_node at the shapes where it weighs most (C5: 375 tiles in split-fp16, C1: 17 tiles): timing ablations and segment marks
-python3 tools/node_variants.py c5 c1 c2 > $out/node_variants.log 2>&1
-for w in c5 c1 10000; do python3 tools/node_marks.py $w > $out/node_marks_$w.log 2>&1; done
+# the bf16 conv kernel: timing ablations / priority variants and segment marks (profiling build)
+python3 tools/bf16_variants.py 0 2048 1 2 4 256 384 263 903 > $out/bf16_variants_c5.log 2>&1
+GAMD_LIB=gamd_amd/libgamd_hip_prof.so GAMD_BF16_VARIANT=64 python3 tools/bf16_marks.py > $out/bf16_marks.log 2>&1
+python3 tools/enc_variants.py 160 0 32 96 224 > $out/enc_variants.log 2>&1
+./gamd_amd/csrc/probes/bf16_overlap_probe > $out/bf16_overlap_probe.log 2>&1
+./gamd_amd/csrc/probes/mfma_korder_probe > $out/mfma_korder_probe.log 2>&1
+python3 tools/c5_error.py > $out/c5_error.log 2>&1
 # conv-layer kernel: scheduling variants A/B and the s_memtime marks (profiling build)
 python3 tools/conv_variants.py 3592 0 8 520 1544 3848 > $out/conv_variants_sched.log 2>&1
 python3 tools/conv_variants.py 3593 --cycles > $out/conv_variants_cycles.log 2>&1
 # the bench records LAST, with this run's counter records in place: bench.py reports roofline.traffic / neighbour_gather_hbm only
 # for the kernel sources they were measured on (hash), and on this box profiles/ still holds the previous sources' records
 cp $out/pmc_conv_edge.json profiles/pmc_conv_edge.json; cp $out/gather_hbm.json profiles/gather_hbm.json
-python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-python3 bench.py --no-cpu-baseline --no-secondary --edge-dtype f16x3 > $out/bench_f16x3.json 2>> $out/bench_default.err
+# (the ONE stdout line is the compact contract record; the full record — per-step distributions, per-kernel list, all twelve
+#  secondary workloads — goes to --detail)
+python3 bench.py --secondary full --detail $out/bench_default_detail.json > $out/bench_default.json 2> $out/bench_default.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --detail $out/bench_driver_cmd_detail.json > $out/bench_driver_cmd.json 2>> $out/bench_default.err   # the driver's command
+python3 bench.py --no-cpu-baseline --no-secondary --edge-dtype f16x3 --detail - > $out/bench_f16x3.json 2>> $out/bench_default.err
 # keep the merge-back small: only the summaries and the per-kernel stats csv
 find $out -name "*_kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete; find $out -name "*agent_info.csv" -delete
 ls -la $out | head -50

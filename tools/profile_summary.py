@@ -128,7 +128,8 @@ def gather(d, n_atoms, dtype):
     hit, miss, req = avg("tcc", "TCC_HIT_sum"), avg("tcc", "TCC_MISS_sum"), avg("tcc", "TCC_REQ_sum")
     e_bytes = {"f32": 512.0, "bf16": 256.0, "f16x3": 512.0}[dtype]
     alg_gather = E * 1028.0 + n_atoms * 1024.0                     # SURVEY.md 8d, per layer: idx + hn[src] + S[src] rows, D rows, agg
-    mandatory = E * (e_bytes + 4.0 + 4.0 + 36.0) + n_atoms * 3 * 512.0   # e stream + col / erow + pieces; each node-table row ONCE
+    row_bytes = 256.0 if dtype == "bf16" else 512.0                        # bf16 edge MLP: fp16 node tables (round 6)
+    mandatory = E * (e_bytes + 4.0 + 4.0 + 36.0) + n_atoms * 3 * row_bytes  # e stream + col / erow + pieces; each node-table row ONCE
     t_live = live["conv_ms_per_launch"] * 1e-3
     hbm = (2.0 * fetch_kb + write_kb) * 1024.0 if fetch_kb is not None and write_kb is not None else None
     rec = {"n_atoms": n_atoms, "edges": E, "edge_dtype": dtype, "kernel": kern.rstrip("<"),
