@@ -256,8 +256,8 @@ int alloc_edges(gamd_handle* h, long long e_cap) {
     h->e_cap = e_cap;
     if (h->skin > 0.f) {
         const double grow = std::pow(((double)h->cfg.cutoff + h->skin) / (double)h->cfg.cutoff, 3.0);
-        // candidate rows have a fixed width (capacity / n), so what must fit is the LONGEST row, not the total:
-        // ~2.5 x the mean row (e_cap is already 1.5 x the density estimate)
+        // candidate rows have a fixed width (capacity / n) on the grid-wide path AND on the small-system path (round 5), so what
+        // must fit is the LONGEST row, not the total: ~2.5 x the mean row (e_cap is already 1.5 x the density estimate, x 1.7)
         const long long want = (long long)((double)e_cap * grow * 1.7) + 1024;
         if (want > h->cand_cap) return alloc_candidates(h, want);
     }

@@ -140,7 +140,6 @@ struct NbrArgs {
     // Verlet-skin reuse (graph_utils.py:21-25,36-44: build with cutoff + dr_threshold, rebuild when an atom has moved
     // dr_threshold / 2): candidate CSR built with rc + skin on the steps that need it, exact filter every step
     const int* gate;       // non-null: the kernel returns unless *gate != 0 (rebuild kernels of the skin mode)
-    int cand_pass;         // 1: deg/row_ptr/col are the candidate arrays; nothing is published to counters but CNT_NCAND
     float skin_half2;      // (skin / 2)^2
     int force_rebuild;     // first call, box change, regrown buffers
     float4* ref_pos;       // [n] wrapped positions at the last candidate build (original order)

@@ -338,7 +338,7 @@ __device__ __forceinline__ void d_scan_deg_fast(const NbrArgs& a) {
     int f[IPT], rp[IPT], mine2 = 0;
 #pragma unroll
     for (int k = 0; k < IPT; ++k) { rp[k] = run; run += v[k]; }
-    if (a.cand_pass == 0 && a.bx.n_boxes > 1 && a.bx.n_boxes <= 1024) {
+    if (a.bx.n_boxes > 1 && a.bx.n_boxes <= 1024) {
         // box alignment (see d_box_align) without leaving the workgroup: box starts -> LDS, thread b owns box b's padding,
         // one more block scan over the boxes, the shifts applied to the rows still in registers
         __shared__ int s_bstart[1025], s_bshift[1025];
@@ -380,7 +380,7 @@ __device__ __forceinline__ void d_scan_deg_fast(const NbrArgs& a) {
             }
         }
         E_all += ptotal;
-    } else if (a.cand_pass == 0 && a.bx.n_boxes > 1) {
+    } else if (a.bx.n_boxes > 1) {
         // (more than 1 024 boxes) publish the plain offsets, align the boxes' first rows in global memory, take the result back
 #pragma unroll
         for (int k = 0; k < IPT; ++k) if (i0 + k < a.n) a.row_ptr[i0 + k] = rp[k];
@@ -393,7 +393,7 @@ __device__ __forceinline__ void d_scan_deg_fast(const NbrArgs& a) {
     }
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        f[k] = (a.cand_pass == 0 && i0 + k < a.n && v[k] > 0 && (rp[k] % GAMD_CHUNK) != 0) ? 1 : 0;
+        f[k] = (i0 + k < a.n && v[k] > 0 && (rp[k] % GAMD_CHUNK) != 0) ? 1 : 0;
         mine2 += f[k];
     }
     if (i0 + IPT <= a.n) {
@@ -405,15 +405,6 @@ __device__ __forceinline__ void d_scan_deg_fast(const NbrArgs& a) {
         for (int k = 0; k < IPT; ++k) if (i0 + k < a.n) a.row_ptr[i0 + k] = rp[k];
     }
     if (tid == 0) a.row_ptr[a.n] = E_all;
-    if (a.cand_pass) {                                     // candidate CSR: only its size and overflow matter
-        if (tid == 0) {
-            a.counters[CNT_NCAND] = E_all;
-            a.sticky[STICKY_NCAND] = E_all;
-            if ((long long)E_all > a.e_cap) { a.sticky[STICKY_CAND_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1; }
-            a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
-        }
-        return;
-    }
     int y2 = mine2;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(y2, d, 64); if (lane >= d) y2 += y; }
@@ -447,17 +438,7 @@ __device__ __forceinline__ void d_scan_deg(const NbrArgs& a) {
     if (a.n <= 16 * 1024) { d_scan_deg_fast(a); return; }
     block_exclusive_scan(a.n, [&](int i) { return a.deg[i]; }, a.row_ptr);
     __syncthreads();
-    if (!a.cand_pass && a.bx.n_boxes > 1) d_box_align(a);
-    if (a.cand_pass) {                                     // candidate CSR: only its size and overflow matter
-        if (threadIdx.x == 0) {
-            const int nc = a.row_ptr[a.n];
-            a.counters[CNT_NCAND] = nc;
-            a.sticky[STICKY_NCAND] = nc;
-            if ((long long)nc > a.e_cap) { a.sticky[STICKY_CAND_OVERFLOW] = 1; a.devflags[DEVFLAG_FROZEN] = 1; }
-            a.sticky[STICKY_REBUILDS] = ++a.devflags[DEVFLAG_REBUILDS];
-        }
-        return;
-    }
+    if (a.bx.n_boxes > 1) d_box_align(a);
     block_exclusive_scan(a.n, [&](int i) { return (a.deg[i] > 0 && (a.row_ptr[i] % GAMD_CHUNK) != 0) ? 1 : 0; },
                          a.na_excl);
     __syncthreads();
@@ -513,7 +494,7 @@ __device__ __forceinline__ void d_publish_candidates(const NbrArgs& a) {
 
 __global__ void __launch_bounds__(1024) k_scan_deg(NbrArgs a) {
     GAMD_GATE();
-    if (!a.cand_pass && a.cand_stride > 0 && a.counters[CNT_REBUILD]) d_publish_candidates<1024>(a);
+    if (a.cand_stride > 0 && a.counters[CNT_REBUILD]) d_publish_candidates<1024>(a);
     d_scan_deg(a);
 }
 
@@ -544,7 +525,7 @@ __device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l, PosPtr 
     }, pos_s, cell_start);
     // self_loop_mode 1: the loop DGL's in-place add_self_loop would append (nn_module.py:650-652), last in the row
     if (a.self_loop && live && l == 0 && w < a.e_cap) { a.col[w] = c; if (a.erow) a.erow[w] = c; }
-    if (live && !a.cand_pass) d_fill_padding(a, c, l, w + (a.self_loop ? 1 : 0));
+    if (live) d_fill_padding(a, c, l, w + (a.self_loop ? 1 : 0));
 }
 __device__ __forceinline__ void d_fill(const NbrArgs& a, int ctr, int l) { d_fill(a, ctr, l, a.pos_s, a.cell_start); }
 
@@ -587,7 +568,6 @@ __global__ void k_chunk_meta(NbrArgs a) {
 // argument block of the candidate pass (rc + skin, candidate arrays, no self loops: the exact filter appends them)
 __device__ __forceinline__ NbrArgs cand_args(const NbrArgs& a) {
     NbrArgs c = a;
-    c.cand_pass = 1;
     c.rc = a.rc_build; c.rc2 = a.rc2_build;
     c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
     c.self_loop = 0;
@@ -1406,7 +1386,6 @@ int launch_neighbor_skin(const NbrArgs& a, hipStream_t st, const MdFuse* fuse) {
         // one gated on the flag k_skin_check has just written
         NbrArgs c = a;
         c.gate = a.counters + CNT_REBUILD;
-        c.cand_pass = 1;
         c.rc = a.rc_build; c.rc2 = a.rc2_build;
         c.deg = a.cand_deg; c.row_ptr = a.cand_ptr; c.col = a.cand_col; c.erow = nullptr; c.e_cap = a.cand_cap;
         c.self_loop = 0;
