@@ -132,6 +132,7 @@ struct gamd_handle {
     std::vector<float> boxes_host;               // [n_boxes][3] as last set
     int H = 128, Eh = 128, HT = 1, EHT = 1;      // node width, edge-embedding width (PADDED to 128-blocks) and their block counts
     int H_true = 128, Eh_true = 128, D_true = 128;   // encoding_size, edge_embedding_dim, hidden_dim as given (<= the padded ones)
+    int Dp = 128, DT = 1;                        // hidden_dim padded to 128-blocks; DT = 2: the kernels of wide_d.hip (fp32)
     int norm_bn = 0;                             // graph_conv.norm_layers are BatchNorm1d (running statistics in the state_dict)
     bool update_edge = false;                    // update_edge_emb=True: conv.<l>.edge_layer_norm keys in the state_dict
     bool node_f16 = false;                       // node.hip's GEMMs in split-fp16 (reduced-precision edge modes, 128-wide kernels)
@@ -633,7 +634,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
         return 0;
     };
     if ((r = tev_begin(100))) return r;                         // kind 100: edge encoder
-    r = h->wide_enc ? launch_edge_encode_wide(ea, h->EHT, h->n_cu, st)
+    r = h->DT > 1 ? launch_edge_encode_wide_d(ea, h->EHT, h->DT, h->n_cu, st)
+        : h->wide_enc ? launch_edge_encode_wide(ea, h->EHT, h->n_cu, st)
         : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_edge_encode_bf16(ea, h->n_cu, st)
         : h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_edge_encode_f16x3(ea, h->n_cu, st)
         : small_tiles > 0 ? launch_edge_encode_small(ea, small_tiles, st) : launch_edge_encode(ea, h->n_cu, st);
@@ -642,7 +644,9 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
     mark("edge_encode");
 
     const size_t nh = (size_t)h->n * (size_t)h->H;
-    auto node = [&](const NodeArgs& na_) { return h->wide_conv ? launch_node_wide(na_, h->HT, st) : launch_node(na_, st); };
+    auto node = [&](const NodeArgs& na_) {
+        return h->DT > 1 ? launch_node_wide_d(na_, h->HT, h->DT, st) : h->wide_conv ? launch_node_wide(na_, h->HT, st) : launch_node(na_, st);
+    };
     auto hptr = [&](int l) { return h->hbuf.as<float>() + (h->cfg.keep_stages ? (size_t)l * nh : (size_t)(l & 1) * nh); };
 
     NodeArgs no{};
@@ -714,7 +718,8 @@ int enqueue_forward(gamd_handle* h, const float* pos_dev, const uint8_t* species
 #endif
         ca.tdbg = h->tdbg.as<long long>();
         if ((r = tev_begin(l))) return r;                        // kind l: conv-layer edge kernel of layer l
-        r = h->wide_conv ? (h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3_wide(ca, h->EHT, h->HT, h->n_cu, st)
+        r = h->DT > 1 ? launch_conv_edge_wide_d(ca, h->EHT, h->HT, h->DT, h->n_cu, st)
+            : h->wide_conv ? (h->cfg.edge_dtype == GAMD_EDGE_F16X3 ? launch_conv_edge_f16x3_wide(ca, h->EHT, h->HT, h->n_cu, st)
                             : h->cfg.edge_dtype == GAMD_EDGE_BF16 ? launch_conv_edge_bf16_wide(ca, h->EHT, h->HT, h->n_cu, st)
                             : (half_quantum && ca.w16p && !ca.emb_out) ? launch_conv_edge_wide16(ca, h->EHT, h->HT, h->n_cu, st)
                             : small_tiles > 0 ? launch_conv_edge_small_wide(ca, h->EHT, h->HT, small_tiles, st)
@@ -918,7 +923,11 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     const int D_true = cfg->hidden_dim ? cfg->hidden_dim : 128;
     if (H_true < 1 || H_true > 256 || Eh_true < 1 || Eh_true > 256)
         return fail(-22, "encoding_size and edge_embedding_dim must be in [1, 256] (got %d, %d)", H_true, Eh_true);
-    if (D_true < 1 || D_true > 128) return fail(-22, "hidden_dim must be in [1, 128] (got %d)", D_true);
+    if (D_true < 1 || D_true > 256) return fail(-22, "hidden_dim must be in [1, 256] (got %d)", D_true);
+    const int Dp = D_true <= 128 ? 128 : 256;
+    // hidden_dim above 128: two 128-blocks per D-wide operand, the fp32 kernels of wide_d.hip
+    if (Dp > 128 && cfg->edge_dtype != GAMD_EDGE_F32)
+        return fail(-22, "hidden_dim above 128 is built for edge_dtype f32 only (got hidden_dim %d)", D_true);
     const int H = H_true <= 128 ? 128 : 256, Eh = Eh_true <= 128 ? 128 : 256;
     const bool exact128 = H_true == 128 && Eh_true == 128 && D_true == 128;
     const bool generic = H != 128 || Eh != 128 || cfg->no_expand_edge;
@@ -941,13 +950,14 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     h->L = cfg->n_layers;
     h->H = H; h->Eh = Eh; h->HT = H / 128; h->EHT = Eh / 128;
     h->H_true = H_true; h->Eh_true = Eh_true; h->D_true = D_true;
+    h->Dp = Dp; h->DT = Dp / 128;
     h->skin = cfg->neighbor_skin;
     if (cfg->small_tile_limit != 0) h->small_tile_limit = cfg->small_tile_limit < 0 ? -1 : cfg->small_tile_limit;
     const bool forced = (cfg->kernel_select & GAMD_KSEL_FORCE_GENERIC_WIDTH) && cfg->edge_dtype == GAMD_EDGE_F32;
     // bf16 / split-fp16 outside 128 / 128 / 128 expanded: encoder, conv and node kernels all take the generic-width route
     const bool lp_generic = cfg->edge_dtype != GAMD_EDGE_F32 && (generic || !exact128);
-    h->wide_enc = generic || forced || lp_generic;
-    h->wide_conv = H != 128 || Eh != 128 || forced || lp_generic;
+    h->wide_enc = generic || forced || lp_generic || Dp > 128;
+    h->wide_conv = H != 128 || Eh != 128 || forced || lp_generic || Dp > 128;
     h->n_feat = (cfg->no_expand_edge ? 4 : 44) + (cfg->use_bond ? 1 : 0);
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t n = (size_t)h->n;
@@ -966,18 +976,18 @@ int32_t gamd_create(const gamd_config* cfg, gamd_handle** out) {
     r |= h->deg.ensure(sizeof(int) * n, true);
     r |= h->row_ptr.ensure(sizeof(int) * (n + 1), true);
     r |= h->na_excl.ensure(sizeof(int) * (n + 1), true);
-    const size_t nh = n * (size_t)H * sizeof(float), nd = n * 128 * sizeof(float);
+    const size_t nh = n * (size_t)H * sizeof(float), nd = n * (size_t)Dp * sizeof(float), zd = (size_t)Dp * sizeof(float);
     r |= h->hbuf.ensure(nh * (cfg->keep_stages ? (size_t)h->L + 1 : 2), true);
     // one extra, all-zero row (index n) behind the node tables the conv-layer edge kernel gathers from: the padding
     // slots of the last 32-edge tile point at it, so their messages are exact zeros without a per-element mask
     r |= h->hn.ensure(nh + (size_t)H * sizeof(float), true);
-    r |= h->S.ensure(nd + 128 * sizeof(float), true);
-    r |= h->D.ensure(nd + 128 * sizeof(float), true);
+    r |= h->S.ensure(nd + zd, true);
+    r |= h->D.ensure(nd + zd, true);
     r |= h->P.ensure(nd, true);
     if (cfg->neighbor_skin > 0.f) {
         r |= h->l0_hn.ensure(nh + (size_t)H * sizeof(float), true);
-        r |= h->l0_S.ensure(nd + 128 * sizeof(float), true);
-        r |= h->l0_D.ensure(nd + 128 * sizeof(float), true);
+        r |= h->l0_S.ensure(nd + zd, true);
+        r |= h->l0_D.ensure(nd + zd, true);
         r |= h->l0_P.ensure(nd, true);
         if (!cfg->keep_stages) r |= h->l0_h.ensure(nh, true);
     }
@@ -1080,6 +1090,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     const int F = h->n_feat, L = h->L;
     const int64_t H = h->H, Eh = h->Eh, HT = h->HT, EHT = h->EHT;         // padded widths the kernels work in
     const int64_t Ht = h->H_true, Et = h->Eh_true, Dt = h->D_true;        // the state_dict's widths
+    const int64_t Dp = h->Dp, DT = h->DT;                                 // hidden_dim padded to 128-blocks (DT = 2: wide_d.hip)
     const bool expand = !h->cfg.no_expand_edge;
     BlobBuilder bb;
     struct Off { size_t w1p, w2p, w3p, w4p, w16p = 0, b1, b3, b4, elng = 0, elnb = 0, lng, lnb, wsp, wdp, wpdp, bS, bP, wpep, wphip, bphi; };
@@ -1157,6 +1168,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             return fail(-22, "update_edge_emb needs encoding_size == edge_embedding_dim (got %d, %d)", (int)Ht, (int)Et);
         if (h->cfg.edge_dtype != GAMD_EDGE_F32 || h->cfg.self_loop_mode)
             return fail(-22, "update_edge_emb is built for the fp32 edge MLP without appended self loops");
+        if (DT > 1) return fail(-22, "update_edge_emb is built for hidden_dim up to 128 (got %d)", (int)Dt);
         h->wide_enc = h->wide_conv = true;
     }
     if (update_edge != h->update_edge) {
@@ -1170,14 +1182,14 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         const std::string p = "graph_conv.conv." + std::to_string(l);
         // edge_affine = MLP(Eh, hidden_dim, hidden_layer=2): its inner width is MLP's default 128 (nn_module.py:25,95)
         const HostTensor *ea0w = get(p + ".edge_affine.mlp_layer.0.weight", {128, Et}, {128, Eh}), *ea0b = get(p + ".edge_affine.mlp_layer.0.bias", {128}, {128});
-        const HostTensor *ea2w = get(p + ".edge_affine.mlp_layer.2.weight", {Dt, 128}, {128, 128}), *ea2b = get(p + ".edge_affine.mlp_layer.2.bias", {Dt}, {128});
-        const HostTensor *sw = get(p + ".src_affine.weight", {Dt, Ht}, {128, H}), *sb = get(p + ".src_affine.bias", {Dt}, {128});
-        const HostTensor *dw = get(p + ".dst_affine.weight", {Dt, Ht}, {128, H}), *db = get(p + ".dst_affine.bias", {Dt}, {128});
-        const HostTensor *t1w = get(p + ".theta_edge.mlp_layer.1.weight", {Dt, Dt}, {128, 128}), *t1b = get(p + ".theta_edge.mlp_layer.1.bias", {Dt}, {128});
-        const HostTensor *t3w = get(p + ".theta_edge.mlp_layer.3.weight", {Ht, Dt}, {H, 128}), *t3b = get(p + ".theta_edge.mlp_layer.3.bias", {Ht}, {H});
-        const HostTensor *pdw = get(p + ".phi_dst.weight", {Dt, Ht}, {128, H}), *pdb = get(p + ".phi_dst.bias", {Dt}, {128});
-        const HostTensor *pew = get(p + ".phi_edge.weight", {Dt, Ht}, {128, H}), *peb = get(p + ".phi_edge.bias", {Dt}, {128});
-        const HostTensor *phw = get(p + ".phi.mlp_layer.1.weight", {Ht, Dt}, {H, 128}), *phb = get(p + ".phi.mlp_layer.1.bias", {Ht}, {H});
+        const HostTensor *ea2w = get(p + ".edge_affine.mlp_layer.2.weight", {Dt, 128}, {Dp, 128}), *ea2b = get(p + ".edge_affine.mlp_layer.2.bias", {Dt}, {Dp});
+        const HostTensor *sw = get(p + ".src_affine.weight", {Dt, Ht}, {Dp, H}), *sb = get(p + ".src_affine.bias", {Dt}, {Dp});
+        const HostTensor *dw = get(p + ".dst_affine.weight", {Dt, Ht}, {Dp, H}), *db = get(p + ".dst_affine.bias", {Dt}, {Dp});
+        const HostTensor *t1w = get(p + ".theta_edge.mlp_layer.1.weight", {Dt, Dt}, {Dp, Dp}), *t1b = get(p + ".theta_edge.mlp_layer.1.bias", {Dt}, {Dp});
+        const HostTensor *t3w = get(p + ".theta_edge.mlp_layer.3.weight", {Ht, Dt}, {H, Dp}), *t3b = get(p + ".theta_edge.mlp_layer.3.bias", {Ht}, {H});
+        const HostTensor *pdw = get(p + ".phi_dst.weight", {Dt, Ht}, {Dp, H}), *pdb = get(p + ".phi_dst.bias", {Dt}, {Dp});
+        const HostTensor *pew = get(p + ".phi_edge.weight", {Dt, Ht}, {Dp, H}), *peb = get(p + ".phi_edge.bias", {Dt}, {Dp});
+        const HostTensor *phw = get(p + ".phi.mlp_layer.1.weight", {Ht, Dt}, {H, Dp}), *phb = get(p + ".phi.mlp_layer.1.bias", {Ht}, {H});
         const HostTensor *ng = get("graph_conv.norm_layers." + std::to_string(l) + ".weight", {Ht}, {H});
         const HostTensor *nb = get("graph_conv.norm_layers." + std::to_string(l) + ".bias", {Ht}, {H});
         if (!ea0w || !ea0b || !ea2w || !ea2b || !sw || !sb || !dw || !db || !t1w || !t1b || !t3w || !t3b || !pdw ||
@@ -1262,10 +1274,13 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             o.w4p = put_blocks_f16x3(t3w, (int)HT, 1);
         } else {
             // one contiguous run of blocks: W1[:, kb] (EHT) | W2 | W3 | W4[ob, :] (HT) -- the order the kernels stream them
+            // (hidden_dim above 128, wide_d.hip: W1[:, kb] (EHT) | W2[db, :] (DT) | W3[ob][db] (DT x DT) | W4[ob][db] (HT x DT))
             o.w1p = put_blocks(ea0w, 1, (int)EHT);
-            o.w2p = put_blocks(ea2w, 1, 1);
-            o.w3p = put_blocks(t1w, 1, 1);
-            if (h->wide_conv) {
+            o.w2p = put_blocks(ea2w, (int)DT, 1);
+            o.w3p = put_blocks(t1w, (int)DT, (int)DT);
+            if (DT > 1) {
+                o.w4p = put_blocks(t3w, (int)HT, (int)DT);
+            } else if (h->wide_conv) {
                 o.w4p = put_blocks(t3w, (int)HT, 1);
                 // the same run of blocks for the opt-in 16-edge kernel (wide16.hip): W1[:, kb] | W2 | W3 chained, W4[ob, :] not
                 o.w16p = bb.add((size_t)(EHT + 2 + HT) * GAMD_WFRAG_FLOATS);
@@ -1286,32 +1301,35 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             if (!eg || !eb) return -2;
             o.elng = put_vec(eg); o.elnb = put_vec(eb);
         }
-        o.wsp = put_node(sw, 1, (int)HT); o.wdp = put_node(dw, 1, (int)HT); o.wpdp = put_node(pdw, 1, (int)HT);
-        o.bS = bb.add(128);
-        for (int i = 0; i < 128; ++i) bb.host[o.bS + i] = (sb->data[i] + db->data[i]) + ea2b->data[i];
-        o.bP = bb.add(128);
-        for (int i = 0; i < 128; ++i) bb.host[o.bP + i] = pdb->data[i] + peb->data[i];
-        o.wpep = put_node(pew, 1, (int)HT); o.wphip = put_node(phw, (int)HT, 1); o.bphi = put_vec(phb);
+        o.wsp = put_node(sw, (int)DT, (int)HT); o.wdp = put_node(dw, (int)DT, (int)HT); o.wpdp = put_node(pdw, (int)DT, (int)HT);
+        o.bS = bb.add((size_t)Dp);
+        for (int i = 0; i < (int)Dp; ++i) bb.host[o.bS + i] = (sb->data[i] + db->data[i]) + ea2b->data[i];
+        o.bP = bb.add((size_t)Dp);
+        for (int i = 0; i < (int)Dp; ++i) bb.host[o.bP + i] = pdb->data[i] + peb->data[i];
+        o.wpep = put_node(pew, (int)DT, (int)HT); o.wphip = put_node(phw, (int)HT, (int)DT); o.bphi = put_vec(phb);
     }
-    const HostTensor *e0w = get("edge_encoder.mlp_layer.0.weight", {Dt, (int64_t)F}, {128, (int64_t)F}), *e0b = get("edge_encoder.mlp_layer.0.bias", {Dt}, {128});
-    const HostTensor *e2w = get("edge_encoder.mlp_layer.2.weight", {Dt, Dt}, {128, 128}), *e2b = get("edge_encoder.mlp_layer.2.bias", {Dt}, {128});
-    const HostTensor *e4w = get("edge_encoder.mlp_layer.4.weight", {Et, Dt}, {Eh, 128}), *e4b = get("edge_encoder.mlp_layer.4.bias", {Et}, {Eh});
+    const HostTensor *e0w = get("edge_encoder.mlp_layer.0.weight", {Dt, (int64_t)F}, {Dp, (int64_t)F}), *e0b = get("edge_encoder.mlp_layer.0.bias", {Dt}, {Dp});
+    const HostTensor *e2w = get("edge_encoder.mlp_layer.2.weight", {Dt, Dt}, {Dp, Dp}), *e2b = get("edge_encoder.mlp_layer.2.bias", {Dt}, {Dp});
+    const HostTensor *e4w = get("edge_encoder.mlp_layer.4.weight", {Et, Dt}, {Eh, Dp}), *e4b = get("edge_encoder.mlp_layer.4.bias", {Et}, {Eh});
     const HostTensor *elg = get("edge_layer_norm.weight", {Et}, {Eh}), *elb = get("edge_layer_norm.bias", {Et}, {Eh});
     const HostTensor *cen = expand ? get("edge_expand.centers", {40}, {40}) : nullptr;
     const HostTensor *lm = get("length_mean", {1}, {1}), *ls = get("length_std", {1}, {1});
-    const HostTensor *d0w = get("graph_decoder.mlp_layer.0.weight", {Dt, Ht}, {128, H}), *d0b = get("graph_decoder.mlp_layer.0.bias", {Dt}, {128});
-    const HostTensor *d2w = get("graph_decoder.mlp_layer.2.weight", {3, Dt}, {3, 128}), *d2b = get("graph_decoder.mlp_layer.2.bias", {3}, {3});
+    const HostTensor *d0w = get("graph_decoder.mlp_layer.0.weight", {Dt, Ht}, {Dp, H}), *d0b = get("graph_decoder.mlp_layer.0.bias", {Dt}, {Dp});
+    const HostTensor *d2w = get("graph_decoder.mlp_layer.2.weight", {3, Dt}, {3, Dp}), *d2b = get("graph_decoder.mlp_layer.2.bias", {3}, {3});
     if (!e0w || !e0b || !e2w || !e2b || !e4w || !e4b || !elg || !elb || (expand && !cen) || !lm || !ls || !d0w || !d0b ||
         !d2w || !d2b)
         return -2;
-    const size_t o_e1 = bb.add(4 * 6 * 64 * 4);
-    if (bf16_edges) pack_enc1_bf16(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
+    // (hidden_dim above 128: the DT 128-row images of the first Linear side by side in one 64 KiB slot, the streamed blocks of
+    //  W2 and W3 right behind it — k_edge_encode_wide_d walks them as one run)
+    const size_t o_e1 = bb.add(DT > 1 ? (size_t)GAMD_WFRAG_FLOATS : (size_t)(4 * 6 * 64 * 4));
+    if (DT > 1) for (int64_t b = 0; b < DT; ++b) pack_enc1(e0w->data.data() + (size_t)(128 * b * F), F, bb.host.data() + o_e1 + (size_t)b * (4 * 6 * 64 * 4));
+    else if (bf16_edges) pack_enc1_bf16(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
     else if (f16x3_edges) pack_enc1_f16x3(e0w->data.data(), F, reinterpret_cast<uint16_t*>(bb.host.data() + o_e1));
     else pack_enc1(e0w->data.data(), F, bb.host.data() + o_e1);
     // generic-width encoder in the reduced-precision modes: its two 128-wide GEMMs run in split-fp16 (wide.hip, e_format != 0)
     const bool enc_wide_f16 = h->wide_enc && h->cfg.edge_dtype != GAMD_EDGE_F32;
     const size_t o_e2 = bf16_edges ? put_edge_bf16(e2w) : f16x3_edges ? put_edge_f16x3(e2w) : enc_wide_f16 ? put_blocks_f16x3(e2w, 1, 1)
-                                                                                                              : put_blocks(e2w, 1, 1);
+                                                                                                              : put_blocks(e2w, (int)DT, (int)DT);
     // fp32 path: the last encoder Linear is stored with its OUTPUT rows centred, W' = W - mean over rows, b' = b - mean(b)
     // (in double): y' = W' x + b' = y - mean(y) exactly in real arithmetic, so edge_layer_norm's mean subtraction
     // (nn_module.py:646) is done here once instead of per edge; the kernels only normalise the variance
@@ -1319,11 +1337,11 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
     HostTensor e4w_c = *e4w, e4b_c = *e4b;
     if (!bf16_edges && !f16x3_edges) {
         // (the mean is over the Et true output rows; zero-padded rows stay zero)
-        for (int64_t k = 0; k < 128; ++k) {
+        for (int64_t k = 0; k < Dp; ++k) {
             double m = 0.0;
-            for (int64_t o = 0; o < Et; ++o) m += (double)e4w->data[(size_t)(o * 128 + k)];
+            for (int64_t o = 0; o < Et; ++o) m += (double)e4w->data[(size_t)(o * Dp + k)];
             m /= (double)Et;
-            for (int64_t o = 0; o < Et; ++o) e4w_c.data[(size_t)(o * 128 + k)] = (float)((double)e4w->data[(size_t)(o * 128 + k)] - m);
+            for (int64_t o = 0; o < Et; ++o) e4w_c.data[(size_t)(o * Dp + k)] = (float)((double)e4w->data[(size_t)(o * Dp + k)] - m);
         }
         double mb = 0.0;
         for (int64_t o = 0; o < Et; ++o) mb += (double)e4b->data[(size_t)o];
@@ -1331,10 +1349,10 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         for (int64_t o = 0; o < Et; ++o) e4b_c.data[(size_t)o] = (float)((double)e4b->data[(size_t)o] - mb);
     }
     const size_t o_e3 = bf16_edges ? put_edge_bf16(e4w) : f16x3_edges ? put_edge_f16x3(e4w) : enc_wide_f16 ? put_blocks_f16x3(&e4w_c, (int)EHT, 1)
-                                                                                                              : put_blocks(&e4w_c, (int)EHT, 1);
+                                                                                                              : put_blocks(&e4w_c, (int)EHT, (int)DT);
     const size_t o_eb1 = put_vec(e0b), o_eb2 = put_vec(e2b), o_eb3 = put_vec(&e4b_c), o_elg = put_vec(elg), o_elb = put_vec(elb);
     const size_t o_cen = expand ? put_vec(cen) : bb.add(64);
-    const size_t o_d1 = put_node(d0w, 1, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
+    const size_t o_d1 = put_node(d0w, (int)DT, (int)HT), o_db1 = put_vec(d0b), o_d2 = put_vec(d2w), o_db2 = put_vec(d2b);
     size_t o_emb = 0, o_nw = 0, o_nb = 0;
     if (h->cfg.kind == GAMD_KIND_LJ) {
         const HostTensor* emb = get("node_emb", {1, Ht}, {1, H});
@@ -1370,7 +1388,7 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
         const Off& o = lo[l];
         LayerDev& d = h->layers[l];
         d.w1p = B + o.w1p; d.w2p = B + o.w2p; d.w3p = B + o.w3p; d.w4p = B + o.w4p;
-        d.w16p = (h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F32) ? B + o.w16p : nullptr;
+        d.w16p = (h->wide_conv && h->cfg.edge_dtype == GAMD_EDGE_F32 && DT == 1) ? B + o.w16p : nullptr;
         d.b1 = B + o.b1; d.b3 = B + o.b3; d.b4 = B + o.b4;
         d.node.ln_g = B + o.lng; d.node.ln_b = B + o.lnb;
         if (update_edge) { d.e_ln_g = B + o.elng; d.e_ln_b = B + o.elnb; }

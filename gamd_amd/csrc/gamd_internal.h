@@ -223,6 +223,9 @@ int launch_edge_encode_f16x3(const EncArgs& a, int n_blocks, hipStream_t st);  /
 // generic widths (wide.hip): n_feat in {4, 5, 44, 45}; w3p = eht packed blocks W3[128 ob : 128 ob + 128, :],
 // b3 / ln_g / ln_b are [128 eht]; e_frag is [tiles][eht][4][4][64][4]
 int launch_edge_encode_wide(const EncArgs& a, int eht, int n_blocks, hipStream_t st);
+// hidden_dim above 128 (wide_d.hip, fp32): D = 128 dt, dt = 2.  w1p points at 1 + dt^2 + eht dt contiguous 64 KiB blocks
+// [W1: dt images of 24 KiB] | W2[ob][kb] | W3[ob][kb]; b1, b2 are [128 dt]
+int launch_edge_encode_wide_d(const EncArgs& a, int eht, int dt, int n_blocks, hipStream_t st);
 
 // ---- conv layer, edge side --------------------------------------------------------------------
 struct ConvEdgeArgs {
@@ -263,6 +266,9 @@ int launch_conv_edge_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, 
 // the same on 16-edge work units (wide16.hip: v_mfma_f32_16x16x4_f32, one wave per SIMD, a.w16p), bit-identical to
 // launch_conv_edge_wide; for launches whose 32-edge tiles leave the SIMDs between 1 and 1.5 (2 and 2.5, ...) quanta of work
 int launch_conv_edge_wide16(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
+// hidden_dim above 128 (wide_d.hip, fp32): w1p points at eht + dt + dt^2 + ht dt contiguous blocks
+// W1[:, kb] | W2[db, :] | W3[ob][db] | W4[ob][db]; b3 is [128 dt]; S and D rows are 128 dt wide
+int launch_conv_edge_wide_d(const ConvEdgeArgs& a, int eht, int ht, int dt, int n_blocks, hipStream_t st);
 // the same on the fp16 matrix pipe by operand splitting (wide_lp.hip): w1p = eht + 2 + ht contiguous [hi | lo] fp16 images,
 // e_frag in the encoder's e_format 2, hn rows in their natural [n][H] layout
 int launch_conv_edge_f16x3_wide(const ConvEdgeArgs& a, int eht, int ht, int n_blocks, hipStream_t st);
@@ -336,6 +342,9 @@ int launch_node(const NodeArgs& a, hipStream_t st);
 // generic widths (wide.hip): h / hn / partial rows and node_emb, enc_w, enc_b, ln_*, bphi are H = 128 ht wide;
 // wsp, wdp, wpdp, wpep, dec_w1p are ht K-blocks, wphip is ht output blocks; S, D, P stay 128 wide
 int launch_node_wide(const NodeArgs& a, int ht, hipStream_t st);
+// hidden_dim above 128 (wide_d.hip, fp32): S, D, P rows, bS, bP, dec_b1 are 128 dt wide, dec_w2 is [3][128 dt]; wsp, wdp, wpdp, wpep,
+// dec_w1p are dt x ht blocks (output block major), wphip is ht x dt
+int launch_node_wide_d(const NodeArgs& a, int ht, int dt, hipStream_t st);
 
 // ---- integrator -------------------------------------------------------------------------------
 // rigid 3-site water (atoms O,H,H): masses and the SETTLE canonical triangle (Miyamoto & Kollman 1992):

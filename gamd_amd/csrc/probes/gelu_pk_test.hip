@@ -2,34 +2,7 @@
 #include <cstdio>
 #include <vector>
 #include <cmath>
-typedef float gelu_f2 __attribute__((ext_vector_type(2)));
-struct GeluCoef { gelu_f2 q[7]; };
-__device__ __forceinline__ GeluCoef gelu_coef() {
-    GeluCoef k;
-    const float c[7] = {GAMD_GELU_Q0, GAMD_GELU_Q1, GAMD_GELU_Q2, GAMD_GELU_Q3, GAMD_GELU_Q4, GAMD_GELU_Q5, GAMD_GELU_Q6};
-#pragma unroll
-    for (int i = 0; i < 7; ++i) { k.q[i] = gelu_f2{c[i], c[i]}; asm volatile("" : "+v"(k.q[i])); }
-    return k;
-}
-__device__ __forceinline__ gelu_f2 pk_fma(gelu_f2 a, gelu_f2 b, gelu_f2 c) {
-    gelu_f2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ gelu_f2 gelu_pair(gelu_f2 x, const GeluCoef& k) {
-    const gelu_f2 a = {__builtin_amdgcn_fmed3f(fabsf(x[0]), 0.0f, 6.0f), __builtin_amdgcn_fmed3f(fabsf(x[1]), 0.0f, 6.0f)};
-    gelu_f2 q = pk_fma(k.q[6], a, k.q[5]);
-    q = pk_fma(q, a, k.q[4]);
-    q = pk_fma(q, a, k.q[3]);
-    q = pk_fma(q, a, k.q[2]);
-    q = pk_fma(q, a, k.q[1]);
-    q = pk_fma(q, a, k.q[0]);
-    const gelu_f2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
-    const gelu_f2 relu = {x[0] - __builtin_amdgcn_fmed3f(x[0], -3.0e38f, 0.0f), x[1] - __builtin_amdgcn_fmed3f(x[1], -3.0e38f, 0.0f)};
-    gelu_f2 r;
-    asm("s_nop 1\n\tv_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(e), "v"(relu));
-    return r;
-}
+// gelu_pair / gelu_coef: the production forms in gamd_common.h
 __global__ void k(const float* x, float* y0, float* y1, int n) {
     const GeluCoef gk = gelu_coef();
     int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2;

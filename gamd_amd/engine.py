@@ -75,11 +75,11 @@ class GamdForce:
             raise _lib.GamdError("GamdForce needs a HIP device (torch.cuda.is_available() is False); "
                                  "there is no CPU fallback")
         cfg = cfg or infer_config(state_dict)
-        # build_model's widths (nn_module.py:561-601): anything up to 256 / 128 / 256 — the library zero-pads to its 128-wide
-        # blocks and normalises over the true widths
-        if (not 1 <= cfg.encoding_size <= 256 or not 1 <= cfg.edge_embedding_dim <= 256 or not 1 <= cfg.hidden_dim <= 128
+        # build_model's widths (nn_module.py:561-601): anything up to 256 / 256 / 256 — the library zero-pads to its 128-wide
+        # blocks and normalises over the true widths (hidden_dim above 128: fp32 edge MLP only, the library says so)
+        if (not 1 <= cfg.encoding_size <= 256 or not 1 <= cfg.edge_embedding_dim <= 256 or not 1 <= cfg.hidden_dim <= 256
                 or cfg.n_rbf not in (0, 40)):
-            raise ValueError("the gfx950 kernels cover encoding_size / edge_embedding_dim up to 256, hidden_dim up to 128 "
+            raise ValueError("the gfx950 kernels cover encoding_size / edge_embedding_dim / hidden_dim up to 256 "
                              "and the RBF expansion on (40 centres) or off "
                              f"(got enc={cfg.encoding_size} hidden={cfg.hidden_dim} edge={cfg.edge_embedding_dim} "
                              f"n_rbf={cfg.n_rbf})")

@@ -282,6 +282,24 @@ def generate(argv):
     if "--only-wide" in argv:
         return
 
+    # hidden_dim above 128 (the MLPs' inner width, nn_module.py:24-51 — any value is legal in the reference): 192 (not a
+    # multiple of the 128-wide block the kernels pad to) on LJ and 256 with the trainers' other default widths on water.
+    # `--only-d256` writes just these two.
+    if "--only-d256" in argv or everything:
+        run_fixed_box(nn_module, "lj258_d192_seed15",
+                      ModelConfig(kind="lj", encoding_size=128, hidden_dim=192, edge_embedding_dim=128, conv_layer=4), 15,
+                      lj_pos, 27.27, 7.5, SHIPPED_SCALERS["lj"], lmean=5.3, lstd=1.6, edge_stride=61, h_stride=3)
+        nd_ = w_pos.shape[0]
+        featd = torch.zeros(nd_, 1)
+        featd[::3] = 1.0
+        run_fixed_box(nn_module, "tip3p774_d256_w256_seed16",
+                      ModelConfig(kind="water", use_bond=True, encoding_size=256, hidden_dim=256, edge_embedding_dim=256,
+                                  conv_layer=4), 16,
+                      w_pos, 20.0, 4.2, SHIPPED_SCALERS["tip3p"], feat=featd, bond=water_bond(nd_),
+                      lmean=2.9, lstd=1.1, edge_stride=211, h_stride=9)
+    if "--only-d256" in argv:
+        return
+
     # use_layer_norm=False: the constructors' and the trainers' DEFAULT (--use_layer_norm is a store_true flag,
     # LJ/train_network_lj.py:398): nn.BatchNorm1d between the conv layers (nn_module.py:171-196, :579), in eval mode with
     # non-trivial running statistics.  `--only-bn` writes just these two.

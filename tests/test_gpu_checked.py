@@ -47,6 +47,7 @@ REPRESENTATIVE = [
     "tests/test_gpu_batch.py::test_batch_rigid_water_and_nose_hoover_chains_per_box",
     "tests/test_gpu_round4.py::test_reduced_precision_kernels_on_sparse_tiny_and_overflowing_inputs",
     "tests/test_gpu_round4.py::test_update_edge_emb_matches_the_reference_goldens",
+    "tests/test_gpu_hidden256.py::test_reference_goldens_stage_by_stage",
     "tests/test_gpu_lifecycle.py::test_fresh_handles_on_side_streams_match_the_default_stream",
     "tests/test_gpu_lifecycle.py::test_candidate_rebuild_by_sliced_workgroups_sorts_like_the_exact_build",
 ]

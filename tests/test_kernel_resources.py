@@ -30,7 +30,7 @@ def test_every_kernel_family_is_present(resources):
     for k in ("k_conv_edge<", "k_conv_edge_small<", "k_conv_edge_bf16", "k_conv_edge_f16x3", "k_conv_edge_wide<2, 2>",
               "k_edge_encode<44", "k_edge_encode_small<45", "k_edge_encode_wide<44, 2, false>", "k_edge_encode_wide<4, 2, true>", "k_node<0, false>",
               "k_node<0, true>", "k_node_wide<2, false>", "k_node_wide<2, true>", "k_conv_edge_f16x3_wide<2, 2>", "k_conv_edge_bf16_wide<2, 2>",
-              "k_edge_update<2>", "k_skin_check", "k_filter<true>", "k_com_partial"):
+              "k_edge_update<2>", "k_conv_edge_wide_d<2, 2, 2>", "k_edge_encode_wide_d<45, 2, 2>", "k_node_wide_d<2, 2>", "k_skin_check", "k_filter<true>", "k_com_partial"):
         assert k in names, k
     assert len(resources) >= 55
 

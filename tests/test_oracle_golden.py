@@ -10,7 +10,8 @@ from helpers import load_golden, rel_err, edge_set
 # the *_w256_* cases: the trainers' default widths 256 / 128 / 256 (LJ/train_network_lj.py:394-396) on the fixed-box models
 # the *_bn_* cases: use_layer_norm=False, the constructors' / trainers' default (BatchNorm1d between the conv layers, eval mode)
 FIXED = ["lj258_seed0", "lj258_pert_seed1", "lj64_h32", "tip3p774_seed3", "lj258_w256_seed9", "tip3p774_w256_seed10",
-         "lj258_bn_seed11", "tip3p774_bn_w256_seed12"]
+         "lj258_bn_seed11", "tip3p774_bn_w256_seed12", "lj258_d192_seed15", "tip3p774_d256_w256_seed16"]
+# the *_d192_* / *_d256_* cases: hidden_dim above 128 (128 / 192 / 128 on LJ, 256 / 256 / 256 on water)
 
 
 @pytest.mark.parametrize("name", FIXED)
