@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Step time of the LJ workload (rho* = 0.5, cutoff 3 sigma, skin reuse, BAOAB on device) over the system size:
 
-    python tools/size_scan.py [N ...] [--edge-dtype f32|bf16|f16x3] [--steps K] [--json out.json]
+    python tools/size_scan.py [N ...] [--edge-dtype f32|bf16|f16x3] [--steps K] [--json out.json] [--widths enc,hidden,emb]
 
 GPU box only; the C2 line of bench.py is the N = 10 000 point.  With --steps K it times exactly K steps after 2 warm-up
 steps (the form tools/gpu_pmc_gather.sh profiles under rocprofv3: at 10^5 - 10^6 atoms the node tables the conv-layer edge
@@ -26,12 +26,14 @@ ap.add_argument("sizes", nargs="*", type=int)
 ap.add_argument("--edge-dtype", default="f32", choices=["f32", "bf16", "f16x3"])
 ap.add_argument("--steps", type=int, default=0)
 ap.add_argument("--json", default="")
+ap.add_argument("--widths", default="128,128,128", help="encoding_size,hidden_dim,edge_embedding_dim of the LJ model")
 args = ap.parse_args()
 sizes = args.sizes or [1000, 2000, 5000, 10000, 20000, 50000, 100000, 200000]
-sd = make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2)
+enc_w, hid_w, emb_w = (int(v) for v in args.widths.split(","))
+sd = make_state_dict(ModelConfig(kind="lj", encoding_size=enc_w, hidden_dim=hid_w, edge_embedding_dim=emb_w), 0, 7.0, 2.2)
 rc = 3.0 * workloads.LJ_SIGMA
 rows = []
-print(f"edge dtype {args.edge_dtype}\n")
+print(f"edge dtype {args.edge_dtype}, widths {enc_w} / {hid_w} / {emb_w}\n")
 print("| atoms | edges | ms / step | atom-steps/s | conv kernel ms / launch | GB device memory | encoder ms | node interval ms | 32-edge tiles per wave slot (2 048) |")
 print("|---|---|---|---|---|---|---|---|---|")
 for n in sizes:
