@@ -44,6 +44,9 @@ namespace {
 
 constexpr int CONV_LDS_FLOATS = 2 * GAMD_WFRAG_FLOATS + 3 * 128;
 
+// SiLU of an input that already carries the factor log2 e (CV_SILU_PRE)
+__device__ __forceinline__ float silu_pre(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x)); }
+
 // SiLU of a whole 16-register output block on PAIRS of elements: the multiply by -log2(e), the "+ 1" and the final product
 // as packed instructions with the constants in registers (hipcc keeps them scalar because v_pk_* cannot take a literal);
 // per element the same IEEE operations as gamd_silu_hw, so the bits do not change.  add: S[src] block of phase 2, or null.
@@ -193,6 +196,8 @@ enum {
     CV_PF3 = 32768,      // weight fragments through an explicit ring of three buffers (gemm128_post_pf<3>)
     CV_NODMA = 65536,    // TIMING ONLY: no weight copies after the prologue
     CV_NOBIAS = 131072,  // TIMING ONLY: accumulators not initialised
+    CV_SILU_PRE = 262144, // TIMING ONLY (the host does not scale the weights): SiLU without the multiply by log2 e in front of its
+                         // exponential, as conv_edge_bf16.hip has it with log2 e folded into W1 / b1 / S / D / b3
 };
 #ifndef CONV_PRODUCTION
 #define CONV_PRODUCTION (CV_INGEMM | CV_CONTIG_DMA | CV_HN2 | CV_ZROW)
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             GEMM(false, buf0, RA, RB,
                                 [&](int tp, int g) {
                                     if (V & CV_NOPOST) return;
-                                    if (g < 0) silu_block16(RB[tp], nullptr, c_nl2e, c_one); else RB[tp][g] = gamd_silu_hw(RB[tp][g]);
+                                    if (g < 0) silu_block16(RB[tp], nullptr, c_nl2e, c_one); else RB[tp][g] = (V & CV_SILU_PRE) ? silu_pre(RB[tp][g]) : gamd_silu_hw(RB[tp][g]);
                                 },
                                 [&]() {
                                     if (INGEMM) {       // previous tile's pieces out of RC, then D[dst] (C-in of phase 2) into it, W2 -> buf1
@@ -419,7 +424,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             GEMM(false, buf1, RB, RC,
                                 [&](int tp, int g) {
                                     if (V & CV_NOPOST) return;
-                                    if (g < 0) silu_block16(RC[tp], &RA[tp], c_nl2e, c_one); else RC[tp][g] = gamd_silu_hw(RC[tp][g] + RA[tp][g]);
+                                    if (g < 0) silu_block16(RC[tp], &RA[tp], c_nl2e, c_one); else RC[tp][g] = (V & CV_SILU_PRE) ? silu_pre(RC[tp][g] + RA[tp][g]) : gamd_silu_hw(RC[tp][g] + RA[tp][g]);
                                 },
                                 [&]() { if (INGEMM) { FENCE(); stage(a.w3p, buf0); FENCE(); } });
             TMARK(4);
@@ -451,7 +456,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_edge(ConvEdgeArgs a) {
             GEMM(false, buf0, RC, RB,
                                 [&](int tp, int g) {
                                     if (V & CV_NOPOST) return;
-                                    if (g < 0) silu_block16(RB[tp], nullptr, c_nl2e, c_one); else RB[tp][g] = gamd_silu_hw(RB[tp][g]);
+                                    if (g < 0) silu_block16(RB[tp], nullptr, c_nl2e, c_one); else RB[tp][g] = (V & CV_SILU_PRE) ? silu_pre(RB[tp][g]) : gamd_silu_hw(RB[tp][g]);
                                 },
                                 [&]() { if (INGEMM) { FENCE(); stage(a.w4p, buf1); FENCE(); } });
             TMARK(8);
@@ -537,7 +542,7 @@ int launch_conv_edge(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
 #define CASE(X) case X: return launch_variant<X>(a, n_blocks, st)
         // (CONV_PRODUCTION = 3592; | 1 = cycle marks)
         CASE(0); CASE(1); CASE(2); CASE(4); CASE(6); CASE(8); CASE(520); CASE(1544); CASE(3592); CASE(3593); CASE(3624); CASE(3720);
-        CASE(3848); CASE(3608); CASE(3864); CASE(3912); CASE(3928); CASE(11784); CASE(19976); CASE(28168); CASE(36360); CASE(60936); CASE(126472); CASE(192008); CASE(257544);
+        CASE(3848); CASE(3608); CASE(3864); CASE(3912); CASE(3928); CASE(11784); CASE(19976); CASE(28168); CASE(36360); CASE(60936); CASE(126472); CASE(192008); CASE(257544); CASE(265736);
 #undef CASE
         default: break;
     }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random feature-matrix sweep on the GPU box (test infrastructure: it checks against the oracle, so it lives under tests/; not
-collected by pytest): 6 x 16 seeded combinations of widths (8..256 / 8..128 / 8..256),
+collected by pytest): 6 x 16 seeded combinations of widths (8..256 / 8..128 / 8..256) and 2 x 16 with hidden_dim 129..256 (fp32),
 1-5 layers, the three model flavours, LayerNorm or BatchNorm, update_edge, expand_edge on / off, bond feature, skin or exact
 neighbour mode, 1-3 boxes per handle and the three edge dtypes -- forces against the oracle (1e-5; bf16: 1e-2).  The fixed
 sample in tests/test_gpu_round4.py::test_sampled_feature_matrix_against_the_oracle is the pytest-sized version of this."""
@@ -16,7 +16,7 @@ from gamd_amd.weights import ModelConfig, make_state_dict
 from gamd_amd import workloads
 from gamd_amd.engine import GamdForce
 bad = 0; tot = 0
-for sweep in range(6):
+for sweep in range(8):
     rng = np.random.default_rng(7000 + sweep)
     for i in range(16):
         kind = ["lj", "water", "dynbox"][int(rng.integers(0, 3))]
@@ -24,6 +24,9 @@ for sweep in range(6):
         enc = int(rng.integers(8, 257)); emb = enc if upd else int(rng.integers(8, 257)); hid = int(rng.integers(8, 129))
         dt = ["f32", "f16x3", "bf16"][int(rng.integers(0, 3))]
         if upd and dt != "f32": dt = "f32"
+        if sweep >= 6:                              # hidden_dim above 128 (wide_d.hip): fp32 edge MLP, no update_edge
+            hid, dt, upd = int(rng.integers(129, 257)), "f32", False
+            if kind == "dynbox": emb = int(rng.integers(8, 257))
         cfg = ModelConfig(kind=kind, encoding_size=enc, edge_embedding_dim=emb, hidden_dim=hid, conv_layer=int(rng.integers(1, 6)),
                           use_bond=kind == "water" and rng.random() < 0.6, n_rbf=0 if (kind == "dynbox" and rng.random() < 0.4) else 40,
                           use_layer_norm=rng.random() < 0.7, update_edge=upd)

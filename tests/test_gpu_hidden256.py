@@ -106,6 +106,42 @@ def test_odd_widths_and_feature_sets_against_the_oracle(enc, hid, emb, kind, n_r
         eng.close()
 
 
+@pytest.mark.parametrize("name,widths", D256)
+def test_reference_edge_lists_appended_self_loops_and_the_model_classes(name, widths):
+    """pnet_model([pos], [edge_idx]) of the drop-in classes with the reference's own edge list, a shuffled and an empty one; the
+    other reading of add_self_loop (one zero-embedding loop appended per atom) against the oracle's restatement of it."""
+    from gamd_amd.compat import ParticleNetLightningLJ, ParticleNetLightningWater
+    g, cfg, sd = load_golden(name)
+    assert (cfg.encoding_size, cfg.hidden_dim, cfg.edge_embedding_dim) == widths
+    box, rc, n = float(g["box"]), float(g["cutoff"]), g["pos"].shape[0]
+    posw = torch.from_numpy(np.mod(g["pos"], box)).float().cuda()
+    edge_idx = torch.from_numpy(g["edge_idx"]).long().cuda()
+    water = "node_feat" in g
+    feat = torch.from_numpy(g["node_feat"]) if water else None
+    bond = g["bond"] if "bond" in g else None
+    species = (g["node_feat"].reshape(-1) != 0) if water else None
+    if water:
+        m = ParticleNetLightningWater(state_dict=sd)
+        out = m.pnet_model([posw], feat.cuda(), [edge_idx])
+    else:
+        m = ParticleNetLightningLJ(state_dict=sd)
+        out = m.pnet_model([posw], [edge_idx])
+    assert rel_err(out.cpu().numpy(), g["out_norm"]) < TOL
+    eng = m._get_engine()
+    perm = torch.randperm(edge_idx.shape[1], generator=torch.Generator().manual_seed(0)).cuda()
+    assert rel_err(eng.forward_edges(posw, edge_idx[:, perm], species=species).cpu().numpy(), g["out_norm"]) < TOL
+    none = torch.zeros((2, 0), dtype=torch.long)
+    ref0 = orc.forward(sd, posw.cpu(), none, box, feat=feat, bond=bond).numpy()
+    assert rel_err(eng.forward_edges(posw, none, species=species).cpu().numpy(), ref0) < TOL
+    mode = "append_zero_feature_loops"
+    loops = _engine(sd, n, box, rc, bond=bond, self_loop_mode=mode)
+    ref = orc.forward(sd, posw.cpu(), edge_idx.cpu(), box, feat=feat, bond=bond, self_loop_mode=mode).numpy()
+    assert rel_err(ref, g["out_norm"]) > 1e-3                                   # the two readings do differ
+    assert rel_err(loops.forward(posw, species=species).cpu().numpy(), ref) < TOL
+    assert rel_err(loops.forward_edges(posw, edge_idx[:, perm], species=species).cpu().numpy(), ref) < TOL
+    loops.close()
+
+
 def test_what_is_not_built_is_refused_loudly():
     cfg = ModelConfig(kind="lj", encoding_size=128, hidden_dim=256, edge_embedding_dim=128, conv_layer=2)
     sd = make_state_dict(cfg, 1, 5.0, 1.5)

@@ -416,9 +416,13 @@ def test_error_conventions():
 def test_error_conventions_for_widths_and_constraints():
     """Unsupported widths and inconsistent integrator parameters are refused with a message, not run."""
     from gamd_amd._lib import GamdError
+    # (hidden_dim up to 256 since round 6, fp32 edge MLP only: tests/test_gpu_hidden256.py)
     with pytest.raises(ValueError, match="hidden_dim"):
-        cfg = ModelConfig(kind="water", hidden_dim=256, encoding_size=256, edge_embedding_dim=256)
+        cfg = ModelConfig(kind="water", hidden_dim=257, encoding_size=256, edge_embedding_dim=256, conv_layer=1)
         _engine(make_state_dict(cfg, 1), 30, 12.0, 3.0, cfg=cfg)
+    with pytest.raises(GamdError, match="hidden_dim above 128"):
+        cfg = ModelConfig(kind="water", hidden_dim=256, encoding_size=256, edge_embedding_dim=256, conv_layer=1)
+        _engine(make_state_dict(cfg, 1), 30, 12.0, 3.0, cfg=cfg, edge_dtype="f16x3")
     wide = ModelConfig(kind="water", encoding_size=256, edge_embedding_dim=256, conv_layer=2)
     # (reduced-precision edge MLPs exist for every width since round 4; appended self loops are an fp32-only switch)
     with pytest.raises((GamdError, ValueError)):
