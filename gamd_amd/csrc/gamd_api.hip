@@ -1168,7 +1168,6 @@ int32_t gamd_finalize_weights(gamd_handle* h) {
             return fail(-22, "update_edge_emb needs encoding_size == edge_embedding_dim (got %d, %d)", (int)Ht, (int)Et);
         if (h->cfg.edge_dtype != GAMD_EDGE_F32 || h->cfg.self_loop_mode)
             return fail(-22, "update_edge_emb is built for the fp32 edge MLP without appended self loops");
-        if (DT > 1) return fail(-22, "update_edge_emb is built for hidden_dim up to 128 (got %d)", (int)Dt);
         h->wide_enc = h->wide_conv = true;
     }
     if (update_edge != h->update_edge) {

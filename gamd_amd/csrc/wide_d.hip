@@ -348,6 +348,13 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_wide_d(ConvEdgeArgs a) {
                     }
                     gemm128<true>(W, lane, T4[db], U);
                     if (db == DT - 1) {
+                        if (a.emb_out) {                       // update_edge_emb: e_emb rows for launch_edge_update (edge x0 + r)
+                            float* er = a.emb_out + (size_t)x0 * H + 128 * ob + slot;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                                for (int tp = 0; tp < 4; ++tp) er[(size_t)r * H + 32 * tp] = U[tp][r];
+                        }
                         const unsigned keep_bits = ~(mask << 1);
 #pragma unroll
                         for (int tp = 0; tp < 4; ++tp)
@@ -649,7 +656,7 @@ int launch_edge_encode_wide_d(const EncArgs& a, int eht, int dt, int n_blocks, h
 }
 
 int launch_conv_edge_wide_d(const ConvEdgeArgs& a, int eht, int ht, int dt, int n_blocks, hipStream_t st) {
-    if (dt != 2 || a.emb_out) return -22;
+    if (dt != 2) return -22;
     if (eht == 1 && ht == 1) return conv_launch_d<1, 1, 2>(a, n_blocks, st);
     if (eht == 1 && ht == 2) return conv_launch_d<1, 2, 2>(a, n_blocks, st);
     if (eht == 2 && ht == 1) return conv_launch_d<2, 1, 2>(a, n_blocks, st);

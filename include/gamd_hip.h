@@ -43,7 +43,7 @@ enum { GAMD_NBR_JAXMD = 0, GAMD_NBR_TORCH = 1 };        /* dr^2 < rc^2 + self pa
  * LJ/train_network_lj.py:68-88,108-112; water/train_network_tip3p.py:75-97;
  * graph_utils.py:12-27.  Widths: whatever build_model passes (nn_module.py:561-601, --encoding_size / --hidden_dim /
  * --edge_embedding_dim, LJ/train_network_lj.py:394-396): encoding_size, edge_embedding_dim and hidden_dim in [1, 256]
- * (hidden_dim above 128: edge_dtype f32 only, no update_edge models).  The kernels work in 128-wide blocks; other widths are zero-padded when the weights are packed (padded features
+ * (hidden_dim above 128: edge_dtype f32 only).  The kernels work in 128-wide blocks; other widths are zero-padded when the weights are packed (padded features
  * are exact zeros through every layer, the two LayerNorms divide by the true width).  128 / 128 / 128 (every shipped LJ / TIP
  * config, LJ/test_script/test_langevin.py:63-73) runs the specialised kernels, anything wider than 128 the generic-width
  * ones (the DFT-water config 256 / 128 / 256, water/test_script/test_nosehoover_hb.py:69-81; the trainers' defaults).

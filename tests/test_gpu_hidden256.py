@@ -142,6 +142,26 @@ def test_reference_edge_lists_appended_self_loops_and_the_model_classes(name, wi
     loops.close()
 
 
+@pytest.mark.parametrize("width,hid,n_rbf", [(160, 200, 40), (256, 256, 0)])
+def test_update_edge_models_with_a_wide_hidden_layer(width, hid, n_rbf):
+    """WaterMDDynamicBoxNet(update_edge=True) (nn_module.py:91-92, :140-146): the layers after the first read the previous
+    layer's LayerNorm(e_emb); with hidden_dim above 128 the conv kernel of wide_d.hip writes those rows."""
+    cfg = ModelConfig(kind="dynbox", encoding_size=width, hidden_dim=hid, edge_embedding_dim=width, conv_layer=3, n_rbf=n_rbf, update_edge=True)
+    sd = make_state_dict(cfg, 77, 2.9, 1.1)
+    assert "graph_conv.conv.0.edge_layer_norm.weight" in sd
+    pos, box, species, _ = workloads.water_box(110, seed=4)
+    feat, rc, n = torch.from_numpy(species.astype(np.float32)).view(-1, 1), 4.2, pos.shape[0]
+    p = torch.remainder(torch.from_numpy(pos).float(), float(box))
+    ref = orc.forward_dynamic_box(sd, p, feat, np.full(3, box, dtype=np.float32), rc).numpy()
+    for kw in (dict(), dict(neighbor_skin=rc / 6.0), dict(n_boxes=2)):
+        eng = _engine(sd, n, box, rc, nbr_flavour="torch", **kw)
+        nb = kw.get("n_boxes", 1)
+        out = eng.forward(torch.cat([p] * nb), species=np.tile(species, nb)).cpu().numpy()
+        for b in range(nb):
+            assert rel_err(out[b * n:(b + 1) * n], ref) < TOL, (kw, b)
+        eng.close()
+
+
 def test_what_is_not_built_is_refused_loudly():
     cfg = ModelConfig(kind="lj", encoding_size=128, hidden_dim=256, edge_embedding_dim=128, conv_layer=2)
     sd = make_state_dict(cfg, 1, 5.0, 1.5)
