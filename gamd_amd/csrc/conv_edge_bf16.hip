@@ -48,6 +48,9 @@ __device__ __forceinline__ float fma_h_f_f(unsigned a, float b, float c, bool HI
 #ifndef BF16_RING
 #define BF16_RING 8
 #endif
+#ifndef BF16_FRING
+#define BF16_FRING 4         // weight-fragment ring depth of the fused GEMM + SiLU form (7 vector instructions between two MFMAs)
+#endif
 #ifndef BF16_STAGGER
 #define BF16_STAGGER 0
 #endif
@@ -134,6 +137,64 @@ __device__ __forceinline__ void silu_pack_bf16(const f32x16 (&X)[4], bf16x8 (&P)
             P[t][u] = __builtin_bit_cast(bf16x8, w);
         }
     if (!(ABL & 2048)) __builtin_amdgcn_s_setprio(0);
+}
+
+// SiLU of one pair of accumulator elements -> one dword of bf16 operands (the element-wise body of silu_pack_bf16)
+__device__ __forceinline__ unsigned silu_pair_bf16(float x0, float x1, const SiluK& k) {
+    const gamd_f32x2 x = {x0, x1};
+    const gamd_f32x2 e = {__builtin_amdgcn_exp2f(-x[0]), __builtin_amdgcn_exp2f(-x[1])};
+    const gamd_f32x2 d = e + k.one;
+    const gamd_f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const gamd_f32x2 y = x * r;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(y, gamd_bf16x2));
+}
+
+// ABL 32768 (variant): the SiLU of the PREVIOUS GEMM's output fused into this GEMM, inside the wave.  The GEMM walks K in four
+// stages of 8 MFMAs (K block t = the previous GEMM's output block t); only the first quarter of the SiLU block has to be done
+// before the first MFMA, quarter t + 1 runs between the MFMAs of stage t (one pair of elements = 7 vector instructions per MFMA of
+// 32 matrix cycles).  Same operations on the same values in the same per-accumulator order: bit-identical results.
+template <bool F2, int D, int PRIO>
+__device__ __forceinline__ void gemm128_bf16_fused(const bf16x8* W, int lane, const f32x16 (&X)[4], bf16x8 (&P)[4][2], f32x16 (&acc)[4],
+                                                   const SiluK& k) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+    {
+        gamd_u32x4 w0, w1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w0[q] = silu_pair_bf16(X[0][2 * q], X[0][2 * q + 1], k); w1[q] = silu_pair_bf16(X[0][8 + 2 * q], X[0][8 + 2 * q + 1], k); }
+        P[0][0] = __builtin_bit_cast(bf16x8, w0); P[0][1] = __builtin_bit_cast(bf16x8, w1);
+    }
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 w[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) w[i] = W[((((i & 3) * 4 + (i >> 3)) * 2) + ((i >> 2) & 1)) * 64 + lane];
+    gamd_u32x4 nw[2];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int tp = i & 3, t = i >> 3, u = (i >> 2) & 1;
+        const bf16x8 cur = w[i % D];
+        acc[tp] = F2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(P[t][u], cur, acc[tp], 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur, P[t][u], acc[tp], 0, 0, 0);
+        if (i + D < 32) {
+            const int j = i + D;
+            w[i % D] = W[((((j & 3) * 4 + (j >> 3)) * 2) + ((j >> 2) & 1)) * 64 + lane];
+        }
+        if (t < 3) {                                       // pair (i & 7) of quarter t + 1
+            const int pr = i & 7, uu = pr >> 2, q = pr & 3;
+            nw[uu][q] = silu_pair_bf16(X[t + 1][8 * uu + 2 * q], X[t + 1][8 * uu + 2 * q + 1], k);
+            if (pr == 7) { P[t + 1][0] = __builtin_bit_cast(bf16x8, nw[0]); P[t + 1][1] = __builtin_bit_cast(bf16x8, nw[1]); }
+        }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, D, 0);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i + D < 32) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (i < 24) { __builtin_amdgcn_sched_group_barrier(0x400, 4, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+    }
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int ABL>
@@ -246,7 +307,9 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
         load_row_tab16(a.S, ((unsigned)((ABL & 32) ? a.zero_row : src) << 8) + half16, S16);
         load_row_tab16(a.D, ((unsigned)((ABL & 32) ? a.zero_row : dst) << 8) + half16, D16);
         BT(2);                                         // S / D gather issue
-        silu_pack_bf16<ABL>(RC, P, sk);
+        constexpr bool FUSE = (ABL & 32768) != 0;    // SiLU blocks fused into the GEMM that consumes them (gemm128_bf16_fused)
+        constexpr int FPRIO = (ABL & 131072) ? 2 : (ABL & 2048) ? 0 : 1;      // 131072: the whole fused GEMM at priority 1
+        if (!FUSE) silu_pack_bf16<ABL>(RC, P, sk);
         BT(3);                                         // SiLU 1 + pack
         if (BF16_PREFETCH_E) fetch_e(tile_n, Pn);     // next tile's e: three phases to land
         // phase 2: T3 = SiLU(W2 T1 + S[src] + D[dst]); group c = 2 t + k holds X[t][8 k .. 8 k + 7], two fp16 per dword
@@ -260,9 +323,9 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
             }
         if (ABL & 16384) { asm volatile("" : "+v"(RB[0]), "+v"(RB[3])); __builtin_amdgcn_s_setprio(0); }
         BT(4);                                         // S + D (waits for both gathers)
-        gemm_abl<ABL, false>(W2, lane, P, RB);
+        if (FUSE) gemm128_bf16_fused<false, BF16_FRING, FPRIO>(W2, lane, RC, P, RB, sk); else gemm_abl<ABL, false>(W2, lane, P, RB);
         BT(5);                                         // GEMM 2
-        silu_pack_bf16<ABL>(RB, P, sk);
+        if (!FUSE) silu_pack_bf16<ABL>(RB, P, sk);
         BT(6);                                         // SiLU 2 + pack
         // hn[src] rows for phase 4 (row layout: lane = feature, reg = edge)
         const int x0 = tile * GAMD_TILE + 16 * half;
@@ -289,9 +352,9 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
         BT(7);                                         // hn gather issue (bpermutes + 16 loads)
         // phase 3: T4 = SiLU(W3 T3 + b3)
         load_bias_chain(vb3, half, RC);
-        gemm_abl<ABL, false>(W3, lane, P, RC);
+        if (FUSE) gemm128_bf16_fused<false, BF16_FRING, FPRIO>(W3, lane, RB, P, RC, sk); else gemm_abl<ABL, false>(W3, lane, P, RC);
         BT(8);                                         // GEMM 3
-        silu_pack_bf16<ABL>(RC, P, sk);
+        if (!FUSE) silu_pack_bf16<ABL>(RC, P, sk);
         BT(9);                                         // SiLU 3 + pack
         // phase 4: e_emb = T4 W4^T + b4 (F2), message, segment sum (fp32)
         const unsigned mask = a.chunk_mask[tile * 2 + half];
@@ -303,7 +366,7 @@ __global__ void __launch_bounds__(64 * BF16_NW, BF16_NW == 8 ? 2 : 1) k_conv_edg
             for (int r = 0; r < 16; ++r) RB[tp][r] = b;
         }
         BT(10);                                        // chunk metadata loads + b4 init
-        gemm_abl<ABL, true>(W4, lane, P, RB);
+        if (FUSE) gemm128_bf16_fused<true, BF16_FRING, FPRIO>(W4, lane, RC, P, RB, sk); else gemm_abl<ABL, true>(W4, lane, P, RB);
         BT(11);                                        // GEMM 4
         if (!BF16_PREFETCH_E && BF16_FETCH_AFTER_GEMM4) fetch_e(tile_n, P);      // P is free: the next tile's e rides under the message / store block
         const unsigned keep_bits = ~(mask << 1);
@@ -410,6 +473,9 @@ int launch_conv_edge_bf16(const ConvEdgeArgs& a, int n_blocks, hipStream_t st) {
         case 16384: return launch_bf16_abl<16384>(a, n_blocks, st);
         case 65536: return launch_bf16_abl<65536>(a, n_blocks, st);
         case 81920: return launch_bf16_abl<81920>(a, n_blocks, st);
+        case 32768: return launch_bf16_abl<32768>(a, n_blocks, st);      // SiLU fused into the consuming GEMM, first quarter at priority
+        case 34816: return launch_bf16_abl<34816>(a, n_blocks, st);      // ... no priority anywhere
+        case 163840: return launch_bf16_abl<163840>(a, n_blocks, st);    // ... the whole fused GEMM at priority
         default: break;
     }
 #endif

@@ -13,7 +13,8 @@ NAMES = {0: "production", 1: "SiLU -> x/2", 2: "gathers from one hot row", 4: "n
          257: "256 + SiLU -> x/2", 263: "256+1+2+4", 9: "no fill + SiLU -> x/2", 384: "GEMMs without MFMAs and LDS reads",
          391: "384+1+2+4", 512: "e from one hot tile", 775: "263 + 512", 903: "everything off", 1024: "prio 1 around the GEMMs",
          2048: "WITHOUT prio in the SiLU blocks", 4096: "static prio for waves 4-7", 8192: "prio everywhere but the GEMMs",
-         16384: "S + D block at prio too", 65536: "message block at prio too", 81920: "both", 32: "S / D gathers from one hot row", 3: "1+2", 7: "1+2+4", 23: "1+2+4+16", 31: "all"}
+         16384: "S + D block at prio too", 65536: "message block at prio too", 81920: "both", 32768: "SiLU fused into the consuming GEMM", 34816: "fused, no priority", 163840: "fused, whole GEMM at prio",
+         32: "S / D gathers from one hot row", 3: "1+2", 7: "1+2+4", 23: "1+2+4+16", 31: "all"}
 WL = os.environ.get("GAMD_VARIANT_WORKLOAD", "c5").split(",")          # e.g. "c5" or "c2,--edge-dtype,bf16"
 for v in [int(x) for x in sys.argv[1:]] or [0]:
     env = dict(os.environ, GAMD_LIB=os.path.join(ROOT, "gamd_amd", "libgamd_hip_prof.so"), GAMD_BF16_VARIANT=str(v))
