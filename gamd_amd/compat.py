@@ -17,6 +17,7 @@ those constants and the reference's constructor signature, so a driver runs with
 from __future__ import annotations
 
 import functools
+import os
 from types import SimpleNamespace
 from typing import Optional
 
@@ -289,7 +290,8 @@ class _ForceFieldBase:
         # enforce periodic boundary in f64 on the host, then f32 (train_network_lj.py:141-142)
         posw = np.mod(np.asarray(pos, dtype=np.float64), np.asarray(self.box_size, dtype=np.float64))
         species = None if feat is None else _node_feature(feat)
-        x = torch.from_numpy(posw).float()
+        if verbose or os.environ.get("GAMD_PREDICT_LEGACY"):
+            x = torch.from_numpy(posw).float()
         if verbose:
             # the reference's two time.time() buckets (train_network_lj.py:134-151): neighbour search vs network forward.
             # Here both are stages of one enqueued call, so they are measured with HIP events on the stream
@@ -300,9 +302,12 @@ class _ForceFieldBase:
             print('=============================================')
             print(f'Nbr search used time: {nbr}')
             print(f'Force eval used time: {force}')
-        else:
+        elif os.environ.get("GAMD_PREDICT_LEGACY"):      # (A/B switch of tools/predict_forces_latency.py: the three-sync form)
             pred = eng.forward(x, species=species, inplace=True).detach().cpu().numpy()   # device -> host sync (:153)
-        return self.denormalize(pred, self.training_var, self.training_mean)   # f64 result (:155)
+        else:
+            # pinned staging both ways, one stream synchronisation (:141-153 in one enqueue); float64 -> float32 as .float() rounds
+            pred = eng.forward_host(posw, species=species)
+        return self.denormalize(pred, self.training_var, self.training_mean)   # f64 result (:155), a fresh array
 
 
 class ParticleNetLightningLJ(_ForceFieldBase):
@@ -353,7 +358,5 @@ class ParticleNetLightningDFT(_ForceFieldBase):
         eng = self._get_engine()
         box = np.asarray(box_size, dtype=np.float64).reshape(-1)
         posw = np.mod(np.asarray(pos, dtype=np.float64), box)                 # train_network_real_large.py:150
-        pred = eng.forward(torch.from_numpy(posw).float(), box=box.astype(np.float32), species=_node_feature(feat),
-                           inplace=True)
-        pred = pred.detach().cpu().numpy()
+        pred = eng.forward_host(posw, box=box.astype(np.float32), species=_node_feature(feat))   # one synchronisation per call
         return self.denormalize(pred, self.training_var, self.training_mean)  # :160

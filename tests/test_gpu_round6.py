@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden
+from helpers import load_golden, rel_err
 from gamd_amd import workloads
 from gamd_amd.engine import GamdForce
 from gamd_amd.weights import ModelConfig, make_state_dict, SHIPPED_SCALERS
@@ -174,3 +174,42 @@ def test_layer0_tables_reused_inside_a_run_give_the_bits_of_a_run_in_single_step
     assert one[3] >= 3, one[3]                                        # the run really crossed candidate rebuilds
     for a, b in zip(one[:3], many[:3]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_host_buffer_boundary_with_one_synchronisation_gives_the_same_bits():
+    """GamdForce.forward_host (pinned staging both ways, one stream synchronisation: what predict_forces runs on) against
+    forward(): float64 and float32 host positions, a batch, the regrow-and-replay path, the dynamic-box model with a box per
+    call, and predict_forces itself against the three-synchronisation form it replaced."""
+    import os
+    from gamd_amd.compat import ParticleNetLightningLJ
+    g, cfg, sd = load_golden("lj258_seed0")
+    box, rc, n = float(g["box"]), float(g["cutoff"]), 258
+    posw = np.mod(g["pos"], box)
+    eng = GamdForce(sd, n, box, rc, scaler=(g["scaler_mean"], g["scaler_var"]), neighbor_skin=rc / 6.0)
+    ref = eng.forward(torch.from_numpy(posw).float()).cpu().numpy()
+    assert rel_err(ref, g["out_norm"]) < 1e-5
+    for p in (posw.astype(np.float64), posw.astype(np.float32)):
+        assert np.array_equal(eng.forward_host(p), ref)
+    den = eng.forward(torch.from_numpy(posw).float(), denormalize=True).cpu().numpy()
+    assert np.array_equal(eng.forward_host(posw, denormalize=True), den)
+    with pytest.raises(ValueError, match="pos must be"):
+        eng.forward_host(posw[:-1])
+    eng.close()
+    # a batch; a capacity far too small: detected on the device, regrown, replayed inside the one call
+    batch = GamdForce(sd, n, box, rc, n_boxes=2, edge_capacity=64)
+    two = np.concatenate([posw, np.mod(posw + 0.3, box)])
+    out = batch.forward_host(two).copy()
+    assert batch.last_status == 1
+    assert np.array_equal(out[:n], ref) and np.array_equal(batch.forward_host(two.reshape(2, n, 3)), out) and batch.last_status == 0
+    batch.close()
+    # predict_forces: same float64 bits as the form with three synchronisations
+    m = ParticleNetLightningLJ(state_dict=sd)
+    a = m.predict_forces(g["pos"])
+    os.environ["GAMD_PREDICT_LEGACY"] = "1"
+    try:
+        b = m.predict_forces(g["pos"])
+    finally:
+        del os.environ["GAMD_PREDICT_LEGACY"]
+    assert a.dtype == np.float64 and np.array_equal(a, b) and a is not b
+    a2 = m.predict_forces(g["pos"] + 0.01)
+    assert not np.array_equal(a, a2) and np.array_equal(a, b)             # the first result does not alias the staging buffer

@@ -12,17 +12,29 @@ sys.path.insert(0, ROOT)
 from gamd_amd import compat, workloads                                   # noqa: E402
 from gamd_amd.weights import ModelConfig, make_state_dict              # noqa: E402
 
+import hashlib                                                           # noqa: E402
+
 for n, rc in ((258, 7.5), (10000, 10.2)):
     pos, box = workloads.lj_box(n, seed=3)
     m = compat.ParticleNetLightningLJ(None, make_state_dict(ModelConfig(kind="lj"), 0, 7.0, 2.2), num_atoms=n,
                                       box_size=float(box), cutoff=rc)
     m.cuda(); m.eval()
     p = pos.astype(np.float64)
-    for _ in range(20):
-        f = m.predict_forces(p)
-    reps = 300 if n < 1000 else 100
-    t0 = time.perf_counter()
-    for k in range(reps):
-        f = m.predict_forces(p + 1e-4 * (k & 1))
-    dt = (time.perf_counter() - t0) / reps
-    print(f"{n:6d} atoms: predict_forces {dt * 1e3:.3f} ms per call ({f.dtype}, {f.shape})")
+    # the pinned one-synchronisation form (default) against the round-5 form (pageable copy in, kernels + sync, copy out + sync):
+    # alternating blocks on the same handle, same positions -> same bits
+    for rnd in range(2):
+        for legacy in (False, True):
+            if legacy:
+                os.environ["GAMD_PREDICT_LEGACY"] = "1"
+            else:
+                os.environ.pop("GAMD_PREDICT_LEGACY", None)
+            for _ in range(20):
+                f = m.predict_forces(p)
+            reps = 300 if n < 1000 else 100
+            t0 = time.perf_counter()
+            for k in range(reps):
+                f = m.predict_forces(p + 1e-4 * (k & 1))
+            dt = (time.perf_counter() - t0) / reps
+            sha = hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest()[:12]
+            print(f"{n:6d} atoms: predict_forces {dt * 1e3:.3f} ms per call ({'three syncs' if legacy else 'pinned, one sync'}; {f.dtype}, {f.shape}, sha {sha})")
+    os.environ.pop("GAMD_PREDICT_LEGACY", None)
