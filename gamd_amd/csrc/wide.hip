@@ -17,6 +17,7 @@
 #include "gamd_bf16.h"
 #include "gamd_f16x3.h"
 #include "gamd_internal.h"
+#include "gamd_wide.h"
 
 namespace {
 
@@ -451,21 +452,6 @@ __global__ void __launch_bounds__(256) k_edge_update(EdgeUpdateArgs a) {
 // ================================================================================================
 // node side (see node.hip) for H = 128*HT: 32-atom tile over 4 waves by output quarter of each block
 // ================================================================================================
-struct WQ { f32x4 w[16]; };
-
-__device__ __forceinline__ void wq_load(const float* __restrict__ Wp, int quarter, int lane, WQ& o) {
-    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 16 * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o.w[i] = W[i * 64];
-}
-__device__ __forceinline__ void wq_gemm(const WQ& wq, const f32x16 (&X)[4], f32x16& acc) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
-}
 // split-fp16 form (the reduced-precision edge mode of the generic widths, wide_lp.hip): the block is a (hi | lo) fp16 image
 // (pack128_f16x3), a quarter = 8 + 8 fragments of 16 bytes per lane; 24 MFMAs of 32 cycles per block GEMM instead of 64 of 64.
 // The activations are split per K step on the fly (gamd_split8): 160 VALU per block GEMM, nothing next to the MFMAs saved.

@@ -10,6 +10,7 @@
 // SIMD (4-wave workgroups, the whole register file per wave: a tile's D-wide activations are 128 registers each).
 #include "gamd_common.h"
 #include "gamd_internal.h"
+#include "gamd_wide.h"
 
 namespace {
 
@@ -390,21 +391,6 @@ __global__ void __launch_bounds__(256, 1) k_conv_edge_wide_d(ConvEdgeArgs a) {
 // node side (wide.hip's k_node_wide) with D = 128 DT: S, D, P rows and the decoder's inner layer are DT blocks
 //   step order: phi_edge (db, kb) | phi (ob, db) | then S (db, kb) | D (db, kb) | P (db, kb), or the decoder's (db, kb)
 // ================================================================================================
-struct WQ { f32x4 w[16]; };
-
-__device__ __forceinline__ void wq_load(const float* __restrict__ Wp, int quarter, int lane, WQ& o) {
-    const f32x4* W = reinterpret_cast<const f32x4*>(Wp) + (size_t)quarter * 16 * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o.w[i] = W[i * 64];
-}
-__device__ __forceinline__ void wq_gemm(const WQ& wq, const f32x16 (&X)[4], f32x16& acc) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = mfma32(wq.w[t * 4 + q][j], X[t][q * 4 + j], acc);
-}
 
 template <int HT, int DT>
 __global__ void __launch_bounds__(256) k_node_wide_d(NodeArgs a) {
