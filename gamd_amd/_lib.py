@@ -55,6 +55,7 @@ SYMBOLS = {
     "gamd_set_node_features": (_i32, [_vp, _vp]),
     "gamd_get_device_flags": (_i32, [_vp, C.POINTER(_i32)]),
     "gamd_sync_status": (_i32, [_vp, _vp]),
+    "gamd_forces_host": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _i32, _vp]),
     "gamd_forces": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _vp]),
     "gamd_forces_edges": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp, _i64, _vp, _vp, _vp]),
     "gamd_build_neighbors": (_i32, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp]),

@@ -173,6 +173,10 @@ struct gamd_handle {
     long long skin_calls = 0;       // skin-mode force evaluations so far (rebuild-frequency estimate)
     int* cur_counters = nullptr;    // the counter block of the call being enqueued
     int* counters_host = nullptr;   // pinned
+    // gamd_forces_host: pinned staging buffers ([n][3] floats each) and the device copy of the positions, allocated on first use
+    float* host_in = nullptr;
+    float* host_out = nullptr;
+    DevBuf pos_in;
     int* sticky_host = nullptr;     // pinned + mapped: overflow flags and rebuild count, written by kernels directly
     int* sticky_dev = nullptr;
     hipStream_t init_stream = nullptr;   // private non-blocking stream: initialising memsets / uploads of the entry points without a stream argument
@@ -1063,6 +1067,9 @@ int32_t gamd_destroy(gamd_handle* h) {
                       &h->chunk_mask, &h->e_frag, &h->e_emb, &h->e_frag2, &h->partial, &h->feat_dbg, &h->counters, &h->tdbg, &h->tmp_eid, &h->ke_partial, &h->com_partial,
                       &h->ref_pos, &h->cand_deg, &h->cand_ptr, &h->cand_col};
     for (DevBuf* b : bufs) b->release();
+    h->pos_in.release();
+    if (h->host_in) (void)hipHostFree(h->host_in);
+    if (h->host_out) (void)hipHostFree(h->host_out);
     if (h->counters_host) (void)hipHostFree(h->counters_host);
     if (h->sticky_host) (void)hipHostFree(h->sticky_host);
     for (hipEvent_t e : h->tev) (void)hipEventDestroy(e);
@@ -1554,6 +1561,40 @@ int32_t gamd_forces(gamd_handle* h, const float* pos_dev, const uint8_t* species
         if (r) return r;
         r = gamd_sync_status(h, stream);
         if (r == 0) return attempt ? 1 : 0;
+        if (r != -34) return r;
+    }
+    return fail(-34, "neighbour buffers still overflow after regrowing");
+}
+
+// The reference's host-array boundary (predict_forces, LJ/train_network_lj.py:133-157) in one call with one synchronisation
+int32_t gamd_forces_host(gamd_handle* h, const float* pos_host, const uint8_t* species_dev, const float* box, float* out_host,
+                         int32_t denormalize, void* stream) {
+    int r;
+    if ((r = check_ready(h))) return r;
+    if (!pos_host || !out_host || !box) return fail(-22, "null argument");
+    DeviceGuard guard(h->dev);
+    const size_t bytes = sizeof(float) * 3 * (size_t)h->n;
+    if (!h->host_in) {
+        InitStream init((hipStream_t)stream);
+        if (hipHostMalloc((void**)&h->host_in, bytes) != hipSuccess) { h->host_in = nullptr; return fail(-12, "pinned allocation failed"); }
+        if (hipHostMalloc((void**)&h->host_out, bytes) != hipSuccess) {
+            (void)hipHostFree(h->host_in);
+            h->host_in = h->host_out = nullptr;
+            return fail(-12, "pinned allocation failed");
+        }
+        if (h->pos_in.ensure(bytes, false)) return fail(-12, "device allocation failed");
+    }
+    std::memcpy(h->host_in, pos_host, bytes);
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        HIP_TRY(hipMemcpyAsync(h->pos_in.p, h->host_in, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+        if ((r = gamd_forces_async(h, h->pos_in.as<float>(), species_dev, box, nullptr, denormalize ? h->f_den.as<float>() : nullptr, stream)))
+            return r;
+        HIP_TRY(hipMemcpyAsync(h->host_out, denormalize ? h->f_den.p : h->f_norm.p, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        r = gamd_sync_status(h, stream);                    // the one synchronisation; -34: regrown, replay
+        if (r == 0) {
+            std::memcpy(out_host, h->host_out, bytes);
+            return attempt ? 1 : 0;
+        }
         if (r != -34) return r;
     }
     return fail(-34, "neighbour buffers still overflow after regrowing");

@@ -240,39 +240,25 @@ class GamdForce:
     __call__ = forward
 
     def forward_host(self, pos: np.ndarray, box=None, species=None, denormalize: bool = False) -> np.ndarray:
-        """The reference's host-buffer boundary (``predict_forces``: numpy positions in, numpy forces out,
-        LJ/train_network_lj.py:133-157) with ONE stream synchronisation per call: positions go through a pinned staging
-        buffer (float64 -> float32 on the way in, the rounding ``torch.from_numpy(pos).float()`` does), the copy to the
-        device, the kernels and the copy of the result back into a pinned buffer are all enqueued on the caller's stream,
-        and ``gamd_sync_status`` waits once (and replays the call if a neighbour buffer had to be regrown).
-        Returns a float32 [N,3] view of the engine's pinned output buffer: valid until the next call."""
-        if getattr(self, "_pin_in", None) is None:
-            self._pin_in = torch.empty((self.n_total, 3), dtype=torch.float32, pin_memory=True)
-            self._pin_out = torch.empty((self.n_total, 3), dtype=torch.float32, pin_memory=True)
-            self._dev_in = torch.empty((self.n_total, 3), dtype=torch.float32, device=self.device)
-            self._pin_in_np, self._pin_out_np = self._pin_in.numpy(), self._pin_out.numpy()
+        """The reference's host-array boundary (``predict_forces``: numpy positions in, numpy forces out,
+        LJ/train_network_lj.py:133-157) through ``gamd_forces_host``: float64 -> float32 as ``torch.from_numpy(pos).float()``
+        rounds, the library's pinned staging buffers both ways, copy in / kernels / copy out enqueued on the caller's stream
+        and ONE synchronisation (the library replays the call if a neighbour buffer had to be regrown: ``last_status`` 1).
+        Returns a float32 [N,3] array owned by the engine: valid until the next call."""
         pos = np.asarray(pos)
         if pos.shape == (self.n_boxes, self.n, 3):
             pos = pos.reshape(self.n_total, 3)
         if pos.shape != (self.n_total, 3):
             raise ValueError(f"pos must be [{self.n_total}, 3], got {tuple(pos.shape)}")
-        np.copyto(self._pin_in_np, pos, casting="unsafe")
+        p32 = np.ascontiguousarray(pos, dtype=np.float32)
+        if getattr(self, "_host_out", None) is None:
+            self._host_out = np.empty((self.n_total, 3), dtype=np.float32)
         s = self._dev_species(species)
-        box_arg = self._box_arg(box)
-        out = self._out_den if denormalize else self._out
-        st, attempts = -34, 0
-        for attempts in range(4):
-            self._dev_in.copy_(self._pin_in, non_blocking=True)
-            check(self._lib.gamd_forces_async(self._h, C.c_void_p(self._dev_in.data_ptr()),
-                                              C.c_void_p(s.data_ptr()) if s is not None else None, box_arg,
-                                              C.c_void_p(self._out.data_ptr()), C.c_void_p(self._out_den.data_ptr()),
-                                              self._stream()), "gamd_forces_async")
-            self._pin_out.copy_(out, non_blocking=True)
-            st = self._lib.gamd_sync_status(self._h, self._stream())
-            if st != -34:                          # -34: a neighbour buffer overflowed and was regrown -> replay
-                break
-        self.last_status = max(check(st, "gamd_sync_status"), 1 if attempts else 0)      # 1: buffers were regrown on the way
-        return self._pin_out_np
+        st = self._lib.gamd_forces_host(self._h, p32.ctypes.data_as(C.c_void_p), C.c_void_p(s.data_ptr()) if s is not None else None,
+                                        self._box_arg(box), self._host_out.ctypes.data_as(C.c_void_p), 1 if denormalize else 0,
+                                        self._stream())
+        self.last_status = check(st, "gamd_forces_host")
+        return self._host_out
 
     def forward_edges(self, pos: ArrayLike, edge_idx, box=None, species=None, denormalize: bool = False,
                       inplace: bool = False) -> torch.Tensor:

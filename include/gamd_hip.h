@@ -170,6 +170,16 @@ int32_t gamd_get_device_flags(gamd_handle* h, int32_t flags[4]);
 int32_t gamd_forces(gamd_handle* h, const float* pos_dev, const uint8_t* species_dev, const float* box,
                     float* out_norm_dev, float* out_denorm_dev, void* stream);
 
+/* The reference's host-array boundary in one call: predict_forces(pos) takes and returns HOST arrays
+ * (LJ/train_network_lj.py:133-157, water/train_network_tip3p.py:142-159).  pos_host: float32 [n][3], wrapped and rounded as
+ * :141-142 do (np.mod in float64, then float32), any host memory; out_host: float32 [n][3] — the normalised network output
+ * (denormalize = 0: what pnet_model returns at :152; the caller denormalises in float64 as :155) or out * sqrt(var) + mean in
+ * fp32 (denormalize = 1).  The positions go through a pinned staging buffer of the handle; the copy in, the kernels and the
+ * copy out are enqueued on `stream`, the call synchronises ONCE and replays itself after a regrow.  species_dev / box as in
+ * gamd_forces.  Returns 0, or 1 if a neighbour buffer was regrown.  PCIe-inclusive: never what bench.py reports as `value`. */
+int32_t gamd_forces_host(gamd_handle* h, const float* pos_host, const uint8_t* species_dev, const float* box, float* out_host,
+                         int32_t denormalize, void* stream);
+
 /* Same network forward on a CALLER-SUPPLIED directed edge list instead of the built-in radius search:
  * centre_dev[e] / neigh_dev[e] (int32, device) = rows 0 / 1 of the reference's edge_idx tensor; messages flow
  * neigh -> centre.  Replaces the model-level call pnet_model([pos], [edge_idx]) / ([pos], feat, [edge_idx])

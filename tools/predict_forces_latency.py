@@ -28,13 +28,17 @@ for n, rc in ((258, 7.5), (10000, 10.2)):
                 os.environ["GAMD_PREDICT_LEGACY"] = "1"
             else:
                 os.environ.pop("GAMD_PREDICT_LEGACY", None)
-            for _ in range(20):
+            # (per-call times, median next to the mean: the ROCm runtime stalls ONE call for 50-60 ms somewhere between the 400th and
+            #  the 500th call of a process on this stack — either form —, which a 300-call mean shows as + 0.2 ms)
+            for _ in range(20 if rnd else (600 if n < 1000 else 50)):
                 f = m.predict_forces(p)
             reps = 300 if n < 1000 else 100
-            t0 = time.perf_counter()
+            ts = []
             for k in range(reps):
+                t0 = time.perf_counter()
                 f = m.predict_forces(p + 1e-4 * (k & 1))
-            dt = (time.perf_counter() - t0) / reps
+                ts.append(time.perf_counter() - t0)
             sha = hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest()[:12]
-            print(f"{n:6d} atoms: predict_forces {dt * 1e3:.3f} ms per call ({'three syncs' if legacy else 'pinned, one sync'}; {f.dtype}, {f.shape}, sha {sha})")
+            print(f"{n:6d} atoms: predict_forces p50 {np.median(ts) * 1e3:.3f} ms, mean {np.mean(ts) * 1e3:.3f} ms per call "
+                  f"({'three syncs' if legacy else 'pinned, one sync'}; {f.dtype}, {f.shape}, sha {sha})")
     os.environ.pop("GAMD_PREDICT_LEGACY", None)
