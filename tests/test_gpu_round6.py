@@ -195,6 +195,15 @@ def test_host_buffer_boundary_with_one_synchronisation_gives_the_same_bits():
     with pytest.raises(ValueError, match="pos must be"):
         eng.forward_host(posw[:-1])
     eng.close()
+    # fresh handles driven from a non-blocking side stream from their first call on (the stream contract of include/gamd_hip.h):
+    # the staging copies, the kernels and the one synchronisation all belong to that stream
+    for k in range(8):
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            e2 = GamdForce(sd, n, box, rc, scaler=(g["scaler_mean"], g["scaler_var"]), neighbor_skin=rc / 6.0 if k & 1 else 0.0)
+            assert np.array_equal(e2.forward_host(posw), ref), k
+            assert np.array_equal(e2.forward_host(posw, denormalize=True), den), k
+            e2.close()
     # a batch; a capacity far too small: detected on the device, regrown, replayed inside the one call
     batch = GamdForce(sd, n, box, rc, n_boxes=2, edge_capacity=64)
     two = np.concatenate([posw, np.mod(posw + 0.3, box)])
