@@ -28,8 +28,9 @@ for n, rc in ((258, 7.5), (10000, 10.2)):
                 os.environ["GAMD_PREDICT_LEGACY"] = "1"
             else:
                 os.environ.pop("GAMD_PREDICT_LEGACY", None)
-            # (per-call times, median next to the mean: the ROCm runtime stalls ONE call for 50-60 ms somewhere between the 400th and
-            #  the 500th call of a process on this stack — either form —, which a 300-call mean shows as + 0.2 ms)
+            # (per-call times, median next to the mean: Python's cyclic garbage collector runs its first FULL collection around the
+            #  450th call of a process — 39 ms with torch's object graph loaded, gone with gc.disable() / gc.freeze() —, which a
+            #  300-call mean shows as + 0.13 ms whichever form is running at the time)
             for _ in range(20 if rnd else (600 if n < 1000 else 50)):
                 f = m.predict_forces(p)
             reps = 300 if n < 1000 else 100
